@@ -1,0 +1,102 @@
+// Shared declarations of libalsep's implementation files (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/alsep.h"
+
+// All kernels use dynamic LDS only, through this one 16-byte aligned symbol
+// (cdna_hip_programming.md Guideline 17: no static __shared__ in front of it).
+extern __shared__ __attribute__((aligned(16))) char alsep_smem[];
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct alsep_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
+    int prof_category = 0;
+    std::vector<hipEvent_t> prof_events;     // start/stop pairs
+    size_t prof_used = 0;
+};
+
+// RAII bracket: records a start/stop event pair around the launches of one kernel class when
+// that class is being profiled (alsep_profile_begin); otherwise costs one integer compare.
+struct ProfScope {
+    alsep_ctx* ctx;
+    bool on;
+    ProfScope(alsep_ctx* c, int category) : ctx(c), on(c && c->prof_category == category) {
+        if (!on) return;
+        if (ctx->prof_used + 2 > ctx->prof_events.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            ctx->prof_events.push_back(a);
+            ctx->prof_events.push_back(b);
+        }
+        (void)hipEventRecord(ctx->prof_events[ctx->prof_used], ctx->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(ctx->prof_events[ctx->prof_used + 1], ctx->stream);
+        ctx->prof_used += 2;
+    }
+};
+
+static inline int alsep_fail(alsep_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define ALSEP_HIP(ctx, call)                                                              \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return alsep_fail((ctx), ALSEP_ERR_HIP, "%s failed: %s (%s:%d)", #call,       \
+                              hipGetErrorString(e_), __FILE__, __LINE__);                 \
+    } while (0)
+
+#define ALSEP_LAUNCH_CHECK(ctx, what)                                                     \
+    do {                                                                                  \
+        hipError_t e_ = hipGetLastError();                                                \
+        if (e_ != hipSuccess)                                                             \
+            return alsep_fail((ctx), ALSEP_ERR_HIP, "launch of %s failed: %s", (what),    \
+                              hipGetErrorString(e_));                                     \
+    } while (0)
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+template <typename T> struct dtype_of;
+template <> struct dtype_of<float> { static constexpr int value = ALSEP_F32; };
+template <> struct dtype_of<bf16_t> { static constexpr int value = ALSEP_BF16; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// XCD-aware remap of a linear workgroup id: the dispatcher deals consecutive ids round-robin
+// over the 8 XCDs, so ids b and b+8 share an L2.  Give each XCD a contiguous run of tiles
+// (bijective for any n; cdna_hip_programming.md T1).  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// internal entry points shared between files
+int alsep_plan_tables(alsep_ctx* ctx, alsep_plan* plan);

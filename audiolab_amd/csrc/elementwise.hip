@@ -1,0 +1,220 @@
+// Element-wise and reduction ops of the ensemble stage and the MDX runner (HBM-bound).
+// Reference semantics: modules/separator/stem_separator.py:241-262 (_blend_tracks),
+// :173-239 (_residual_subtract), :415-456 (de-bleed); mdxnet.py:168-173 (denoise average).
+#include "alsep_common.h"
+
+namespace {
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 2048;      // grid-stride above this (cdna_hip_programming.md Guideline 11)
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ void __launch_bounds__(kThreads)
+axpby_kernel(float a, const float* __restrict__ x, float b, float* __restrict__ y, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) {
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        float4 yv = reinterpret_cast<float4*>(y)[i];
+        yv.x = a * xv.x + b * yv.x; yv.y = a * xv.y + b * yv.y;
+        yv.z = a * xv.z + b * yv.z; yv.w = a * xv.w + b * yv.w;
+        reinterpret_cast<float4*>(y)[i] = yv;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) y[i] = a * x[i] + b * y[i];
+}
+
+// |x| >= 0 so the float bit pattern orders like an unsigned integer: one atomicMax per block.
+__global__ void __launch_bounds__(kThreads)
+peak_abs_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out_bits) {
+    float* red = reinterpret_cast<float*>(alsep_smem);
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const float v = fabsf(x[i]);
+        m = v > m ? v : m;                                  // NaN-ignoring like np.max? (np.max propagates; inputs are finite)
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax(out_bits, __float_as_uint(r));
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+scale_by_device_kernel(float* __restrict__ y, int64_t n, float num, const float* __restrict__ den, float floor_) {
+    const float d = *den;
+    const float s = num / (d > floor_ ? d : floor_);
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) y[i] *= s;
+}
+
+// per-block partial sums in double, finished by one block in a fixed order (deterministic)
+__global__ void __launch_bounds__(kThreads)
+dot3_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, double* __restrict__ part) {
+    double* red = reinterpret_cast<double*>(alsep_smem);    // [3][4]
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    double sab = 0, saa = 0, sbb = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const double av = a[i], bv = b[i];
+        sab += av * bv; saa += av * av; sbb += bv * bv;
+    }
+    sab = wave_sum(sab); saa = wave_sum(saa); sbb = wave_sum(sbb);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w] = sab; red[4 + w] = saa; red[8 + w] = sbb; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const double* r = red + 4 * threadIdx.x;
+        part[(int64_t)blockIdx.x * 3 + threadIdx.x] = (r[0] + r[1]) + (r[2] + r[3]);
+    }
+}
+__global__ void __launch_bounds__(64)
+dot3_final_kernel(const double* __restrict__ part, int nblocks, double* __restrict__ out) {
+    if (threadIdx.x < 3) {
+        double s = 0;
+        for (int i = 0; i < nblocks; ++i) s += part[(int64_t)i * 3 + threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+
+// one block per lag; double accumulation
+__global__ void __launch_bounds__(kThreads)
+xcorr_window_kernel(const float* __restrict__ ref, const float* __restrict__ sig, int64_t probe, int max_shift,
+                    double* __restrict__ corr) {
+    double* red = reinterpret_cast<double*>(alsep_smem);
+    const int lag = (int)blockIdx.x - max_shift;
+    const int64_t lo = lag >= 0 ? 0 : -lag;                 // n range so that 0 <= n+lag < probe
+    const int64_t hi = lag >= 0 ? probe - lag : probe;
+    double s = 0;
+    for (int64_t nidx = lo + threadIdx.x; nidx < hi; nidx += kThreads) s += (double)ref[nidx + lag] * (double)sig[nidx];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) corr[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(kThreads)
+shift_subtract_kernel(const float* __restrict__ ref, const float* __restrict__ sig, int64_t len, int lag, float alpha,
+                      float* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < len; i += stride) {
+        const int64_t j = i - lag;
+        const float s = (j >= 0 && j < len) ? sig[j] : 0.f;
+        float r = ref[i] - alpha * s;
+        if (!(fabsf(r) <= 3.4028234e38f)) r = 0.f;          // nan_to_num(nan=0, +-inf=0), stem_separator.py:237-238
+        out[i] = r;
+    }
+}
+
+unsigned grid_for(int64_t n, int per_thread = 1) {
+    int64_t b = ceil_div64(n, (int64_t)kThreads * per_thread);
+    if (b < 1) b = 1;
+    return (unsigned)(b > kMaxBlocks ? kMaxBlocks : b);
+}
+}  // namespace
+
+extern "C" int alsep_abi_version(void) { return ALSEP_ABI_VERSION; }
+
+extern "C" int alsep_create(int device_id, void* hip_stream, alsep_ctx** out) {
+    if (!out || device_id < 0) return ALSEP_ERR_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return ALSEP_ERR_HIP;
+    alsep_ctx* c = new alsep_ctx();
+    c->device = device_id;
+    c->stream = (hipStream_t)hip_stream;
+    *out = c;
+    return ALSEP_OK;
+}
+extern "C" int alsep_destroy(alsep_ctx* ctx) {
+    if (ctx)
+        for (hipEvent_t ev : ctx->prof_events) (void)hipEventDestroy(ev);
+    delete ctx;
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_profile_begin(alsep_ctx* ctx, int category) {
+    if (!ctx || category < 0) return ALSEP_ERR_ARG;
+    ctx->prof_category = category;
+    ctx->prof_used = 0;
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_profile_end(alsep_ctx* ctx, double* total_ms, int64_t* launches) {
+    if (!ctx || !total_ms || !launches) return ALSEP_ERR_ARG;
+    double sum = 0.0;
+    for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
+        ALSEP_HIP(ctx, hipEventSynchronize(ctx->prof_events[i + 1]));
+        float ms = 0.f;
+        ALSEP_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_events[i], ctx->prof_events[i + 1]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (int64_t)(ctx->prof_used / 2);
+    ctx->prof_category = ALSEP_PROF_NONE;
+    ctx->prof_used = 0;
+    return ALSEP_OK;
+}
+extern "C" const char* alsep_last_error(const alsep_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+extern "C" int alsep_axpby(alsep_ctx* ctx, float a, const float* x, float b, float* y, int64_t n) {
+    if (!ctx || !x || !y || n < 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_axpby: bad argument");
+    if (n == 0) return ALSEP_OK;
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_axpby: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 4)), dim3(kThreads), 0, ctx->stream, a, x, b, y, n);
+    ALSEP_LAUNCH_CHECK(ctx, "axpby_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_peak_abs(alsep_ctx* ctx, const float* x, int64_t n, float* out) {
+    if (!ctx || !out || n < 0 || (n > 0 && !x)) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_peak_abs: bad argument");
+    ALSEP_HIP(ctx, hipMemsetAsync(out, 0, sizeof(float), ctx->stream));
+    if (n == 0) return ALSEP_OK;
+    hipLaunchKernelGGL(peak_abs_kernel, dim3(grid_for(n, 8)), dim3(kThreads), 4 * sizeof(float), ctx->stream, x, n, (unsigned*)out);
+    ALSEP_LAUNCH_CHECK(ctx, "peak_abs_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_scale_by_device(alsep_ctx* ctx, float* y, int64_t n, float num, const float* den, float floor_) {
+    if (!ctx || !y || !den || n < 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_scale_by_device: bad argument");
+    if (n == 0) return ALSEP_OK;
+    hipLaunchKernelGGL(scale_by_device_kernel, dim3(grid_for(n, 4)), dim3(kThreads), 0, ctx->stream, y, n, num, den, floor_);
+    ALSEP_LAUNCH_CHECK(ctx, "scale_by_device_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_dot3(alsep_ctx* ctx, const float* a, const float* b, int64_t n, double* dots) {
+    if (!ctx || !a || !b || !dots || n < 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_dot3: bad argument");
+    // partial sums live after the 3 results: caller provides 3 + 3*1024 doubles
+    const unsigned nb = std::min<unsigned>(grid_for(n, 8), 1024u);
+    double* part = dots + 4;
+    hipLaunchKernelGGL(dot3_partial_kernel, dim3(nb), dim3(kThreads), 12 * sizeof(double), ctx->stream, a, b, n, part);
+    hipLaunchKernelGGL(dot3_final_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)part, (int)nb, dots);
+    ALSEP_LAUNCH_CHECK(ctx, "dot3 kernels");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_xcorr_window(alsep_ctx* ctx, const float* ref, const float* sig, int64_t probe, int max_shift, double* corr) {
+    if (!ctx || !ref || !sig || !corr || probe <= 0 || max_shift < 0 || max_shift >= probe)
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_xcorr_window: bad argument");
+    hipLaunchKernelGGL(xcorr_window_kernel, dim3(2 * max_shift + 1), dim3(kThreads), 4 * sizeof(double), ctx->stream,
+                       ref, sig, probe, max_shift, corr);
+    ALSEP_LAUNCH_CHECK(ctx, "xcorr_window_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_shift_subtract(alsep_ctx* ctx, const float* ref, const float* sig, int64_t len, int lag, float alpha, float* out) {
+    if (!ctx || !ref || !sig || !out || len < 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_shift_subtract: bad argument");
+    if (len == 0) return ALSEP_OK;
+    hipLaunchKernelGGL(shift_subtract_kernel, dim3(grid_for(len, 4)), dim3(kThreads), 0, ctx->stream, ref, sig, len, lag, alpha, out);
+    ALSEP_LAUNCH_CHECK(ctx, "shift_subtract_kernel");
+    return ALSEP_OK;
+}

@@ -1,0 +1,525 @@
+// STFT / iSTFT of the MDX front and back end as LDS-resident mixed-radix FFTs (gfx950).
+//
+// Semantics: ConvTDFNetTrim.stft / .istft, reference modules/rvc/infer/modules/uvr5/mdxnet.py:41-75
+// (torch.stft/istft, periodic Hann, center=True, no normalisation).
+//
+// Design
+//  * One workgroup transforms one frame of BOTH stereo channels with a single complex FFT of
+//    n_fft points ("two-for-one": z = xL + i*xR; XL[k] = (Z[k]+conj Z[N-k])/2,
+//    XR[k] = (Z[k]-conj Z[N-k])/(2i)).  The whole transform lives in LDS (n_fft*8 B: 48 KiB at
+//    6144), Stockham auto-sort passes of radix 8/5/4/3/2, one read + one write of the LDS
+//    buffer per pass, radix sequence fixed at compile time per n_fft.
+//  * STFT loads are coalesced float reads of the PCM (each sample is re-read n_fft/hop times,
+//    served from L2); stores in NHWC layout are one 16-byte (f32) or 8-byte (bf16) vector per
+//    bin: [B,T,dim_f,(L_re,L_im,R_re,R_im)].
+//  * iSTFT walks a run of consecutive frames per workgroup, overlap-adds in an LDS ring of
+//    ceil(n_fft/hop) hop-blocks, divides by the exact sum-of-w^2 envelope table (the envelope
+//    ripples when hop does not divide n_fft: 7680/1024) and writes each finished hop-block once,
+//    straight to its final place (chunk trim / stitch fused into the store).
+#include "alsep_common.h"
+
+#include <cmath>
+
+struct alsep_plan {
+    alsep_ctx* ctx = nullptr;
+    int n_fft = 0, hop = 0, dim_f = 0, dim_t = 0;
+    int chunk = 0;
+    float2* tw = nullptr;     // W_N^j = exp(-2*pi*i*j/N), j in [0,N)
+    float* env = nullptr;     // sum_t w^2 over the padded chunk timeline, N + hop*(T-1)
+    int64_t env_len = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// complex helpers + small DFTs (forward, sign -)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cmul_negi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+
+template <int R> __device__ __forceinline__ void dft(float2 (&u)[R]);
+
+template <> __device__ __forceinline__ void dft<2>(float2 (&u)[2]) {
+    float2 a = u[0], b = u[1];
+    u[0] = cadd(a, b);
+    u[1] = csub(a, b);
+}
+template <> __device__ __forceinline__ void dft<3>(float2 (&u)[3]) {
+    const float S = 0.86602540378443864676f;
+    float2 t1 = cadd(u[1], u[2]);
+    float2 t2 = make_float2(u[0].x - 0.5f * t1.x, u[0].y - 0.5f * t1.y);
+    float2 t3 = cscale(csub(u[1], u[2]), S);
+    u[0] = cadd(u[0], t1);
+    u[1] = make_float2(t2.x + t3.y, t2.y - t3.x);
+    u[2] = make_float2(t2.x - t3.y, t2.y + t3.x);
+}
+template <> __device__ __forceinline__ void dft<4>(float2 (&u)[4]) {
+    float2 t0 = cadd(u[0], u[2]), t1 = csub(u[0], u[2]);
+    float2 t2 = cadd(u[1], u[3]), t3 = cmul_negi(csub(u[1], u[3]));
+    u[0] = cadd(t0, t2);
+    u[2] = csub(t0, t2);
+    u[1] = cadd(t1, t3);
+    u[3] = csub(t1, t3);
+}
+template <> __device__ __forceinline__ void dft<5>(float2 (&u)[5]) {
+    const float C1 = 0.30901699437494742410f, C2 = -0.80901699437494742410f;
+    const float S1 = 0.95105651629515357212f, S2 = 0.58778525229247312917f;
+    float2 t1 = cadd(u[1], u[4]), t2 = cadd(u[2], u[3]);
+    float2 t3 = csub(u[1], u[4]), t4 = csub(u[2], u[3]);
+    float2 m1 = make_float2(u[0].x + C1 * t1.x + C2 * t2.x, u[0].y + C1 * t1.y + C2 * t2.y);
+    float2 m2 = make_float2(u[0].x + C2 * t1.x + C1 * t2.x, u[0].y + C2 * t1.y + C1 * t2.y);
+    float2 n1 = make_float2(S1 * t3.x + S2 * t4.x, S1 * t3.y + S2 * t4.y);
+    float2 n2 = make_float2(S2 * t3.x - S1 * t4.x, S2 * t3.y - S1 * t4.y);
+    u[0] = cadd(u[0], cadd(t1, t2));
+    u[1] = make_float2(m1.x + n1.y, m1.y - n1.x);     // m1 - i n1
+    u[4] = make_float2(m1.x - n1.y, m1.y + n1.x);     // m1 + i n1
+    u[2] = make_float2(m2.x + n2.y, m2.y - n2.x);
+    u[3] = make_float2(m2.x - n2.y, m2.y + n2.x);
+}
+template <> __device__ __forceinline__ void dft<8>(float2 (&u)[8]) {
+    const float H = 0.70710678118654752440f;
+    float2 e[4] = {u[0], u[2], u[4], u[6]};
+    float2 o[4] = {u[1], u[3], u[5], u[7]};
+    dft<4>(e);
+    dft<4>(o);
+    float2 o1 = make_float2(H * (o[1].x + o[1].y), H * (o[1].y - o[1].x));      // * (1-i)/sqrt2
+    float2 o2 = cmul_negi(o[2]);                                                 // * (-i)
+    float2 o3 = make_float2(H * (o[3].y - o[3].x), -H * (o[3].x + o[3].y));     // * (-1-i)/sqrt2
+    u[0] = cadd(e[0], o[0]);  u[4] = csub(e[0], o[0]);
+    u[1] = cadd(e[1], o1);    u[5] = csub(e[1], o1);
+    u[2] = cadd(e[2], o2);    u[6] = csub(e[2], o2);
+    u[3] = cadd(e[3], o3);    u[7] = csub(e[3], o3);
+}
+
+// One Stockham pass of radix R over the LDS buffer; P = product of the radices already done.
+// Butterfly i reads buf[i + r*N/R], twiddles by W_{P*R}^{k*r} (k = i mod P) and writes
+// buf[(i-k)*R + k + r*P].  All reads precede all writes (barrier), so one buffer suffices.
+template <int N, int NT, int P, int R>
+__device__ __forceinline__ void fft_pass(float2* buf, const float2* __restrict__ tw, int tid) {
+    constexpr int M = N / R;
+    constexpr int NB = (M + NT - 1) / NT;
+    constexpr int TWS = N / (P * R);
+    float2 u[NB][R];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = tid + b * NT;
+        if (i < M) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[b][r] = buf[i + r * M];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = tid + b * NT;
+        if (i < M) {
+            const int k = i % P;
+            if (P > 1) {
+#pragma unroll
+                for (int r = 1; r < R; ++r) u[b][r] = cmul(u[b][r], tw[k * r * TWS]);
+            }
+            dft<R>(u[b]);
+            const int j = (i - k) * R + k;
+#pragma unroll
+            for (int r = 0; r < R; ++r) buf[j + r * P] = u[b][r];
+        }
+    }
+    __syncthreads();
+}
+
+template <int N, int NT, int P, int... Rs> struct FftRun;
+template <int N, int NT, int P> struct FftRun<N, NT, P> {
+    static __device__ __forceinline__ void run(float2*, const float2*, int) { static_assert(P == N, "radices must multiply to N"); }
+};
+template <int N, int NT, int P, int R0, int... Rs> struct FftRun<N, NT, P, R0, Rs...> {
+    static __device__ __forceinline__ void run(float2* buf, const float2* tw, int tid) {
+        fft_pass<N, NT, P, R0>(buf, tw, tid);
+        FftRun<N, NT, P * R0, Rs...>::run(buf, tw, tid);
+    }
+};
+
+// radix sequences per supported n_fft
+template <int N, int NT> struct Fft;
+#define ALSEP_FFT(N_, ...)                                                                 \
+    template <int NT> struct Fft<N_, NT> {                                                 \
+        static __device__ __forceinline__ void run(float2* buf, const float2* tw, int tid) { \
+            FftRun<N_, NT, 1, __VA_ARGS__>::run(buf, tw, tid);                             \
+        }                                                                                  \
+    };
+ALSEP_FFT(256, 8, 8, 4)
+ALSEP_FFT(384, 8, 8, 2, 3)
+ALSEP_FFT(480, 8, 4, 5, 3)
+ALSEP_FFT(512, 8, 8, 8)
+ALSEP_FFT(1024, 8, 8, 8, 2)
+ALSEP_FFT(2048, 8, 8, 8, 4)
+ALSEP_FFT(4096, 8, 8, 8, 8)
+ALSEP_FFT(6144, 8, 8, 8, 4, 3)
+ALSEP_FFT(7680, 8, 8, 8, 5, 3)
+ALSEP_FFT(8192, 8, 8, 8, 8, 2)
+#undef ALSEP_FFT
+
+#define ALSEP_FOR_EACH_NFFT(X) X(256) X(384) X(480) X(512) X(1024) X(2048) X(4096) X(6144) X(7680) X(8192)
+
+constexpr int kFftThreads = 256;
+
+template <typename OutT> __device__ __forceinline__ void store_spec4(OutT* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store_spec4<float>(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void store_spec4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+    bf16x4 v;
+    v[0] = (bf16_t)a; v[1] = (bf16_t)b; v[2] = (bf16_t)c; v[3] = (bf16_t)d;
+    *reinterpret_cast<bf16x4*>(p) = v;
+}
+template <typename T> __device__ __forceinline__ void load_spec4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load_spec4<float>(const float* p, float (&v)[4]) {
+    float4 q = *reinterpret_cast<const float4*>(p);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+template <> __device__ __forceinline__ void load_spec4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+    bf16x4 q = *reinterpret_cast<const bf16x4*>(p);
+    v[0] = (float)q[0]; v[1] = (float)q[1]; v[2] = (float)q[2]; v[3] = (float)q[3];
+}
+
+// ------------------------------------------------------------------------------------------
+// STFT: grid (T, n_chunks), one frame of both channels per workgroup.
+// ------------------------------------------------------------------------------------------
+template <int N, typename OutT, int LAYOUT>
+__global__ void __launch_bounds__(kFftThreads)
+stft_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_stride, int chunk, int hop,
+            int dim_f, int T, const float2* __restrict__ tw, OutT* __restrict__ spec) {
+    constexpr int NT = kFftThreads;
+    float2* buf = reinterpret_cast<float2*>(alsep_smem);
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    const float* xl = pcm + b * chunk_stride;
+    const float* xr = xl + ch_stride;
+    const int p0 = t * hop - N / 2;
+    for (int n = tid; n < N; n += NT) {
+        int p = p0 + n;
+        if (p < 0) p = -p;                                   // reflect (center=True)
+        if (p >= chunk) p = 2 * (chunk - 1) - p;
+        const float w = 0.5f - 0.5f * tw[n].x;               // periodic Hann = (1 - cos(2 pi n/N))/2
+        buf[n] = make_float2(xl[p] * w, xr[p] * w);
+    }
+    __syncthreads();
+    Fft<N, NT>::run(buf, tw, tid);
+    for (int k = tid; k < dim_f; k += NT) {
+        const float2 zk = buf[k];
+        const float2 zn = buf[k == 0 ? 0 : N - k];
+        const float lre = 0.5f * (zk.x + zn.x), lim = 0.5f * (zk.y - zn.y);
+        const float rre = 0.5f * (zk.y + zn.y), rim = -0.5f * (zk.x - zn.x);
+        if (LAYOUT == ALSEP_LAYOUT_NHWC) {
+            store_spec4<OutT>(spec + ((b * T + t) * (int64_t)dim_f + k) * 4, lre, lim, rre, rim);
+        } else {
+            const int64_t plane = (int64_t)dim_f * T;
+            OutT* o = spec + b * 4 * plane + (int64_t)k * T + t;
+            o[0] = from_f32<OutT>(lre);
+            o[plane] = from_f32<OutT>(lim);
+            o[2 * plane] = from_f32<OutT>(rre);
+            o[3 * plane] = from_f32<OutT>(rim);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// iSTFT + overlap-add + envelope divide + trim/stitch store.
+// grid (n_groups, n_chunks); each workgroup finishes `run` consecutive hop-blocks.
+// LDS: buf[N] (FFT) + ring[Q*hop] (OLA accumulator, float2 = both channels), Q = ceil(N/hop).
+// ------------------------------------------------------------------------------------------
+template <int N, typename InT, int LAYOUT>
+__global__ void __launch_bounds__(kFftThreads)
+istft_kernel(const InT* __restrict__ spec, int hop, int dim_f, int T, const float2* __restrict__ tw,
+             const float* __restrict__ env, int j_lo, int j_hi, int run, float* __restrict__ out,
+             int64_t out_ch_stride, int64_t out_chunk_stride, int64_t keep_lo, int64_t keep_hi,
+             int64_t out_limit) {
+    constexpr int NT = kFftThreads;
+    float2* buf = reinterpret_cast<float2*>(alsep_smem);
+    float2* ring = buf + N;
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.y;
+    const int Q = (N + hop - 1) / hop;
+    const int RN = Q * hop;
+    const int j0 = j_lo + blockIdx.x * run;
+    const int j1 = min(j0 + run, j_hi);
+    if (j0 >= j1) return;
+    for (int i = tid; i < RN; i += NT) ring[i] = make_float2(0.f, 0.f);
+    const float inv_n = 1.0f / (float)N;
+    const int t_start = max(0, j0 - Q + 1);
+    for (int t = t_start; t < j1; ++t) {
+        if (t < T) {
+            // conj(Z) with Z[k] = XL[k] + i XR[k], Hermitian-extended; bins >= dim_f are zero.
+            for (int k = tid; k <= N / 2; k += NT) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (k < dim_f) {
+                    if (LAYOUT == ALSEP_LAYOUT_NHWC) {
+                        load_spec4<InT>(spec + ((b * T + t) * (int64_t)dim_f + k) * 4, v);
+                    } else {
+                        const int64_t plane = (int64_t)dim_f * T;
+                        const InT* s = spec + b * 4 * plane + (int64_t)k * T + t;
+                        v[0] = to_f32(s[0]); v[1] = to_f32(s[plane]);
+                        v[2] = to_f32(s[2 * plane]); v[3] = to_f32(s[3 * plane]);
+                    }
+                }
+                if (k == 0 || k == N / 2) {                  // c2r ignores Im of DC / Nyquist
+                    buf[k] = make_float2(v[0], -v[2]);
+                } else {
+                    buf[k] = make_float2(v[0] - v[3], -(v[1] + v[2]));
+                    buf[N - k] = make_float2(v[0] + v[3], v[1] - v[2]);
+                }
+            }
+            __syncthreads();
+            Fft<N, NT>::run(buf, tw, tid);
+            const int base = (t % Q) * hop;                  // (t*hop) mod RN
+            for (int n = tid; n < N; n += NT) {
+                const float w = (0.5f - 0.5f * tw[n].x) * inv_n;
+                int r = base + n;
+                if (r >= RN) r -= RN;
+                float2 a = ring[r];
+                a.x += w * buf[n].x;                         // z = conj(buf)/N
+                a.y -= w * buf[n].y;
+                ring[r] = a;
+            }
+            __syncthreads();
+        }
+        // hop-block j = t is complete: every frame covering it (t-Q+1..t) has been added.
+        const int slot = (t % Q) * hop;
+        if (t >= j0) {
+            const int64_t p_base = (int64_t)t * hop;
+            for (int i = tid; i < hop; i += NT) {
+                const int64_t p = p_base + i;
+                const int64_t s = p - N / 2;
+                if (s >= keep_lo && s < keep_hi) {
+                    const int64_t o = b * out_chunk_stride + (s - keep_lo);
+                    if (o < out_limit) {
+                        const float e = 1.0f / env[p];
+                        const float2 a = ring[slot + i];
+                        out[o] = a.x * e;
+                        out[out_ch_stride + o] = a.y * e;
+                    }
+                }
+            }
+        }
+        for (int i = tid; i < hop; i += NT) ring[slot + i] = make_float2(0.f, 0.f);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// layout conversion REF [B,4,F,T] <-> NHWC [B,T,F,4] via 32x32 LDS tiles (coalesced both ways)
+// ------------------------------------------------------------------------------------------
+template <typename T, int TO_NHWC>
+__global__ void __launch_bounds__(256)
+spec_convert_kernel(const T* __restrict__ src, T* __restrict__ dst, int F, int Tn) {
+    T* tile = reinterpret_cast<T*>(alsep_smem);             // [4][32][33]
+    const int64_t b = blockIdx.z;
+    const int f0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int64_t plane = (int64_t)F * Tn;
+    if (TO_NHWC) {
+        for (int c = 0; c < 4; ++c)
+            for (int r = ty; r < 32; r += 8) {               // r: f within tile, tx: t within tile
+                const int f = f0 + r, t = t0 + tx;
+                if (f < F && t < Tn) tile[(c * 32 + r) * 33 + tx] = src[(b * 4 + c) * plane + (int64_t)f * Tn + t];
+            }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {                   // r: t within tile; tx: f within tile
+            const int f = f0 + tx, t = t0 + r;
+            if (f < F && t < Tn) {
+                T* o = dst + ((b * Tn + t) * (int64_t)F + f) * 4;
+                for (int c = 0; c < 4; ++c) o[c] = tile[(c * 32 + tx) * 33 + r];
+            }
+        }
+    } else {
+        for (int r = ty; r < 32; r += 8) {
+            const int f = f0 + tx, t = t0 + r;
+            if (f < F && t < Tn) {
+                const T* s = src + ((b * Tn + t) * (int64_t)F + f) * 4;
+                for (int c = 0; c < 4; ++c) tile[(c * 32 + tx) * 33 + r] = s[c];
+            }
+        }
+        __syncthreads();
+        for (int c = 0; c < 4; ++c)
+            for (int r = ty; r < 32; r += 8) {
+                const int f = f0 + r, t = t0 + tx;
+                if (f < F && t < Tn) dst[(b * 4 + c) * plane + (int64_t)f * Tn + t] = tile[(c * 32 + r) * 33 + tx];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+extern "C" int alsep_plan_supported_nfft(int n_fft) {
+    switch (n_fft) {
+#define X(N_) case N_:
+        ALSEP_FOR_EACH_NFFT(X)
+#undef X
+        return 1;
+        default: return 0;
+    }
+}
+
+extern "C" int alsep_plan_create(alsep_ctx* ctx, int n_fft, int hop, int dim_f, int dim_t, alsep_plan** out) {
+    if (!ctx || !out) return ALSEP_ERR_ARG;
+    if (!alsep_plan_supported_nfft(n_fft)) return alsep_fail(ctx, ALSEP_ERR_ARG, "n_fft=%d has no FFT kernel", n_fft);
+    if (hop <= 0 || hop > n_fft || dim_t < 2 || dim_f < 1 || dim_f > n_fft / 2 + 1)
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "bad STFT geometry n_fft=%d hop=%d dim_f=%d dim_t=%d", n_fft, hop, dim_f, dim_t);
+    const int64_t chunk = (int64_t)hop * (dim_t - 1);
+    if (chunk <= n_fft / 2)     // torch.stft's reflect padding needs pad < length
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "chunk %lld must exceed n_fft/2=%d", (long long)chunk, n_fft / 2);
+    const int Q = (n_fft + hop - 1) / hop;
+    if ((size_t)(n_fft + Q * hop) * sizeof(float2) > 160 * 1024)
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "n_fft=%d hop=%d needs more than 160 KiB of LDS", n_fft, hop);
+    alsep_plan* p = new alsep_plan();
+    p->ctx = ctx; p->n_fft = n_fft; p->hop = hop; p->dim_f = dim_f; p->dim_t = dim_t; p->chunk = (int)chunk;
+    std::vector<float2> tw(n_fft);
+    std::vector<double> w2(n_fft);
+    for (int j = 0; j < n_fft; ++j) {
+        const double a = -2.0 * M_PI * (double)j / (double)n_fft;
+        tw[j] = make_float2((float)cos(a), (float)sin(a));
+        const double w = 0.5 - 0.5 * cos(2.0 * M_PI * (double)j / (double)n_fft);
+        w2[j] = w * w;
+    }
+    p->env_len = (int64_t)n_fft + (int64_t)hop * (dim_t - 1);
+    std::vector<double> envd(p->env_len, 0.0);
+    for (int t = 0; t < dim_t; ++t)
+        for (int n = 0; n < n_fft; ++n) envd[(int64_t)t * hop + n] += w2[n];
+    std::vector<float> env(p->env_len);
+    for (int64_t i = 0; i < p->env_len; ++i) env[i] = (float)envd[i];
+    if (hipMalloc((void**)&p->tw, sizeof(float2) * n_fft) != hipSuccess ||
+        hipMalloc((void**)&p->env, sizeof(float) * p->env_len) != hipSuccess) {
+        alsep_plan_destroy(p);
+        return alsep_fail(ctx, ALSEP_ERR_NOMEM, "plan tables: hipMalloc failed");
+    }
+    // blocking copies on purpose: the host vectors die at return
+    ALSEP_HIP(ctx, hipMemcpy(p->tw, tw.data(), sizeof(float2) * n_fft, hipMemcpyHostToDevice));
+    ALSEP_HIP(ctx, hipMemcpy(p->env, env.data(), sizeof(float) * p->env_len, hipMemcpyHostToDevice));
+    *out = p;
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_plan_destroy(alsep_plan* plan) {
+    if (!plan) return ALSEP_OK;
+    if (plan->tw) (void)hipFree(plan->tw);
+    if (plan->env) (void)hipFree(plan->env);
+    delete plan;
+    return ALSEP_OK;
+}
+
+template <int N, typename OutT, int LAYOUT>
+static int launch_stft(alsep_ctx* ctx, const alsep_plan* p, const float* pcm, int64_t ch_stride,
+                       int64_t chunk_stride, int64_t n_chunks, void* spec) {
+    const size_t lds = sizeof(float2) * N;
+    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)stft_kernel<N, OutT, LAYOUT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope prof(ctx, ALSEP_PROF_STFT);
+    // grid.y is limited to 65535: split long batches
+    for (int64_t b0 = 0; b0 < n_chunks; b0 += 32768) {
+        const int64_t nb = std::min<int64_t>(32768, n_chunks - b0);
+        const int64_t spec_off = b0 * 4 * (int64_t)p->dim_f * p->dim_t;
+        hipLaunchKernelGGL((stft_kernel<N, OutT, LAYOUT>), dim3(p->dim_t, (unsigned)nb), dim3(kFftThreads), lds,
+                           ctx->stream, pcm + b0 * chunk_stride, ch_stride, chunk_stride, p->chunk, p->hop,
+                           p->dim_f, p->dim_t, (const float2*)p->tw, (OutT*)spec + spec_off);
+    }
+    ALSEP_LAUNCH_CHECK(ctx, "stft_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_stft(alsep_ctx* ctx, const alsep_plan* plan, const float* pcm, int64_t ch_stride,
+                          int64_t chunk_stride, int64_t n_chunks, void* spec, int dtype, int layout) {
+    if (!ctx || !plan || !pcm || !spec) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_stft: null argument");
+    if (n_chunks == 0) return ALSEP_OK;
+    if (n_chunks < 0 || (dtype != ALSEP_F32 && dtype != ALSEP_BF16) ||
+        (layout != ALSEP_LAYOUT_REF && layout != ALSEP_LAYOUT_NHWC))
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_stft: bad n_chunks/dtype/layout");
+#define X(N_)                                                                                          \
+    if (plan->n_fft == N_) {                                                                           \
+        if (dtype == ALSEP_F32)                                                                        \
+            return layout == ALSEP_LAYOUT_NHWC                                                         \
+                       ? launch_stft<N_, float, ALSEP_LAYOUT_NHWC>(ctx, plan, pcm, ch_stride, chunk_stride, n_chunks, spec) \
+                       : launch_stft<N_, float, ALSEP_LAYOUT_REF>(ctx, plan, pcm, ch_stride, chunk_stride, n_chunks, spec); \
+        return layout == ALSEP_LAYOUT_NHWC                                                             \
+                   ? launch_stft<N_, bf16_t, ALSEP_LAYOUT_NHWC>(ctx, plan, pcm, ch_stride, chunk_stride, n_chunks, spec) \
+                   : launch_stft<N_, bf16_t, ALSEP_LAYOUT_REF>(ctx, plan, pcm, ch_stride, chunk_stride, n_chunks, spec); \
+    }
+    ALSEP_FOR_EACH_NFFT(X)
+#undef X
+    return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_stft: unsupported n_fft %d", plan->n_fft);
+}
+
+constexpr int kIstftRun = 32;   // hop-blocks finished per workgroup (warm-up = ceil(N/hop)-1 frames)
+
+template <int N, typename InT, int LAYOUT>
+static int launch_istft(alsep_ctx* ctx, const alsep_plan* p, const void* spec, int64_t n_chunks, float* out,
+                        int64_t out_ch_stride, int64_t out_chunk_stride, int64_t keep_lo, int64_t keep_hi,
+                        int64_t out_limit) {
+    const int Q = (N + p->hop - 1) / p->hop;
+    const size_t lds = sizeof(float2) * (size_t)(N + Q * p->hop);
+    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)istft_kernel<N, InT, LAYOUT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int j_lo = (int)((keep_lo + N / 2) / p->hop);
+    const int j_hi = (int)((keep_hi - 1 + N / 2) / p->hop) + 1;
+    const int groups = (j_hi - j_lo + kIstftRun - 1) / kIstftRun;
+    ProfScope prof(ctx, ALSEP_PROF_ISTFT);
+    for (int64_t b0 = 0; b0 < n_chunks; b0 += 32768) {
+        const int64_t nb = std::min<int64_t>(32768, n_chunks - b0);
+        const int64_t spec_off = b0 * 4 * (int64_t)p->dim_f * p->dim_t;
+        hipLaunchKernelGGL((istft_kernel<N, InT, LAYOUT>), dim3(groups, (unsigned)nb), dim3(kFftThreads), lds,
+                           ctx->stream, (const InT*)spec + spec_off, p->hop, p->dim_f, p->dim_t,
+                           (const float2*)p->tw, (const float*)p->env, j_lo, j_hi, kIstftRun,
+                           out + b0 * out_chunk_stride, out_ch_stride, out_chunk_stride, keep_lo, keep_hi,
+                           out_limit - b0 * out_chunk_stride);
+    }
+    ALSEP_LAUNCH_CHECK(ctx, "istft_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_istft(alsep_ctx* ctx, const alsep_plan* plan, const void* spec, int dtype, int layout,
+                           int64_t n_chunks, float* out, int64_t out_ch_stride, int64_t out_chunk_stride,
+                           int64_t keep_lo, int64_t keep_hi, int64_t out_limit) {
+    if (!ctx || !plan || !spec || !out) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_istft: null argument");
+    if (n_chunks == 0) return ALSEP_OK;
+    if (n_chunks < 0 || keep_lo < 0 || keep_hi > plan->chunk || keep_lo >= keep_hi || out_limit <= 0 ||
+        (dtype != ALSEP_F32 && dtype != ALSEP_BF16) || (layout != ALSEP_LAYOUT_REF && layout != ALSEP_LAYOUT_NHWC))
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_istft: bad argument");
+#define X(N_)                                                                                          \
+    if (plan->n_fft == N_) {                                                                           \
+        if (dtype == ALSEP_F32)                                                                        \
+            return layout == ALSEP_LAYOUT_NHWC                                                         \
+                       ? launch_istft<N_, float, ALSEP_LAYOUT_NHWC>(ctx, plan, spec, n_chunks, out, out_ch_stride, out_chunk_stride, keep_lo, keep_hi, out_limit) \
+                       : launch_istft<N_, float, ALSEP_LAYOUT_REF>(ctx, plan, spec, n_chunks, out, out_ch_stride, out_chunk_stride, keep_lo, keep_hi, out_limit); \
+        return layout == ALSEP_LAYOUT_NHWC                                                             \
+                   ? launch_istft<N_, bf16_t, ALSEP_LAYOUT_NHWC>(ctx, plan, spec, n_chunks, out, out_ch_stride, out_chunk_stride, keep_lo, keep_hi, out_limit) \
+                   : launch_istft<N_, bf16_t, ALSEP_LAYOUT_REF>(ctx, plan, spec, n_chunks, out, out_ch_stride, out_chunk_stride, keep_lo, keep_hi, out_limit); \
+    }
+    ALSEP_FOR_EACH_NFFT(X)
+#undef X
+    return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_istft: unsupported n_fft %d", plan->n_fft);
+}
+
+extern "C" int alsep_spec_convert(alsep_ctx* ctx, const void* src, void* dst, int dtype, int src_layout,
+                                  int64_t B, int64_t dim_f, int64_t T) {
+    if (!ctx || !src || !dst) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_spec_convert: null argument");
+    if (B == 0) return ALSEP_OK;
+    if (B < 0 || B > 65535 || dim_f <= 0 || T <= 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_spec_convert: bad shape");
+    dim3 grid((unsigned)ceil_div64(dim_f, 32), (unsigned)ceil_div64(T, 32), (unsigned)B);
+    const bool to_nhwc = src_layout == ALSEP_LAYOUT_REF;
+    if (dtype == ALSEP_F32) {
+        const size_t lds = 4 * 32 * 33 * sizeof(float);
+        if (to_nhwc) hipLaunchKernelGGL((spec_convert_kernel<float, 1>), grid, dim3(256), lds, ctx->stream, (const float*)src, (float*)dst, (int)dim_f, (int)T);
+        else hipLaunchKernelGGL((spec_convert_kernel<float, 0>), grid, dim3(256), lds, ctx->stream, (const float*)src, (float*)dst, (int)dim_f, (int)T);
+    } else if (dtype == ALSEP_BF16) {
+        const size_t lds = 4 * 32 * 33 * sizeof(bf16_t);
+        if (to_nhwc) hipLaunchKernelGGL((spec_convert_kernel<bf16_t, 1>), grid, dim3(256), lds, ctx->stream, (const bf16_t*)src, (bf16_t*)dst, (int)dim_f, (int)T);
+        else hipLaunchKernelGGL((spec_convert_kernel<bf16_t, 0>), grid, dim3(256), lds, ctx->stream, (const bf16_t*)src, (bf16_t*)dst, (int)dim_f, (int)T);
+    } else {
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_spec_convert: bad dtype");
+    }
+    ALSEP_LAUNCH_CHECK(ctx, "spec_convert_kernel");
+    return ALSEP_OK;
+}

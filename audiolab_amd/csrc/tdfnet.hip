@@ -1,0 +1,838 @@
+// TFC-TDF U-Net ("ConvTDFNet", MDX-Net) forward on gfx950: MFMA implicit-GEMM convolutions,
+// TDF linears as MFMA GEMMs, fused BatchNorm/ReLU/skip/residual epilogues.
+//
+// What it replaces: the ONNX network executed per chunk through MDXSeparator.model_run
+// (reference handlers/patch_separate.py:52,58-62; loaded at modules/separator/stem_separator.py:394,512).
+// Topology: see oracle/tdfnet_oracle.py (published KUIELab TFC-TDF v2; parity unpinned).
+//
+// Activation layout: channels-last [B, T, F, C] ("NHWC"; T = frames, F = bins).  A lane's
+// 16-byte k-group is then 8 (bf16) / 4 (f32) consecutive input channels of one pixel/tap, so
+// the 3x3 convolution is an implicit GEMM over K = (tap, ci) with no im2col buffer: the halo
+// patch of a 256-pixel tile sits in LDS once and all 9 taps read it.
+//   conv3x3 : D[co][pixel]  = sum_{tap,ci} W[co][tap,ci] * patch[pixel+tap][ci]
+//   ds 2x2/2: D[co][pixel'] = sum_{dy,dx,ci} W * X[2t'+dy][2f'+dx][ci]           (K = 4c, two runs of 2c)
+//   us 2x2^T: D[(dy,dx,co)][pixel'] = sum_ci W * X[pixel'][ci]; store scatters to (2t'+dy, 2f'+dx), * skip
+//   TDF     : D[c][f'] = sum_f X[bt][f][c] * W[f'][f]        (activations are the A operand;
+//             their k axis is strided in memory, so the stage transposes through LDS)
+// Weights are always the operand with rows = output features; the epilogue therefore holds
+// 4 consecutive output channels per lane and stores them as one 8/16-byte vector.
+#include "mma.h"
+
+#include <map>
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ------------------------------------------------------------------------------------------
+// first 1x1 conv (4 -> g) + BN + ReLU, and final 1x1 conv (c -> 4) + bias: memory-bound VALU.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+first_conv_kernel(const T* __restrict__ X, T* __restrict__ Y, const float* __restrict__ W,
+                  const float* __restrict__ scale, const float* __restrict__ shift, int64_t npix, int g,
+                  float in_scale) {
+    const int q = g >> 2;                                     // groups of 4 output channels
+    const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= npix * q) return;
+    const int64_t p = idx / q;
+    const int co = (int)(idx % q) * 4;
+    float x[4];
+    load4(X + p * 4, x);
+    float y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float* w = W + (co + r) * 4;
+        float a = w[0] * x[0];
+        a = fmaf(w[1], x[1], a);
+        a = fmaf(w[2], x[2], a);
+        a = fmaf(w[3], x[3], a);
+        y[r] = fmaxf(fmaf(a * in_scale, scale[co + r], shift[co + r]), 0.f);
+    }
+    store4(Y + p * g + co, y);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+final_conv_kernel(const T* __restrict__ X, T* __restrict__ Y, const float* __restrict__ W,
+                  const float* __restrict__ bias, int64_t npix, int c, float alpha, float beta) {
+    const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (p >= npix) return;
+    float y[4] = {bias[0], bias[1], bias[2], bias[3]};
+    for (int ci = 0; ci < c; ci += 4) {
+        float x[4];
+        load4(X + p * c + ci, x);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* w = W + r * c + ci;
+            y[r] = fmaf(w[0], x[0], y[r]);
+            y[r] = fmaf(w[1], x[1], y[r]);
+            y[r] = fmaf(w[2], x[2], y[r]);
+            y[r] = fmaf(w[3], x[3], y[r]);
+        }
+    }
+    if (beta != 0.f) {                                      // Y = alpha * net + beta * Y (denoise average)
+        float o[4];
+        load4(Y + p * 4, o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = fmaf(alpha, y[r], beta * o[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] *= alpha;
+    }
+    store4(Y + p * 4, y);
+}
+
+// ------------------------------------------------------------------------------------------
+// 3x3 convolution (pad 1) + scale/shift + ReLU.
+// Tile: 256 output pixels (TH x TW) x BN output channels per workgroup; 4 waves, wave w owns
+// pixels [64w, 64w+64) of the tile.  K loop over chunks of KC input channels: the halo patch
+// chunk [(TH+2)(TW+2)][KC] and the packed weight block [BN][9*KC] are staged in LDS.
+// ------------------------------------------------------------------------------------------
+template <typename T, int KC, int BN, int TW>
+struct ConvCfg {
+    static constexpr int G = Frag<T>::G;
+    static constexpr int TH = 256 / TW;
+    static constexpr int PW = TW + 2, PH = TH + 2;
+    static constexpr int CG = KC / G;                  // k-groups per pixel per chunk
+    static constexpr int KCP = KC + G;                 // padded pixel stride (odd in 16-B units)
+    static constexpr int NG = 9 * CG;                  // k-groups per chunk
+    static constexpr int NS = (NG + 3) / 4;            // k-steps per chunk
+    static constexpr int KP = NS * 4 * G + G;          // padded weight row stride
+    static constexpr int MR = BN / 16;
+    static constexpr size_t lds_bytes = sizeof(T) * ((size_t)PH * PW * KCP + (size_t)BN * KP);
+    static_assert(KC % G == 0 && BN % 16 == 0 && 256 % TW == 0 && TW % 16 == 0, "bad conv tile");
+};
+
+template <typename T, int KC, int BN, int TW>
+__global__ void __launch_bounds__(kThreads)
+conv3x3_kernel(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict__ Wp,
+               const float* __restrict__ scale, const float* __restrict__ shift, int Th, int Fw, int Cin,
+               int Cout, int tiles_t, int tiles_f, int ntiles) {
+    typedef ConvCfg<T, KC, BN, TW> Cf;
+    constexpr int G = Cf::G;
+    T* patch = reinterpret_cast<T*>(alsep_smem);
+    T* wts = patch + (size_t)Cf::PH * Cf::PW * Cf::KCP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    int tile = xcd_remap(blockIdx.x, ntiles);
+    const int tf = tile % tiles_f;  tile /= tiles_f;
+    const int tt = tile % tiles_t;
+    const int64_t b = tile / tiles_t;
+    const int t0 = tt * Cf::TH, f0 = tf * TW;
+    const int ny = blockIdx.y;
+    const int nq = Cin / KC;
+
+    int pbase[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int pm = wave * 64 + ni * 16 + l15;
+        pbase[ni] = ((pm / TW) * Cf::PW + (pm % TW)) * Cf::KCP;
+    }
+    f32x4 acc[Cf::MR][4];
+#pragma unroll
+    for (int mi = 0; mi < Cf::MR; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const T* xb = X + b * (int64_t)Th * Fw * Cin;
+    for (int q = 0; q < nq; ++q) {
+        __syncthreads();                                     // previous chunk's reads are done
+        for (int it = tid; it < Cf::PH * Cf::PW * Cf::CG; it += kThreads) {
+            const int pix = it / Cf::CG, g = it % Cf::CG;
+            const int t = t0 - 1 + pix / Cf::PW, f = f0 - 1 + pix % Cf::PW;
+            vec16 v = zero16();
+            if (t >= 0 && t < Th && f >= 0 && f < Fw)
+                v = *reinterpret_cast<const vec16*>(xb + ((int64_t)t * Fw + f) * Cin + q * KC + g * G);
+            *reinterpret_cast<vec16*>(patch + pix * Cf::KCP + g * G) = v;
+        }
+        const T* wsrc = Wp + ((int64_t)ny * nq + q) * BN * Cf::KP;
+        for (int it = tid; it < BN * Cf::KP / G; it += kThreads)
+            *reinterpret_cast<vec16*>(wts + it * G) = *reinterpret_cast<const vec16*>(wsrc + it * G);
+        __syncthreads();
+#pragma unroll 2
+        for (int s = 0; s < Cf::NS; ++s) {
+            const int grp = 4 * s + lq;
+            const int gc = grp < Cf::NG ? grp : Cf::NG - 1;   // padded groups: weights are zero there
+            const int tap = gc / Cf::CG, cg = gc % Cf::CG;
+            const int koff = ((tap / 3) * Cf::PW + (tap % 3)) * Cf::KCP + cg * G;
+            typename Frag<T>::type xf[4], wf[Cf::MR];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) xf[ni] = lds_frag<T>(patch + pbase[ni] + koff);
+#pragma unroll
+            for (int mi = 0; mi < Cf::MR; ++mi) wf[mi] = lds_frag<T>(wts + (mi * 16 + l15) * Cf::KP + grp * G);
+#pragma unroll
+            for (int mi = 0; mi < Cf::MR; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) mma_step(acc[mi][ni], wf[mi], xf[ni]);
+        }
+    }
+    // epilogue: lane holds channels co..co+3 (rows 4*lq+r) of pixel column l15
+    T* yb = Y + b * (int64_t)Th * Fw * Cout;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int pm = wave * 64 + ni * 16 + l15;
+        const int t = t0 + pm / TW, f = f0 + pm % TW;
+        if (t < Th && f < Fw) {
+#pragma unroll
+            for (int mi = 0; mi < Cf::MR; ++mi) {
+                const int co = ny * BN + mi * 16 + 4 * lq;
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[mi][ni][r], scale[co + r], shift[co + r]), 0.f);
+                store4(yb + ((int64_t)t * Fw + f) * Cout + co, y);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic tile GEMM: 64 weight rows x 128 activation columns per workgroup, BK = 8 k-groups.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct GemmCfg {
+    static constexpr int G = Frag<T>::G;
+    static constexpr int BR = 64, BC = 128;
+    static constexpr int KG = 8;                        // k-groups per tile (2 k-steps)
+    static constexpr int BK = KG * G;
+    static constexpr int LD = BK + G;                   // padded LDS row stride (9 groups: odd)
+    static constexpr size_t lds_bytes = sizeof(T) * (size_t)(BR + BC) * LD;
+};
+
+template <typename T, bool W_IS_A>
+__device__ __forceinline__ void gemm_tile_compute(const T* Ws, const T* Xs, f32x4 (&acc)[4][2], int wave, int l15, int lq) {
+    typedef GemmCfg<T> Gc;
+#pragma unroll
+    for (int ks = 0; ks < Gc::KG / 4; ++ks) {
+        typename Frag<T>::type wf[4], xf[2];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) wf[mi] = lds_frag<T>(Ws + (mi * 16 + l15) * Gc::LD + (ks * 4 + lq) * Gc::G);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) xf[ni] = lds_frag<T>(Xs + (wave * 32 + ni * 16 + l15) * Gc::LD + (ks * 4 + lq) * Gc::G);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                if (W_IS_A) mma_step(acc[mi][ni], wf[mi], xf[ni]);
+                else mma_step(acc[mi][ni], xf[ni], wf[mi]);
+            }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_weights(T* Ws, const T* __restrict__ Wp, int row0, int k0, int Kp, int tid) {
+    typedef GemmCfg<T> Gc;
+    for (int it = tid; it < Gc::BR * Gc::KG; it += kThreads) {
+        const int r = it / Gc::KG, g = it % Gc::KG;
+        *reinterpret_cast<vec16*>(Ws + r * Gc::LD + g * Gc::G) =
+            *reinterpret_cast<const vec16*>(Wp + (int64_t)(row0 + r) * Kp + k0 + g * Gc::G);
+    }
+}
+
+enum { PIX_DS = 0, PIX_US = 1 };
+
+// ds: X [B,2T',2F',C] -> Y [B,T',F',M], K = 4C;  us: X [B,T',F',K] -> Y [B,2T',2F',C2] * skip, M = 4*C2.
+template <typename T, int MODE>
+__global__ void __launch_bounds__(kThreads)
+pix_gemm_kernel(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict__ Wp,
+                const float* __restrict__ scale, const float* __restrict__ shift, const T* __restrict__ skip,
+                int M, int K, int Kp, int64_t ncols, int Tp, int Fp, int C, int C2) {
+    typedef GemmCfg<T> Gc;
+    constexpr int G = Gc::G;
+    T* Ws = reinterpret_cast<T*>(alsep_smem);
+    T* Xs = Ws + Gc::BR * Gc::LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int64_t col0 = (int64_t)blockIdx.x * Gc::BC;
+    const int row0 = blockIdx.y * Gc::BR;
+
+    // this thread stages k-group (tid % 8) of columns tid/8 + 32*j, j < 4
+    int64_t cbase[4];
+    bool cvalid[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t col = col0 + tid / Gc::KG + 32 * j;
+        cvalid[j] = col < ncols;
+        if (MODE == PIX_DS) {
+            const int64_t fp = col % Fp, tp = (col / Fp) % Tp, bb = col / ((int64_t)Fp * Tp);
+            cbase[j] = ((bb * 2 * Tp + 2 * tp) * (2 * (int64_t)Fp) + 2 * fp) * C;
+        } else {
+            cbase[j] = col * K;
+        }
+    }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < Kp; k0 += Gc::BK) {
+        __syncthreads();
+        stage_weights<T>(Ws, Wp, row0, k0, Kp, tid);
+        const int k = k0 + (tid % Gc::KG) * G;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            vec16 v = zero16();
+            if (cvalid[j] && k < K) {
+                int64_t off = k;
+                if (MODE == PIX_DS) {                        // two contiguous runs of 2C (dy = 0, 1)
+                    const int seg = 2 * C;
+                    off = (int64_t)(k / seg) * (2 * (int64_t)Fp * C) + (k % seg);
+                }
+                v = *reinterpret_cast<const vec16*>(X + cbase[j] + off);
+            }
+            *reinterpret_cast<vec16*>(Xs + (tid / Gc::KG + 32 * j) * Gc::LD + (tid % Gc::KG) * G) = v;
+        }
+        __syncthreads();
+        gemm_tile_compute<T, true>(Ws, Xs, acc, wave, l15, lq);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int64_t col = col0 + wave * 32 + ni * 16 + l15;
+        if (col >= ncols) continue;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int row = row0 + mi * 16 + 4 * lq;
+            if (row >= M) continue;
+            float y[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[mi][ni][r], scale[row + r], shift[row + r]), 0.f);
+            if (MODE == PIX_DS) {
+                store4(Y + col * M + row, y);
+            } else {
+                const int d = row / C2, co = row % C2;
+                const int64_t fp = col % Fp, tp = (col / Fp) % Tp, bb = col / ((int64_t)Fp * Tp);
+                const int64_t o = ((bb * 2 * Tp + 2 * tp + (d >> 1)) * (2 * (int64_t)Fp) + 2 * fp + (d & 1)) * C2 + co;
+                float s[4];
+                load4(skip + o, s);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] *= s[r];
+                store4(Y + o, y);
+            }
+        }
+    }
+}
+
+// TDF linear over the F axis: Y[bt][f'][c] = act(scale[c]*(sum_f W[f'][f] X[bt][f][c] + bias[f']) + shift[c]) (+ R)
+// columns are "units" of 16 channels of one (b,t): unit u -> bt = u / (C/16), c0 = 16*(u % (C/16)).
+template <typename T, bool RESIDUAL>
+__global__ void __launch_bounds__(kThreads)
+tdf_gemm_kernel(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict__ Wp,
+                const float* __restrict__ bias, const float* __restrict__ scale, const float* __restrict__ shift,
+                const T* __restrict__ R, int M, int K, int Kp, int64_t nunits, int C) {
+    typedef GemmCfg<T> Gc;
+    constexpr int G = Gc::G;
+    constexpr int CGU = 16 / G;                              // 16-byte groups per unit row
+    T* Ws = reinterpret_cast<T*>(alsep_smem);
+    T* Xs = Ws + Gc::BR * Gc::LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int64_t u0 = (int64_t)blockIdx.x * 8;
+    const int row0 = blockIdx.y * Gc::BR;
+    const int upc = C / 16;
+
+    // staging item (kk, ul, cgi): cgi fastest, then unit, then k -> coalesced channel runs
+    const int cgi = tid % CGU, ul = (tid / CGU) % 8, kk0 = tid / (CGU * 8);
+    constexpr int KSTEP = kThreads / (CGU * 8);              // k rows covered per pass
+    const int64_t u = u0 + ul;
+    const bool uvalid = u < nunits;
+    const int64_t xbase = uvalid ? ((u / upc) * (int64_t)K) * C + (u % upc) * 16 + cgi * G : 0;
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < Kp; k0 += Gc::BK) {
+        __syncthreads();
+        stage_weights<T>(Ws, Wp, row0, k0, Kp, tid);
+#pragma unroll
+        for (int j = 0; j < Gc::BK / KSTEP; ++j) {
+            const int kk = kk0 + j * KSTEP;
+            vec16 v = zero16();
+            if (uvalid && k0 + kk < K) v = *reinterpret_cast<const vec16*>(X + xbase + (int64_t)(k0 + kk) * C);
+            const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int i = 0; i < G; ++i) Xs[(ul * 16 + cgi * G + i) * Gc::LD + kk] = e[i];   // transpose
+        }
+        __syncthreads();
+        gemm_tile_compute<T, false>(Ws, Xs, acc, wave, l15, lq);
+    }
+    // D rows = channel within unit (4*lq + r), D cols = weight row f' (l15)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int64_t uu = u0 + wave * 2 + ni;
+        if (uu >= nunits) continue;
+        const int64_t bt = uu / upc;
+        const int c = (int)(uu % upc) * 16 + 4 * lq;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int fo = row0 + mi * 16 + l15;
+            if (fo >= M) continue;
+            const float bv = bias ? bias[fo] : 0.f;
+            const int64_t o = (bt * M + fo) * C + c;
+            float y[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[mi][ni][r] + bv, scale[c + r], shift[c + r]), 0.f);
+            if (RESIDUAL) {
+                float x[4];
+                load4(R + o, x);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] += x[r];
+            }
+            store4(Y + o, y);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: packing + orchestration
+// ------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct ConvLayer {       // 3x3
+    DevBuf w, scale, shift;
+    int cin = 0, cout = 0;
+};
+struct GemmLayer {       // ds / us / tdf
+    DevBuf w, bias, scale, shift;
+    int M = 0, K = 0, Kp = 0, Mp = 0;
+    bool has_bias = false;
+};
+struct Block {
+    std::vector<ConvLayer> tfc;
+    std::vector<GemmLayer> tdf;
+};
+
+}  // namespace
+
+struct alsep_net {
+    alsep_ctx* ctx = nullptr;
+    alsep_net_config cfg{};
+    int n = 0;
+    std::vector<DevBuf> owned;
+    DevBuf first_w, first_scale, first_shift, final_w, final_b;
+    std::vector<Block> enc, dec;
+    Block bott;
+    std::vector<GemmLayer> ds, us;
+};
+
+namespace {
+
+typedef std::map<std::string, std::vector<float>> TensorMap;
+
+template <typename T> T host_cast(float v);
+template <> float host_cast<float>(float v) { return v; }
+template <> bf16_t host_cast<bf16_t>(float v) { return (bf16_t)v; }
+
+int upload(alsep_net* net, const void* src, size_t bytes, DevBuf* out) {
+    void* d = nullptr;
+    if (hipMalloc(&d, bytes ? bytes : 16) != hipSuccess) return alsep_fail(net->ctx, ALSEP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+    out->p = d;
+    out->bytes = bytes;
+    net->owned.push_back(*out);
+    if (bytes) ALSEP_HIP(net->ctx, hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+    return ALSEP_OK;
+}
+
+const std::vector<float>* find(const TensorMap& tm, const std::string& name, int64_t numel, alsep_ctx* ctx, bool required = true) {
+    auto it = tm.find(name);
+    if (it == tm.end()) {
+        if (required) alsep_fail(ctx, ALSEP_ERR_ARG, "missing tensor '%s'", name.c_str());
+        return nullptr;
+    }
+    if ((int64_t)it->second.size() != numel) {
+        alsep_fail(ctx, ALSEP_ERR_ARG, "tensor '%s' has %zu elements, expected %lld", name.c_str(), it->second.size(), (long long)numel);
+        return nullptr;
+    }
+    return &it->second;
+}
+
+// conv tile parameters per dtype (must match the launch in run_conv)
+template <typename T> struct ConvSel;
+template <> struct ConvSel<bf16_t> { static constexpr int KC = 48, BN = 48; };
+template <> struct ConvSel<float> { static constexpr int KC = 16, BN = 48; };
+// fall-back tiles for channel counts that are multiples of 16 / 32 only
+template <typename T> struct ConvSel16;
+template <> struct ConvSel16<bf16_t> { static constexpr int KC = 16, BN = 16; };
+template <> struct ConvSel16<float> { static constexpr int KC = 16, BN = 16; };
+
+template <typename T> bool conv_uses_main(int cin, int cout) {
+    return cin % ConvSel<T>::KC == 0 && cout % ConvSel<T>::BN == 0;
+}
+
+template <typename T, int KC, int BN>
+std::vector<T> pack_conv3x3(const std::vector<float>& w, int cin, int cout) {
+    typedef ConvCfg<T, KC, BN, 64> Cf;      // KP, CG, NG do not depend on TW
+    const int nq = cin / KC, nn = cout / BN;
+    std::vector<T> out((size_t)nn * nq * BN * Cf::KP, host_cast<T>(0.f));
+    for (int j = 0; j < nn; ++j)
+        for (int q = 0; q < nq; ++q)
+            for (int r = 0; r < BN; ++r)
+                for (int grp = 0; grp < Cf::NG; ++grp)
+                    for (int e = 0; e < Cf::G; ++e) {
+                        const int tap = grp / Cf::CG, cg = grp % Cf::CG;
+                        const int ci = q * KC + cg * Cf::G + e, co = j * BN + r;
+                        const float v = w[(((size_t)co * cin + ci) * 3 + tap / 3) * 3 + tap % 3];
+                        out[(((size_t)j * nq + q) * BN + r) * Cf::KP + grp * Cf::G + e] = host_cast<T>(v);
+                    }
+    return out;
+}
+
+template <typename T>
+int make_conv(alsep_net* net, const TensorMap& tm, const std::string& p, int c, ConvLayer* L) {
+    auto w = find(tm, p + ".weight", (int64_t)c * c * 9, net->ctx);
+    auto sc = find(tm, p + ".scale", c, net->ctx);
+    auto sh = find(tm, p + ".shift", c, net->ctx);
+    if (!w || !sc || !sh) return ALSEP_ERR_ARG;
+    L->cin = L->cout = c;
+    int rc;
+    if (conv_uses_main<T>(c, c)) {
+        auto pk = pack_conv3x3<T, ConvSel<T>::KC, ConvSel<T>::BN>(*w, c, c);
+        rc = upload(net, pk.data(), pk.size() * sizeof(T), &L->w);
+    } else {
+        auto pk = pack_conv3x3<T, ConvSel16<T>::KC, ConvSel16<T>::BN>(*w, c, c);
+        rc = upload(net, pk.data(), pk.size() * sizeof(T), &L->w);
+    }
+    if (rc) return rc;
+    if ((rc = upload(net, sc->data(), c * sizeof(float), &L->scale))) return rc;
+    return upload(net, sh->data(), c * sizeof(float), &L->shift);
+}
+
+// pack a [M][K] row-major fp32 matrix into [Mp][Kp] of T, zero padded to tile multiples
+template <typename T>
+int make_gemm_weights(alsep_net* net, const std::vector<float>& wmk, int M, int K, GemmLayer* L) {
+    typedef GemmCfg<T> Gc;
+    L->M = M; L->K = K;
+    L->Mp = (int)ceil_div64(M, Gc::BR) * Gc::BR;
+    L->Kp = (int)ceil_div64(K, Gc::BK) * Gc::BK;
+    std::vector<T> pk((size_t)L->Mp * L->Kp, host_cast<T>(0.f));
+    for (int m = 0; m < M; ++m)
+        for (int k = 0; k < K; ++k) pk[(size_t)m * L->Kp + k] = host_cast<T>(wmk[(size_t)m * K + k]);
+    return upload(net, pk.data(), pk.size() * sizeof(T), &L->w);
+}
+
+template <typename T>
+int make_block(alsep_net* net, const TensorMap& tm, const std::string& p, int c, int f, Block* blk) {
+    const alsep_net_config& cfg = net->cfg;
+    blk->tfc.resize(cfg.l);
+    for (int j = 0; j < cfg.l; ++j) {
+        int rc = make_conv<T>(net, tm, p + ".tfc." + std::to_string(j), c, &blk->tfc[j]);
+        if (rc) return rc;
+    }
+    const int n_lin = cfg.bn == 0 ? 1 : 2;
+    blk->tdf.resize(n_lin);
+    for (int j = 0; j < n_lin; ++j) {
+        const int fi = (j == 0) ? f : f / cfg.bn;
+        const int fo = (n_lin == 1 || j == 1) ? f : f / cfg.bn;
+        const std::string q = p + ".tdf." + std::to_string(j);
+        auto w = find(tm, q + ".weight", (int64_t)fo * fi, net->ctx);
+        auto sc = find(tm, q + ".scale", c, net->ctx);
+        auto sh = find(tm, q + ".shift", c, net->ctx);
+        if (!w || !sc || !sh) return ALSEP_ERR_ARG;
+        GemmLayer* L = &blk->tdf[j];
+        int rc = make_gemm_weights<T>(net, *w, fo, fi, L);
+        if (rc) return rc;
+        if ((rc = upload(net, sc->data(), c * sizeof(float), &L->scale))) return rc;
+        if ((rc = upload(net, sh->data(), c * sizeof(float), &L->shift))) return rc;
+        auto bi = find(tm, q + ".bias", fo, net->ctx, false);
+        if (tm.count(q + ".bias") && !bi) return ALSEP_ERR_ARG;
+        L->has_bias = bi != nullptr;
+        if (bi && (rc = upload(net, bi->data(), fo * sizeof(float), &L->bias))) return rc;
+    }
+    return ALSEP_OK;
+}
+
+template <typename T>
+int build_net(alsep_net* net, const TensorMap& tm) {
+    const alsep_net_config& cfg = net->cfg;
+    alsep_ctx* ctx = net->ctx;
+    const int g = cfg.g, n = net->n;
+    int rc;
+    {
+        auto w = find(tm, "first_conv.weight", (int64_t)g * 4, ctx);
+        auto sc = find(tm, "first_conv.scale", g, ctx);
+        auto sh = find(tm, "first_conv.shift", g, ctx);
+        if (!w || !sc || !sh) return ALSEP_ERR_ARG;
+        if ((rc = upload(net, w->data(), w->size() * 4, &net->first_w))) return rc;
+        if ((rc = upload(net, sc->data(), g * 4, &net->first_scale))) return rc;
+        if ((rc = upload(net, sh->data(), g * 4, &net->first_shift))) return rc;
+        auto fw = find(tm, "final_conv.weight", (int64_t)4 * g, ctx);
+        auto fb = find(tm, "final_conv.bias", 4, ctx);
+        if (!fw || !fb) return ALSEP_ERR_ARG;
+        if ((rc = upload(net, fw->data(), fw->size() * 4, &net->final_w))) return rc;
+        if ((rc = upload(net, fb->data(), 16, &net->final_b))) return rc;
+    }
+    net->enc.resize(n); net->dec.resize(n); net->ds.resize(n); net->us.resize(n);
+    int c = g, f = cfg.dim_f;
+    for (int i = 0; i < n; ++i) {
+        if ((rc = make_block<T>(net, tm, "encoding_blocks." + std::to_string(i), c, f, &net->enc[i]))) return rc;
+        // ds: torch Conv2d weight [c+g][c][2][2] -> rows co, k = (dy*2+dx)*c + ci
+        const int c2 = c + g;
+        const std::string p = "ds." + std::to_string(i);
+        auto w = find(tm, p + ".weight", (int64_t)c2 * c * 4, ctx);
+        auto sc = find(tm, p + ".scale", c2, ctx);
+        auto sh = find(tm, p + ".shift", c2, ctx);
+        if (!w || !sc || !sh) return ALSEP_ERR_ARG;
+        std::vector<float> mk((size_t)c2 * 4 * c);
+        for (int co = 0; co < c2; ++co)
+            for (int ci = 0; ci < c; ++ci)
+                for (int d = 0; d < 4; ++d) mk[(size_t)co * 4 * c + d * c + ci] = (*w)[((size_t)co * c + ci) * 4 + d];
+        if ((rc = make_gemm_weights<T>(net, mk, c2, 4 * c, &net->ds[i]))) return rc;
+        if ((rc = upload(net, sc->data(), c2 * 4, &net->ds[i].scale))) return rc;
+        if ((rc = upload(net, sh->data(), c2 * 4, &net->ds[i].shift))) return rc;
+        c = c2; f /= 2;
+    }
+    if ((rc = make_block<T>(net, tm, "bottleneck_block", c, f, &net->bott))) return rc;
+    for (int i = 0; i < n; ++i) {
+        // us: torch ConvTranspose2d weight [c][c-g][2][2] -> rows (d*c2 + co), k = ci; scale/shift per row
+        const int c2 = c - g;
+        const std::string p = "us." + std::to_string(i);
+        auto w = find(tm, p + ".weight", (int64_t)c * c2 * 4, ctx);
+        auto sc = find(tm, p + ".scale", c2, ctx);
+        auto sh = find(tm, p + ".shift", c2, ctx);
+        if (!w || !sc || !sh) return ALSEP_ERR_ARG;
+        std::vector<float> mk((size_t)4 * c2 * c), sc4((size_t)4 * c2), sh4((size_t)4 * c2);
+        for (int ci = 0; ci < c; ++ci)
+            for (int co = 0; co < c2; ++co)
+                for (int d = 0; d < 4; ++d) mk[((size_t)d * c2 + co) * c + ci] = (*w)[((size_t)ci * c2 + co) * 4 + d];
+        for (int d = 0; d < 4; ++d)
+            for (int co = 0; co < c2; ++co) { sc4[d * c2 + co] = (*sc)[co]; sh4[d * c2 + co] = (*sh)[co]; }
+        if ((rc = make_gemm_weights<T>(net, mk, 4 * c2, c, &net->us[i]))) return rc;
+        if ((rc = upload(net, sc4.data(), sc4.size() * 4, &net->us[i].scale))) return rc;
+        if ((rc = upload(net, sh4.data(), sh4.size() * 4, &net->us[i].shift))) return rc;
+        c = c2; f *= 2;
+        if ((rc = make_block<T>(net, tm, "decoding_blocks." + std::to_string(i), c, f, &net->dec[i]))) return rc;
+    }
+    return ALSEP_OK;
+}
+
+// ---- launches ------------------------------------------------------------------------------
+template <typename T, int KC, int BN, int TW>
+int launch_conv(alsep_ctx* ctx, const ConvLayer& L, const T* X, T* Y, int64_t B, int Th, int Fw) {
+    typedef ConvCfg<T, KC, BN, TW> Cf;
+    const int tiles_t = (int)ceil_div64(Th, Cf::TH), tiles_f = (int)ceil_div64(Fw, TW);
+    const int64_t ntiles = B * tiles_t * tiles_f;
+    if (ntiles > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "conv3x3: too many tiles");
+    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_kernel<T, KC, BN, TW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
+    ProfScope prof(ctx, TW == 64 ? ALSEP_PROF_CONV3X3 : ALSEP_PROF_CONV3X3_SMALL);
+    hipLaunchKernelGGL((conv3x3_kernel<T, KC, BN, TW>), dim3((unsigned)ntiles, L.cout / BN), dim3(kThreads),
+                       Cf::lds_bytes, ctx->stream, X, Y, (const T*)L.w.p, (const float*)L.scale.p,
+                       (const float*)L.shift.p, Th, Fw, L.cin, L.cout, tiles_t, tiles_f, (int)ntiles);
+    ALSEP_LAUNCH_CHECK(ctx, "conv3x3_kernel");
+    return ALSEP_OK;
+}
+
+template <typename T, int KC, int BN>
+int run_conv_tw(alsep_ctx* ctx, const ConvLayer& L, const T* X, T* Y, int64_t B, int Th, int Fw) {
+    if (Fw >= 64 && Fw % 64 == 0) return launch_conv<T, KC, BN, 64>(ctx, L, X, Y, B, Th, Fw);
+    if (Fw >= 32) return launch_conv<T, KC, BN, 32>(ctx, L, X, Y, B, Th, Fw);
+    return launch_conv<T, KC, BN, 16>(ctx, L, X, Y, B, Th, Fw);
+}
+
+template <typename T>
+int run_conv(alsep_ctx* ctx, const ConvLayer& L, const T* X, T* Y, int64_t B, int Th, int Fw) {
+    if (conv_uses_main<T>(L.cin, L.cout)) return run_conv_tw<T, ConvSel<T>::KC, ConvSel<T>::BN>(ctx, L, X, Y, B, Th, Fw);
+    return run_conv_tw<T, ConvSel16<T>::KC, ConvSel16<T>::BN>(ctx, L, X, Y, B, Th, Fw);
+}
+
+template <typename T, int MODE>
+int run_pix(alsep_ctx* ctx, const GemmLayer& L, const T* X, T* Y, const T* skip, int64_t ncols, int Tp, int Fp, int C, int C2) {
+    typedef GemmCfg<T> Gc;
+    const int64_t gx = ceil_div64(ncols, Gc::BC);
+    if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "pix_gemm: too many column tiles");
+    ProfScope prof(ctx, ALSEP_PROF_PIX);
+    hipLaunchKernelGGL((pix_gemm_kernel<T, MODE>), dim3((unsigned)gx, L.Mp / Gc::BR), dim3(kThreads), Gc::lds_bytes,
+                       ctx->stream, X, Y, (const T*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, skip,
+                       L.M, L.K, L.Kp, ncols, Tp, Fp, C, C2);
+    ALSEP_LAUNCH_CHECK(ctx, "pix_gemm_kernel");
+    return ALSEP_OK;
+}
+
+template <typename T>
+int run_tdf(alsep_ctx* ctx, const GemmLayer& L, const T* X, T* Y, const T* R, int64_t BT, int C) {
+    typedef GemmCfg<T> Gc;
+    const int64_t nunits = BT * (C / 16);
+    const int64_t gx = ceil_div64(nunits, 8);
+    if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "tdf_gemm: too many column tiles");
+    const float* bias = L.has_bias ? (const float*)L.bias.p : nullptr;
+    ProfScope prof(ctx, ALSEP_PROF_TDF);
+    if (R)
+        hipLaunchKernelGGL((tdf_gemm_kernel<T, true>), dim3((unsigned)gx, L.Mp / Gc::BR), dim3(kThreads), Gc::lds_bytes,
+                           ctx->stream, X, Y, (const T*)L.w.p, bias, (const float*)L.scale.p, (const float*)L.shift.p, R,
+                           L.M, L.K, L.Kp, nunits, C);
+    else
+        hipLaunchKernelGGL((tdf_gemm_kernel<T, false>), dim3((unsigned)gx, L.Mp / Gc::BR), dim3(kThreads), Gc::lds_bytes,
+                           ctx->stream, X, Y, (const T*)L.w.p, bias, (const float*)L.scale.p, (const float*)L.shift.p, R,
+                           L.M, L.K, L.Kp, nunits, C);
+    ALSEP_LAUNCH_CHECK(ctx, "tdf_gemm_kernel");
+    return ALSEP_OK;
+}
+
+// TFC_TDF block: cur -> dest, using scratch a, b (cur may alias b), hidden h.
+template <typename T>
+int run_block(alsep_ctx* ctx, const alsep_net* net, const Block& blk, const T* cur, T* a, T* b, T* h, T* dest,
+              int64_t B, int Th, int Fw, int c) {
+    const T* src = cur;
+    T* pp[2] = {a, b};
+    int rc;
+    const int l = (int)blk.tfc.size();
+    for (int j = 0; j < l; ++j) {
+        T* dst = pp[j & 1];
+        if ((rc = run_conv<T>(ctx, blk.tfc[j], src, dst, B, Th, Fw))) return rc;
+        src = dst;
+    }
+    if (blk.tdf.size() == 2) {
+        if ((rc = run_tdf<T>(ctx, blk.tdf[0], src, h, (const T*)nullptr, B * Th, c))) return rc;
+        return run_tdf<T>(ctx, blk.tdf[1], h, dest, src, B * Th, c);
+    }
+    return run_tdf<T>(ctx, blk.tdf[0], src, dest, src, B * Th, c);
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct WsLayout {
+    size_t p0, p1, p2, h, total;
+    std::vector<size_t> skip;
+};
+
+WsLayout ws_layout(const alsep_net* net, int64_t B) {
+    const alsep_net_config& cfg = net->cfg;
+    const size_t es = cfg.dtype == ALSEP_F32 ? 4 : 2;
+    WsLayout w;
+    const size_t s0 = align256((size_t)B * cfg.dim_t * cfg.dim_f * cfg.g * es);
+    size_t off = 0;
+    w.p0 = off; off += s0;
+    w.p1 = off; off += s0;
+    w.p2 = off; off += s0;
+    w.h = off;  off += align256(cfg.bn > 1 ? s0 / cfg.bn : 16);
+    int c = cfg.g;
+    size_t t = cfg.dim_t, f = cfg.dim_f;
+    for (int i = 0; i < net->n; ++i) {
+        w.skip.push_back(off);
+        off += align256((size_t)B * t * f * c * es);
+        c += cfg.g; t /= 2; f /= 2;
+    }
+    w.total = off;
+    return w;
+}
+
+template <typename T>
+int forward_impl(alsep_ctx* ctx, const alsep_net* net, const T* in, T* out, int64_t B, char* ws, float in_scale,
+                 float out_alpha, float out_beta) {
+    const alsep_net_config& cfg = net->cfg;
+    const WsLayout L = ws_layout(net, B);
+    T* P[3] = {(T*)(ws + L.p0), (T*)(ws + L.p1), (T*)(ws + L.p2)};
+    T* H = (T*)(ws + L.h);
+    int Th = cfg.dim_t, Fw = cfg.dim_f, c = cfg.g;
+    const int64_t npix0 = B * Th * Fw;
+    int rc;
+    {
+        ProfScope prof(ctx, ALSEP_PROF_POINTWISE);
+        const int64_t nthr = npix0 * (cfg.g / 4);
+        hipLaunchKernelGGL((first_conv_kernel<T>), dim3((unsigned)ceil_div64(nthr, kThreads)), dim3(kThreads), 0,
+                           ctx->stream, in, P[0], (const float*)net->first_w.p, (const float*)net->first_scale.p,
+                           (const float*)net->first_shift.p, npix0, cfg.g, in_scale);
+        ALSEP_LAUNCH_CHECK(ctx, "first_conv_kernel");
+    }
+    // rotating buffers: cur = P[ic]; the block uses the other two as scratch
+    int ic = 0;
+    for (int i = 0; i < net->n; ++i) {
+        T* skip = (T*)(ws + L.skip[i]);
+        if ((rc = run_block<T>(ctx, net, net->enc[i], P[ic], P[(ic + 1) % 3], P[(ic + 2) % 3], H, skip, B, Th, Fw, c))) return rc;
+        // ds: skip [B,Th,Fw,c] -> P[ic] [B,Th/2,Fw/2,c+g]
+        const int Tp = Th / 2, Fp = Fw / 2;
+        if ((rc = run_pix<T, PIX_DS>(ctx, net->ds[i], skip, P[ic], (const T*)nullptr, B * Tp * Fp, Tp, Fp, c, c + cfg.g))) return rc;
+        Th = Tp; Fw = Fp; c += cfg.g;
+    }
+    {
+        T* dest = P[(ic + 1) % 3];
+        if ((rc = run_block<T>(ctx, net, net->bott, P[ic], P[(ic + 2) % 3], P[ic], H, dest, B, Th, Fw, c))) return rc;
+        ic = (ic + 1) % 3;
+    }
+    for (int i = 0; i < net->n; ++i) {
+        const T* skip = (const T*)(ws + L.skip[net->n - 1 - i]);
+        const int c2 = c - cfg.g;
+        T* up = P[(ic + 1) % 3];
+        // us: P[ic] [B,Th,Fw,c] -> up [B,2Th,2Fw,c2] * skip
+        if ((rc = run_pix<T, PIX_US>(ctx, net->us[i], P[ic], up, skip, B * Th * Fw, Th, Fw, c, c2))) return rc;
+        Th *= 2; Fw *= 2; c = c2;
+        T* dest = P[ic];                                   // old input is dead after the up conv
+        if ((rc = run_block<T>(ctx, net, net->dec[i], up, P[(ic + 2) % 3], up, H, dest, B, Th, Fw, c))) return rc;
+    }
+    ProfScope prof(ctx, ALSEP_PROF_POINTWISE);
+    hipLaunchKernelGGL((final_conv_kernel<T>), dim3((unsigned)ceil_div64(npix0, kThreads)), dim3(kThreads), 0, ctx->stream,
+                       (const T*)P[ic], out, (const float*)net->final_w.p, (const float*)net->final_b.p, npix0, cfg.g, out_alpha, out_beta);
+    ALSEP_LAUNCH_CHECK(ctx, "final_conv_kernel");
+    return ALSEP_OK;
+}
+
+}  // namespace
+
+extern "C" int alsep_net_create(alsep_ctx* ctx, const alsep_net_config* cfg, const alsep_tensor* tensors,
+                                int64_t n_tensors, alsep_net** out) {
+    if (!ctx || !cfg || !tensors || !out) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_create: null argument");
+    const int n = cfg->num_blocks / 2;
+    if (cfg->num_blocks < 1 || cfg->l < 1 || cfg->g < 16 || cfg->g % 16 != 0 || cfg->bn < 0 ||
+        (cfg->dtype != ALSEP_F32 && cfg->dtype != ALSEP_BF16))
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_create: unsupported config (g must be a multiple of 16)");
+    if (cfg->dim_f % (1 << n) != 0 || cfg->dim_t % (1 << n) != 0 ||
+        (cfg->bn > 0 && (cfg->dim_f >> n) % cfg->bn != 0))
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_create: dim_f/dim_t not divisible by 2^%d (and bn)", n);
+    TensorMap tm;
+    for (int64_t i = 0; i < n_tensors; ++i) {
+        if (!tensors[i].name || !tensors[i].data || tensors[i].numel < 0)
+            return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_create: bad tensor entry %lld", (long long)i);
+        std::vector<float> h((size_t)tensors[i].numel);
+        if (tensors[i].numel)
+            ALSEP_HIP(ctx, hipMemcpy(h.data(), tensors[i].data, sizeof(float) * h.size(), hipMemcpyDeviceToHost));
+        tm[tensors[i].name] = std::move(h);
+    }
+    alsep_net* net = new alsep_net();
+    net->ctx = ctx;
+    net->cfg = *cfg;
+    net->n = n;
+    const int rc = cfg->dtype == ALSEP_F32 ? build_net<float>(net, tm) : build_net<bf16_t>(net, tm);
+    if (rc) {
+        const std::string keep = ctx->err;
+        alsep_net_destroy(net);
+        ctx->err = keep;
+        return rc;
+    }
+    *out = net;
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_net_destroy(alsep_net* net) {
+    if (!net) return ALSEP_OK;
+    for (auto& b : net->owned)
+        if (b.p) (void)hipFree(b.p);
+    delete net;
+    return ALSEP_OK;
+}
+
+extern "C" int64_t alsep_net_workspace_bytes(const alsep_net* net, int64_t B) {
+    if (!net || B <= 0) return 0;
+    return (int64_t)ws_layout(net, B).total;
+}
+
+extern "C" int alsep_net_forward(alsep_ctx* ctx, const alsep_net* net, const void* spec_in, void* spec_out,
+                                 int64_t B, void* workspace, int64_t workspace_bytes, float in_scale,
+                                 float out_alpha, float out_beta) {
+    if (!ctx || !net || !spec_in || !spec_out || !workspace) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_forward: null argument");
+    if (B == 0) return ALSEP_OK;
+    if (B < 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_forward: negative batch");
+    if (workspace_bytes < alsep_net_workspace_bytes(net, B))
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_forward: workspace too small (%lld < %lld)",
+                          (long long)workspace_bytes, (long long)alsep_net_workspace_bytes(net, B));
+    if (((uintptr_t)workspace & 255) != 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_forward: workspace must be 256-byte aligned");
+    if (net->cfg.dtype == ALSEP_F32)
+        return forward_impl<float>(ctx, net, (const float*)spec_in, (float*)spec_out, B, (char*)workspace, in_scale, out_alpha, out_beta);
+    return forward_impl<bf16_t>(ctx, net, (const bf16_t*)spec_in, (bf16_t*)spec_out, B, (char*)workspace, in_scale, out_alpha, out_beta);
+}

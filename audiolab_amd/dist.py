@@ -1,0 +1,52 @@
+"""Multi-GPU sharding of the separation path: one process per GPU, model windows (the overlap
+chunks of mdxnet.py:158-163) split into contiguous ranges, and ONE all-gather of the finished
+stem segments (RCCL over xGMI when the process group's backend is "nccl"; gloo on CPU for
+tests).  The reference has no multi-device path (device is hard-wired, stem_separator.py:99-100):
+windows are independent given the mix, so no other exchange exists on this path.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def window_range(n_win: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced split: the first ``n_win % world`` ranks get one extra window."""
+    base, extra = divmod(n_win, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def sample_range(n_win: int, gen: int, n_sample: int, world: int, rank: int) -> Tuple[int, int]:
+    """Output samples [lo, hi) of a segment produced by ``rank``'s windows (margin-style
+    stitching: window w yields samples [w*gen, (w+1)*gen), the tail is cut at n_sample)."""
+    w_lo, w_hi = window_range(n_win, world, rank)
+    return min(w_lo * gen, n_sample), min(w_hi * gen, n_sample)
+
+
+def all_gather_segments(local: torch.Tensor, n_win: int, gen: int, n_sample: int,
+                        group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """local: [..., n_local] this rank's stem samples (its ``sample_range``) -> [..., n_sample] on
+    every rank.  One collective: shards are padded to the largest shard so that a single
+    ``all_gather_into_tensor`` moves everything (each peer's shard travels its own xGMI link)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    ranges = [sample_range(n_win, gen, n_sample, world, r) for r in range(world)]
+    lo, hi = ranges[rank]
+    if local.shape[-1] != hi - lo:
+        raise ValueError(f"rank {rank}: local shard has {local.shape[-1]} samples, expected {hi - lo}")
+    width = max(h - l for l, h in ranges)
+    lead = local.shape[:-1]
+    send = torch.zeros(lead + (width,), dtype=local.dtype, device=local.device)
+    send[..., : hi - lo] = local
+    recv = torch.empty((world,) + lead + (width,), dtype=local.dtype, device=local.device)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(recv, send.contiguous(), group=group)     # one ncclAllGather (RCCL)
+    else:                                                                     # gloo has no _allgather_base
+        dist.all_gather(list(recv.unbind(0)), send.contiguous(), group=group)
+    out = torch.empty(lead + (n_sample,), dtype=local.dtype, device=local.device)
+    for r, (l, h) in enumerate(ranges):
+        out[..., l:h] = recv[r][..., : h - l]
+    return out

@@ -1,0 +1,261 @@
+"""MDX-Net front end / back end / chunker on the GPU, mirroring the reference's in-tree runner
+``modules/rvc/infer/modules/uvr5/mdxnet.py`` (ConvTDFNetTrim :15-75, Predictor :90-197) --
+same class names, constructor arguments and result shapes -- with every transform executed by
+the HIP kernels of libalsep.so.
+
+Two ways in:
+  * the *reference-shaped* API (``ConvTDFNetTrim.stft/istft``, ``Predictor.demix`` with a
+    ``model.run(None, {"input": spek})`` callable) keeps the reference's tensor layout
+    ``[B,4,dim_f,dim_t]`` so parity tests read like the reference;
+  * the *fused* path (``Predictor.demix`` with a :class:`audiolab_amd.tdfnet.TDFNet`) frames the
+    zero-padded mix in place (no chunk copies), keeps the spectrogram channels-last on the
+    device between STFT, network and iSTFT, and lets the iSTFT store straight into the stitched
+    track (trim / pad / margins folded into the store).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import AlsepError, Context
+
+
+class StftPlan:
+    """alsep_plan: geometry of ConvTDFNetTrim.__init__ (mdxnet.py:15-39) + device tables."""
+
+    def __init__(self, ctx: Context, n_fft: int, hop: int, dim_f: int, dim_t: int):
+        self.ctx = ctx
+        self.n_fft, self.hop, self.dim_f, self.dim_t = n_fft, hop, dim_f, dim_t
+        self.n_bins = n_fft // 2 + 1
+        self.chunk_size = hop * (dim_t - 1)
+        self.trim = n_fft // 2
+        self.gen_size = self.chunk_size - 2 * self.trim
+        h = C.c_void_p()
+        ctx.check(ctx.lib.alsep_plan_create(ctx.handle, n_fft, hop, dim_f, dim_t, C.byref(h)), "alsep_plan_create")
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and self.ctx.handle:
+                self.ctx.lib.alsep_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # -- raw calls ---------------------------------------------------------------------------
+    def spec_shape(self, n_chunks: int, layout: int) -> Tuple[int, ...]:
+        if layout == _lib.LAYOUT_REF:
+            return (n_chunks, 4, self.dim_f, self.dim_t)
+        return (n_chunks, self.dim_t, self.dim_f, 4)
+
+    def stft_strided(self, pcm: torch.Tensor, ch_stride: int, chunk_stride: int, n_chunks: int,
+                     dtype: torch.dtype = torch.float32, layout: int = _lib.LAYOUT_NHWC,
+                     out: Optional[torch.Tensor] = None, pcm_offset: int = 0) -> torch.Tensor:
+        """Frames ``n_chunks`` chunks out of the flat float32 buffer ``pcm`` (see alsep_stft)."""
+        if pcm.dtype != torch.float32:
+            raise AlsepError("pcm must be float32")
+        need = ch_stride + (n_chunks - 1) * chunk_stride + self.chunk_size + pcm_offset
+        if n_chunks > 0 and pcm.numel() < need:
+            raise AlsepError(f"pcm buffer too small: {pcm.numel()} < {need}")
+        if out is None:
+            out = self.ctx.empty(self.spec_shape(n_chunks, layout), dtype)
+        elif tuple(out.shape) != self.spec_shape(n_chunks, layout) or out.dtype != dtype:
+            raise AlsepError("stft: bad output tensor")
+        base = _lib.ptr(pcm) + 4 * pcm_offset
+        self.ctx.check(self.ctx.lib.alsep_stft(self.ctx.handle, self.handle, C.c_void_p(base), ch_stride, chunk_stride,
+                                               n_chunks, _lib.ptr(out), _lib.dtype_code(dtype), layout), "alsep_stft")
+        return out
+
+    def istft_strided(self, spec: torch.Tensor, layout: int, out: torch.Tensor, out_ch_stride: int,
+                      out_chunk_stride: int, keep_lo: int, keep_hi: int, out_limit: int, out_offset: int = 0) -> None:
+        n_chunks = spec.shape[0]
+        if tuple(spec.shape) != self.spec_shape(n_chunks, layout):
+            raise AlsepError(f"istft: spec shape {tuple(spec.shape)} != {self.spec_shape(n_chunks, layout)}")
+        if out.dtype != torch.float32:
+            raise AlsepError("istft output must be float32")
+        if out.numel() < out_offset + out_ch_stride + out_limit:
+            raise AlsepError("istft: output buffer too small")
+        base = _lib.ptr(out) + 4 * out_offset
+        self.ctx.check(self.ctx.lib.alsep_istft(self.ctx.handle, self.handle, _lib.ptr(spec), _lib.dtype_code(spec.dtype),
+                                                layout, n_chunks, C.c_void_p(base), out_ch_stride, out_chunk_stride,
+                                                keep_lo, keep_hi, out_limit), "alsep_istft")
+
+    def convert(self, spec: torch.Tensor, src_layout: int) -> torch.Tensor:
+        n = spec.shape[0]
+        dst_layout = _lib.LAYOUT_NHWC if src_layout == _lib.LAYOUT_REF else _lib.LAYOUT_REF
+        if tuple(spec.shape) != self.spec_shape(n, src_layout):
+            raise AlsepError("convert: bad spec shape")
+        out = self.ctx.empty(self.spec_shape(n, dst_layout), spec.dtype)
+        self.ctx.check(self.ctx.lib.alsep_spec_convert(self.ctx.handle, _lib.ptr(spec), _lib.ptr(out),
+                                                       _lib.dtype_code(spec.dtype), src_layout, n, self.dim_f,
+                                                       self.dim_t), "alsep_spec_convert")
+        return out
+
+
+class ConvTDFNetTrim:
+    """Drop-in for the reference class of the same name (mdxnet.py:15-75): STFT geometry and the
+    ``stft`` / ``istft`` pair, tensors in the reference layout, computed by the HIP kernels."""
+
+    def __init__(self, device, model_name, target_name, L, dim_f, dim_t, n_fft, hop=1024, ctx: Optional[Context] = None):
+        self.ctx = ctx if ctx is not None else _lib.default_context(device)
+        self.dim_f = dim_f
+        self.dim_t = 2 ** dim_t                          # mdxnet.py:22
+        self.n_fft = n_fft
+        self.hop = hop
+        self.n_bins = self.n_fft // 2 + 1
+        self.chunk_size = hop * (self.dim_t - 1)
+        self.target_name = target_name
+        self.blender = "blender" in model_name
+        self.dim_c = 4
+        self.n = L // 2
+        if target_name == "*":
+            raise AlsepError("multi-target ('*') ConvTDFNetTrim is not supported")
+        self.plan = StftPlan(self.ctx, n_fft, hop, dim_f, self.dim_t)
+
+    def stft(self, x: torch.Tensor) -> torch.Tensor:
+        """[B,2,chunk] (any shape reshapable to [-1,chunk] pairs) -> [B,4,dim_f,dim_t] float32."""
+        x = x.reshape(-1, 2, self.chunk_size).contiguous().float()
+        b = x.shape[0]
+        return self.plan.stft_strided(x, self.chunk_size, 2 * self.chunk_size, b, torch.float32, _lib.LAYOUT_REF)
+
+    def istft(self, x: torch.Tensor, freq_pad=None) -> torch.Tensor:
+        """[B,4,dim_f,dim_t] -> [B,2,chunk]; bins >= dim_f are zero (mdxnet.py:59-64)."""
+        if freq_pad is not None:
+            raise AlsepError("custom freq_pad is not supported; bins >= dim_f are zero")
+        x = x.contiguous()
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        b = x.shape[0]
+        out = self.ctx.empty((b, 2, self.chunk_size), torch.float32)
+        self.plan.istft_strided(x, _lib.LAYOUT_REF, out, self.chunk_size, 2 * self.chunk_size, 0, self.chunk_size,
+                                (b - 1) * 2 * self.chunk_size + self.chunk_size)
+        return out
+
+
+def get_models(device, dim_f, dim_t, n_fft, ctx: Optional[Context] = None):
+    """mdxnet.py:78-87."""
+    return ConvTDFNetTrim(device=device, model_name="Conv-TDF", target_name="vocals", L=11, dim_f=dim_f,
+                          dim_t=dim_t, n_fft=n_fft, ctx=ctx)
+
+
+class Predictor:
+    """Reference ``Predictor`` (mdxnet.py:90-197) on the GPU.
+
+    ``args`` needs ``margin, chunks, denoise, dim_f, dim_t, n_fft`` (as MDXNetDereverb supplies,
+    mdxnet.py:241-252).  ``model`` is either
+      * a :class:`audiolab_amd.tdfnet.TDFNet` (fused channels-last path), or
+      * any object with ``run(None, {"input": tensor}) -> [tensor]`` taking/returning the
+        reference layout ``[B,4,dim_f,dim_t]`` on the device (the ORT-session seam, :170-176).
+    """
+
+    def __init__(self, args, model, ctx: Optional[Context] = None, hop: int = 1024, max_batch: int = 0,
+                 group=None, sharded: bool = False):
+        """``sharded=True`` splits every segment's model windows over the ranks of ``group``
+        (torch.distributed; default group if None) and all-gathers the stem segments."""
+        self.group = group
+        self.sharded = sharded
+        self.args = args
+        self.ctx = ctx if ctx is not None else _lib.default_context(None)
+        self.model_ = ConvTDFNetTrim(self.ctx.device, "Conv-TDF", "vocals", 11, args.dim_f, args.dim_t, args.n_fft,
+                                     hop=hop, ctx=self.ctx)
+        self.model = model
+        self.max_batch = max_batch                      # chunks per network launch (0 = whole segment)
+
+    # -- outer segmentation, mdxnet.py:109-141 -------------------------------------------------
+    def segments(self, samples: int) -> Tuple[List[Tuple[int, int, int]], int]:
+        """[(skip, start, end)], margin -- the index arithmetic of demix (:109-133)."""
+        margin = self.args.margin
+        chunk_size = self.args.chunks * 44100
+        assert not margin == 0, "margin cannot be zero!"
+        if margin > chunk_size:
+            margin = chunk_size
+        if self.args.chunks == 0 or samples < chunk_size:
+            chunk_size = samples
+        segs = []
+        counter = -1
+        for skip in range(0, samples, chunk_size):
+            counter += 1
+            s_margin = 0 if counter == 0 else margin
+            end = min(skip + chunk_size + margin, samples)
+            segs.append((skip, skip - s_margin, end))
+            if end == samples:
+                break
+        return segs, margin
+
+    def demix(self, mix: torch.Tensor) -> torch.Tensor:
+        """mix [2,N] float32 on the device -> sources [1,2,N] (mdxnet.py:109-141)."""
+        if mix.dim() != 2 or mix.shape[0] != 2:
+            raise AlsepError("demix expects a [2,N] stereo tensor")
+        mix = mix.contiguous().float()
+        samples = mix.shape[-1]
+        segs, margin = self.segments(samples)
+        out = self.ctx.empty((1, 2, samples), torch.float32)
+        pos = 0
+        for idx, (skip, start, end) in enumerate(segs):
+            first, last = idx == 0, idx == len(segs) - 1
+            seg = self.demix_segment(mix[:, start:end])            # [2, end-start]
+            lo = 0 if first else margin                            # :185
+            hi = seg.shape[-1] if (last or margin == 0) else seg.shape[-1] - margin   # :186-188
+            n = hi - lo
+            out[0, :, pos:pos + n] = seg[:, lo:hi]
+            pos += n
+        if pos != samples:
+            raise AlsepError(f"demix stitched {pos} samples, expected {samples}")
+        return out
+
+    # -- inner framing + inference + stitch of one segment, mdxnet.py:147-183 -------------------
+    def demix_segment(self, cmix: torch.Tensor) -> torch.Tensor:
+        m = self.model_
+        plan = m.plan
+        n_sample = cmix.shape[1]
+        trim, gen = plan.trim, plan.gen_size
+        pad = gen - n_sample % gen                                  # :153
+        n_win = (n_sample + pad) // gen                             # windows i = 0, gen, ... < n_sample+pad
+        total = trim + n_sample + pad + trim
+        mix_p = self.ctx.zeros((2, total), torch.float32)           # :154-156
+        mix_p[:, trim:trim + n_sample] = cmix
+        w_lo, w_hi, s_lo, s_hi = 0, n_win, 0, n_sample
+        if self.sharded:
+            import torch.distributed as tdist
+            from . import dist as adist
+            world, rank = tdist.get_world_size(self.group), tdist.get_rank(self.group)
+            w_lo, w_hi = adist.window_range(n_win, world, rank)
+            s_lo, s_hi = adist.sample_range(n_win, gen, n_sample, world, rank)
+        n_local = s_hi - s_lo
+        seg_out = self.ctx.empty((2, max(n_local, 1)), torch.float32)
+        if n_local > 0:
+            self._run_windows(mix_p, total, seg_out, n_local, w_lo, w_hi, s_lo, n_sample)
+        seg_out = seg_out[:, :n_local]
+        if self.sharded:
+            seg_out = adist.all_gather_segments(seg_out.contiguous(), n_win, gen, n_sample, self.group)
+        return seg_out
+
+    def _run_windows(self, mix_p, total, seg_out, n_local, w_lo, w_hi, s_lo, n_sample) -> None:
+        """STFT -> network -> iSTFT for windows [w_lo, w_hi); window w lands at sample w*gen - s_lo
+        of ``seg_out`` [2, >= n_local]; samples beyond n_sample (the trailing pad, :183) are dropped."""
+        m = self.model_
+        plan = m.plan
+        trim, gen = plan.trim, plan.gen_size
+        ld = seg_out.shape[1]
+        step = self.max_batch if self.max_batch > 0 else (w_hi - w_lo)
+        for w0 in range(w_lo, w_hi, step):
+            nb = min(step, w_hi - w0)
+            limit = min(n_sample, s_lo + n_local) - w0 * gen
+            if hasattr(self.model, "forward_nhwc"):
+                net = self.model
+                spek = plan.stft_strided(mix_p, total, gen, nb, net.dtype, _lib.LAYOUT_NHWC, pcm_offset=w0 * gen)
+                pred = net.forward_nhwc(spek, denoise=bool(self.args.denoise))
+                plan.istft_strided(pred, _lib.LAYOUT_NHWC, seg_out, ld, gen, trim, plan.chunk_size - trim,
+                                   limit, out_offset=w0 * gen - s_lo)
+            else:
+                spek = plan.stft_strided(mix_p, total, gen, nb, torch.float32, _lib.LAYOUT_REF, pcm_offset=w0 * gen)
+                if self.args.denoise:                               # :168-173
+                    pred = -self.model.run(None, {"input": -spek})[0] * 0.5 + self.model.run(None, {"input": spek})[0] * 0.5
+                else:
+                    pred = self.model.run(None, {"input": spek})[0]
+                pred = torch.as_tensor(pred, device=self.ctx.device).contiguous()
+                plan.istft_strided(pred, _lib.LAYOUT_REF, seg_out, ld, gen, trim, plan.chunk_size - trim,
+                                   limit, out_offset=w0 * gen - s_lo)

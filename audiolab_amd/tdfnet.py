@@ -1,0 +1,213 @@
+"""TFC-TDF U-Net (MDX-Net "ConvTDFNet") on the GPU: host-side model object over alsep_net.
+
+This is what the reference reaches through ``MDXSeparator.model_run(spek)``
+(handlers/patch_separate.py:52,58-62) after ``Separator.load_model('*.onnx')``
+(modules/separator/stem_separator.py:394,512).  Weights come as a torch ``state_dict``-style
+dict (``first_conv.0.weight``, ``encoding_blocks.0.tfc.H.0.1.running_var`` ...); BatchNorm is
+folded here into per-channel (scale, shift) and everything else happens in libalsep.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import AlsepError, Context
+
+BN_EPS = 1e-5
+
+
+@dataclass(frozen=True)
+class TDFNetConfig:
+    dim_f: int = 3072
+    dim_t: int = 256          # frames (2**dim_t_arg of mdxnet.py:22)
+    n_fft: int = 6144
+    hop: int = 1024
+    num_blocks: int = 11      # L
+    l: int = 3
+    g: int = 48
+    k: int = 3
+    bn: int = 8
+    bias: bool = True
+    dim_c: int = 4
+
+    @property
+    def n(self) -> int:
+        return self.num_blocks // 2
+
+    def levels(self):
+        """[(channels, frames, bins)] for encoder levels 0..n (n = bottleneck)."""
+        out = []
+        c, t, f = self.g, self.dim_t, self.dim_f
+        for _ in range(self.n + 1):
+            out.append((c, t, f))
+            c += self.g
+            t //= 2
+            f //= 2
+        return out
+
+    def flops_per_chunk(self) -> float:
+        """MACs*2 of one forward over one chunk (convs + TDF + ds/us + 1x1)."""
+        lv = self.levels()
+        total = 0.0
+
+        def block(c, t, f):
+            s = self.l * 2.0 * 9 * c * c * t * f
+            if self.bn is not None:
+                if self.bn == 0:
+                    s += 2.0 * c * t * f * f
+                else:
+                    s += 2 * 2.0 * c * t * f * (f // self.bn)
+            return s
+        for i, (c, t, f) in enumerate(lv):
+            total += block(c, t, f) * (1 if i == self.n else 2)
+        for i in range(self.n):
+            c, t, f = lv[i]
+            total += 2 * 2.0 * 4 * c * (c + self.g) * (t // 2) * (f // 2)      # ds + us
+        total += 2 * 2.0 * 4 * self.g * self.dim_t * self.dim_f                # first + final 1x1
+        return total
+
+
+def fold_batchnorm(sd: Dict[str, torch.Tensor], conv: str, bn: str, conv_bias_per_channel: bool = True):
+    """(scale, shift) with y = scale * conv_nobias(x) + shift  ==  BN(conv(x)) in eval mode."""
+    gamma, beta = sd[bn + ".weight"].double(), sd[bn + ".bias"].double()
+    mean, var = sd[bn + ".running_mean"].double(), sd[bn + ".running_var"].double()
+    scale = gamma / torch.sqrt(var + BN_EPS)
+    shift = beta - mean * scale
+    b = sd.get(conv + ".bias")
+    if b is not None and conv_bias_per_channel:
+        shift = shift + b.double() * scale
+    return scale.float(), shift.float()
+
+
+def folded_tensors(sd: Dict[str, torch.Tensor], cfg: TDFNetConfig) -> Dict[str, torch.Tensor]:
+    """state_dict -> the flat table alsep_net_create expects (names in tdfnet.hip build_net)."""
+    out: Dict[str, torch.Tensor] = {}
+
+    def conv_bn(dst: str, conv: str, bn: str):
+        out[dst + ".weight"] = sd[conv + ".weight"]
+        out[dst + ".scale"], out[dst + ".shift"] = fold_batchnorm(sd, conv, bn)
+
+    def block(dst: str, src: str):
+        for j in range(cfg.l):
+            conv_bn(f"{dst}.tfc.{j}", f"{src}.tfc.H.{j}.0", f"{src}.tfc.H.{j}.1")
+        if cfg.bn is not None:
+            for j in range(1 if cfg.bn == 0 else 2):
+                lin, bn = f"{src}.tdf.{3 * j}", f"{src}.tdf.{3 * j + 1}"
+                out[f"{dst}.tdf.{j}.weight"] = sd[lin + ".weight"]
+                # the Linear bias is per output FEATURE (f'), BN is per CHANNEL: keep them apart
+                s, sh = fold_batchnorm(sd, lin, bn, conv_bias_per_channel=False)
+                out[f"{dst}.tdf.{j}.scale"], out[f"{dst}.tdf.{j}.shift"] = s, sh
+                if lin + ".bias" in sd:
+                    out[f"{dst}.tdf.{j}.bias"] = sd[lin + ".bias"]
+
+    conv_bn("first_conv", "first_conv.0", "first_conv.1")
+    for i in range(cfg.n):
+        block(f"encoding_blocks.{i}", f"encoding_blocks.{i}")
+        conv_bn(f"ds.{i}", f"ds.{i}.0", f"ds.{i}.1")
+        block(f"decoding_blocks.{i}", f"decoding_blocks.{i}")
+        conv_bn(f"us.{i}", f"us.{i}.0", f"us.{i}.1")
+    block("bottleneck_block", "bottleneck_block")
+    out["final_conv.weight"] = sd["final_conv.0.weight"]
+    fb = sd.get("final_conv.0.bias")
+    out["final_conv.bias"] = fb if fb is not None else torch.zeros(cfg.dim_c)
+    return out
+
+
+class TDFNet:
+    """One loaded MDX-Net model on one GPU.  ``forward_nhwc`` takes/returns the channels-last
+    spectrogram ``[B, dim_t, dim_f, 4]`` in the model dtype; ``run`` offers the ORT-session
+    surface of the reference seam (``run(None, {"input": spek[B,4,dim_f,dim_t]}) -> [pred]``)."""
+
+    def __init__(self, cfg: TDFNetConfig, state_dict: Dict[str, torch.Tensor], ctx: Optional[Context] = None,
+                 dtype: torch.dtype = torch.float32, max_batch: int = 4):
+        if cfg.k != 3:
+            raise AlsepError("only k=3 TFC convolutions are implemented")
+        if cfg.bn is None:
+            raise AlsepError("bn=None (no TDF) is not implemented")
+        self.cfg = cfg
+        self.ctx = ctx if ctx is not None else _lib.default_context(None)
+        self.dtype = dtype
+        self.max_batch = max_batch
+        table = folded_tensors(state_dict, cfg)
+        keep: List[torch.Tensor] = []
+        entries = (_lib.TensorEntry * len(table))()
+        for i, (name, t) in enumerate(table.items()):
+            d = t.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
+            keep.append(d)
+            entries[i].name = name.encode()
+            entries[i].data = d.data_ptr()
+            entries[i].numel = d.numel()
+        ncfg = _lib.NetConfig(cfg.dim_f, cfg.dim_t, cfg.num_blocks, cfg.l, cfg.g, cfg.bn, _lib.dtype_code(dtype), 0)
+        self.ctx.synchronize()
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.alsep_net_create(self.ctx.handle, C.byref(ncfg), entries, len(table), C.byref(h)),
+                       "alsep_net_create")
+        self.handle = h
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_batch = 0
+        del keep
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and self.ctx.handle:
+                self.ctx.lib.alsep_net_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def workspace(self, batch: int) -> torch.Tensor:
+        if self._ws is None or self._ws_batch < batch:
+            nbytes = self.ctx.lib.alsep_net_workspace_bytes(self.handle, batch)
+            self._ws = self.ctx.empty((nbytes + 256,), torch.uint8)
+            self._ws_batch = batch
+        return self._ws
+
+    def _forward(self, spek: torch.Tensor, out: torch.Tensor, in_scale: float = 1.0, alpha: float = 1.0,
+                 beta: float = 0.0) -> None:
+        b = spek.shape[0]
+        ws = self.workspace(b)
+        base = (ws.data_ptr() + 255) & ~255
+        self.ctx.check(self.ctx.lib.alsep_net_forward(self.ctx.handle, self.handle, _lib.ptr(spek), _lib.ptr(out), b,
+                                                      C.c_void_p(base), ws.numel() - 256, in_scale, alpha, beta),
+                       "alsep_net_forward")
+
+    def forward_nhwc(self, spek: torch.Tensor, denoise: bool = False) -> torch.Tensor:
+        cfg = self.cfg
+        if tuple(spek.shape[1:]) != (cfg.dim_t, cfg.dim_f, 4) or spek.dtype != self.dtype:
+            raise AlsepError(f"forward_nhwc: expected [B,{cfg.dim_t},{cfg.dim_f},4] {self.dtype}, got "
+                             f"{tuple(spek.shape)} {spek.dtype}")
+        spek = spek.contiguous()
+        out = torch.empty_like(spek)
+        step = self.max_batch if self.max_batch > 0 else spek.shape[0]
+        for b0 in range(0, spek.shape[0], step):
+            x = spek[b0:b0 + step]
+            y = out[b0:b0 + step]
+            if denoise:                                   # 0.5*f(x) - 0.5*f(-x), mdxnet.py:168-173
+                self._forward(x, y, 1.0, 0.5, 0.0)
+                self._forward(x, y, -1.0, -0.5, 1.0)
+            else:
+                self._forward(x, y)
+        return out
+
+    def run(self, _names, feed):
+        """ORT-session surface (mdxnet.py:170-176, patch_separate.py:52): reference layout in/out."""
+        from .mdx import StftPlan
+        spek = feed["input"]
+        plan = self._plan()
+        x = plan.convert(spek.contiguous().to(self.dtype), _lib.LAYOUT_REF)
+        y = self.forward_nhwc(x)
+        return [plan.convert(y, _lib.LAYOUT_NHWC).float()]
+
+    def _plan(self):
+        from .mdx import StftPlan
+        if not hasattr(self, "_plan_obj"):
+            self._plan_obj = StftPlan(self.ctx, self.cfg.n_fft, self.cfg.hop, self.cfg.dim_f, self.cfg.dim_t)
+        return self._plan_obj
+
+    def __call__(self, spek: torch.Tensor) -> torch.Tensor:
+        """model_run(spek) of the reference seam (patch_separate.py:52)."""
+        return self.run(None, {"input": spek})[0]

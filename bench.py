@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- stems x realtime-factor of the MDX separation hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): MDX-Net UVR 4-stem -- four TFC-TDF U-Nets (L=11, g=48,
+dim_f 3072, dim_t 256, n_fft 6144, hop 1024) -- over 5 min of 44.1 kHz stereo per GPU, bf16,
+synthetic audio and random-init weights (no dataset / checkpoint is reachable offline).
+One step = one full pass of the hot path over the track: for each of the 4 models
+STFT -> network -> iSTFT -> stitch (reference mdxnet.py:143-197), inputs resident in HBM.
+With N GPUs the track is N x 5 min: model windows are sharded over the ranks and the stem
+segments are all-gathered once per model (RCCL), so per-GPU work is fixed ("weak").
+
+python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+SR = 44100
+TRACK_SECONDS = 300
+N_STEMS = 4
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def conv_main_flops_per_chunk(cfg) -> float:
+    """FLOPs of the conv3x3 launches that use the main (TW=64) tile, per chunk-forward."""
+    total = 0.0
+    for i, (c, t, f) in enumerate(cfg.levels()):
+        if f % 64 == 0:
+            total += (1 if i == cfg.n else 2) * cfg.l * 2.0 * 9 * c * c * t * f
+    return total
+
+
+def cpu_baseline(cfg, sd, mix_np, n_windows: int):
+    """The oracle (CPU restatement of the reference path: numpy STFT/iSTFT/chunker + torch-CPU
+    fp32 network) timed on the host cores over the first ``n_windows`` model windows, 1 stem."""
+    from oracle import mdx_oracle, tdfnet_oracle
+    g = mdx_oracle.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
+    n = n_windows * g.gen_size - 1                       # exactly n_windows windows (pad = 1)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def model_run(spek):
+        with torch.no_grad():
+            return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)),
+                                         cfg.num_blocks, cfg.l, cfg.bn).numpy()
+    t0 = time.perf_counter()
+    out = mdx_oracle.demix(mix_np[:, :n], g, model_run, chunks=0, margin=SR, dtype=np.float32)
+    dt = time.perf_counter() - t0
+    assert out.shape[-1] == n
+    seconds = n / SR
+    return {"value": round(seconds / dt, 4), "unit": "stems*x_realtime", "cores": cores, "kind": "port",
+            "sample": f"1 of {N_STEMS} models, first {n_windows} model windows ({seconds:.2f} s of audio), fp32, "
+                      f"oracle/mdx_oracle.demix + oracle/tdfnet_oracle.forward, {dt:.1f} s wall"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=4, help="model windows per network launch")
+    ap.add_argument("--seconds", type=int, default=TRACK_SECONDS, help="audio seconds per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-windows", type=int, default=1)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU; there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from audiolab_amd import _lib
+    from audiolab_amd.mdx import Predictor
+    from audiolab_amd.synth import synth_mix, synthetic_state_dict
+    from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    device = torch.device("cuda", local_rank)
+    ctx = _lib.Context(device)
+    cfg = TDFNetConfig()
+    n_samples = args.seconds * SR * world
+    mix_np = synth_mix(n_samples)
+    mix = torch.from_numpy(mix_np).to(device)
+    sds = [synthetic_state_dict(cfg, seed=s) for s in range(N_STEMS)]
+    nets = [TDFNet(cfg, sd, ctx=ctx, dtype=dtype, max_batch=args.batch) for sd in sds]
+    pargs = types.SimpleNamespace(margin=SR, chunks=0, denoise=False, dim_f=cfg.dim_f, dim_t=8, n_fft=cfg.n_fft)
+    preds = [Predictor(pargs, net, ctx=ctx, max_batch=0, sharded=world > 1) for net in nets]
+
+    def step():
+        return [p.demix(mix) for p in preds]
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        stems = step()
+    fence()
+    ctx.profile_begin(_lib.PROF_CONV3X3)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stems = step()
+    fence()
+    dt = time.perf_counter() - t0
+    conv_ms, conv_launches = ctx.profile_end()
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    assert stems[0].shape == (1, 2, n_samples) and bool(torch.isfinite(stems[0]).all())
+
+    # windows this rank pushed through the network per step (per model)
+    gen = cfg.hop * (cfg.dim_t - 1) - cfg.n_fft
+    n_win = n_samples // gen + 1
+    from audiolab_amd.dist import window_range
+    w_lo, w_hi = window_range(n_win, world, rank)
+    local_windows = (w_hi - w_lo) * N_STEMS * args.steps
+    conv_flops = conv_main_flops_per_chunk(cfg) * local_windows
+    achieved_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+
+    # per-stage HBM rooflines (outside the timed region): STFT and iSTFT over this rank's windows
+    stages = {}
+    plan = preds[0].model_.plan
+    nb = min(w_hi - w_lo, 52)
+    pad_len = plan.trim * 2 + nb * gen + plan.chunk_size
+    buf = torch.zeros((2, pad_len), device=device)
+    buf[:, plan.trim:plan.trim + min(n_samples, pad_len - 2 * plan.trim)] = mix[:, :min(n_samples, pad_len - 2 * plan.trim)]
+    es = 2 if dtype == torch.bfloat16 else 4
+    spec = plan.stft_strided(buf, pad_len, gen, nb, dtype, _lib.LAYOUT_NHWC)
+    outb = torch.empty((2, nb * gen), device=device)
+    torch.cuda.synchronize()
+    for name, cat in (("stft", _lib.PROF_STFT), ("istft", _lib.PROF_ISTFT)):
+        reps = 10
+        ctx.profile_begin(cat)
+        for _ in range(reps):
+            if name == "stft":
+                plan.stft_strided(buf, pad_len, gen, nb, dtype, _lib.LAYOUT_NHWC, out=spec)
+            else:
+                plan.istft_strided(spec, _lib.LAYOUT_NHWC, outb, nb * gen, gen, plan.trim, plan.chunk_size - plan.trim, nb * gen)
+        ms, launches = ctx.profile_end()
+        spec_bytes = 4 * cfg.dim_f * cfg.dim_t * es
+        if name == "stft":
+            alg = 2 * plan.chunk_size * 4 + spec_bytes                     # PCM read + spec write
+        else:
+            alg = spec_bytes + 3 * 2 * plan.chunk_size * 4                 # spec read + acc/div read-modify-write
+        gbs = alg * nb * reps / (ms * 1e-3) / 1e9
+        stages[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(gbs / PEAK_HBM_GBS, 4), "bytes_per_chunk": alg, "chunks_per_launch": nb,
+                        "us_per_launch": round(ms * 1e3 / max(launches, 1), 2), "traffic": None}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, sds[0], mix_np, args.cpu_windows)
+
+    if rank == 0:
+        audio_seconds = n_samples / SR
+        value = N_STEMS * audio_seconds * args.steps / dt
+        line = {
+            "metric": "stems*realtime-factor (44.1kHz stereo)",
+            "value": round(value, 2),
+            "unit": "stems*x_realtime",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"MDX-Net UVR 4-stem (4x TFC-TDF U-Net L=11 g=48 dim_f=3072 dim_t=256 n_fft=6144), "
+                                   f"{args.seconds} s 44.1 kHz stereo per GPU, margin chunker, windows/launch={args.batch}",
+                       "stems": N_STEMS, "audio_seconds": audio_seconds, "sharding": f"windows/{world} + all_gather"},
+            "realtime_factor_4stem": round(audio_seconds * args.steps / dt, 2),
+            "roofline": {"kernel": "conv3x3_kernel<bf16,48,48,64>" if dtype == torch.bfloat16 else "conv3x3_kernel<f32,16,48,64>",
+                         "bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved_tflops / peak, 4), "traffic": None,
+                         "launches": conv_launches, "avg_us": round(conv_ms * 1e3 / max(conv_launches, 1), 2),
+                         "flops_per_chunk": conv_main_flops_per_chunk(cfg)},
+            "stages": stages,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+"""CPU (-m "not gpu"): the N>1 path -- window sharding + one all-gather of stem segments -- with
+world_size 2 over gloo, kernels emulated on the CPU, checked against the reference's demix output."""
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, emul_so, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from audiolab_amd import _lib
+    from audiolab_amd.mdx import Predictor
+    from oracle.toy import synth_mix, toy_net
+    _lib._LIB = _lib.bind(emul_so)          # test-only: emulated kernels on the CPU
+    _lib.DEVICE_TYPE = "cpu"
+    ctx = _lib.Context("cpu")
+
+    class Seam:
+        def run(self, _n, feed):
+            return [torch.from_numpy(toy_net(feed["input"].numpy()))]
+    z = np.load(os.path.join(ROOT, "tests", "golden", "demix.npz"))
+    n, chunks, margin, denoise = (int(v) for v in z["small_a_cfg"])
+    n_fft, hop, dta, dim_f = (int(v) for v in z["small_geom"])
+    args = types.SimpleNamespace(margin=margin, chunks=chunks, denoise=bool(denoise), dim_f=dim_f, dim_t=dta, n_fft=n_fft)
+    pred = Predictor(args, Seam(), ctx=ctx, hop=hop, max_batch=3, sharded=True)
+    out = pred.demix(torch.from_numpy(synth_mix(n, seed=300 + n + chunks))).numpy()
+    err = float(np.max(np.abs(out - z["small_a_out"])))
+    res = torch.tensor([err])
+    dist.all_reduce(res, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        np.save(out_path, np.array([float(res[0])]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_window_ranges_cover_everything():
+    from audiolab_amd.dist import sample_range, window_range
+    for n_win in (0, 1, 5, 8, 53):
+        for world in (1, 2, 3, 8):
+            r = [window_range(n_win, world, k) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n_win
+            assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+            assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+            s = [sample_range(n_win, 100, max(n_win * 100 - 37, 0), world, k) for k in range(world)]
+            assert s[0][0] == 0 and s[-1][1] == max(n_win * 100 - 37, 0)
+
+
+def test_sharded_demix_world2_gloo(emul_lib_path, tmp_path):
+    out_path = str(tmp_path / "err.npy")
+    mp.spawn(_worker, args=(2, _free_port(), emul_lib_path, out_path), nprocs=2, join=True)
+    err = float(np.load(out_path)[0])
+    assert err < 1e-5

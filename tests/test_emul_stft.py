@@ -1,0 +1,62 @@
+"""CPU (-m "not gpu"): the unchanged STFT/iSTFT kernel sources, run through the host emulation
+(tests/cpu_emul), against the golden vectors of the reference and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mdx_oracle as mo
+
+
+def geom_of(arr):
+    n_fft, hop, dta, dim_f = (int(v) for v in arr)
+    return n_fft, hop, dta, dim_f
+
+
+@pytest.mark.parametrize("name", ["p2", "p3", "p15", "full"])
+def test_stft_istft_small_vs_golden(emul, golden_dir, name):
+    from audiolab_amd.mdx import ConvTDFNetTrim
+    z = np.load(os.path.join(golden_dir, "mdx_small.npz"))
+    n_fft, hop, dta, dim_f = geom_of(z[f"{name}_geom"])
+    net = ConvTDFNetTrim("cpu", "Conv-TDF", "vocals", 11, dim_f, dta, n_fft, hop=hop, ctx=emul)
+    x = torch.from_numpy(z[f"{name}_x"])
+    spec = net.stft(x).numpy()
+    ref = z[f"{name}_spec"]
+    assert spec.shape == ref.shape
+    assert np.max(np.abs(spec - ref)) < 3e-6 * np.max(np.abs(ref))
+    y = net.istft(torch.from_numpy(ref)).numpy()
+    assert y.shape == z[f"{name}_y"].shape
+    assert np.max(np.abs(y - z[f"{name}_y"])) < 1e-5
+    y2 = net.istft(torch.from_numpy(z[f"{name}_s2"])).numpy()
+    assert np.max(np.abs(y2 - z[f"{name}_y2"])) < 1e-5 * max(1.0, np.max(np.abs(z[f"{name}_y2"])))
+
+
+def test_layout_convert_and_nhwc_roundtrip(emul):
+    from audiolab_amd import _lib
+    from audiolab_amd.mdx import StftPlan
+    plan = StftPlan(emul, 384, 64, 160, 16)
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.standard_normal((2, 2, plan.chunk_size)).astype(np.float32))
+    ref = plan.stft_strided(x, plan.chunk_size, 2 * plan.chunk_size, 2, torch.float32, _lib.LAYOUT_REF)
+    nhwc = plan.stft_strided(x, plan.chunk_size, 2 * plan.chunk_size, 2, torch.float32, _lib.LAYOUT_NHWC)
+    assert torch.equal(plan.convert(ref, _lib.LAYOUT_REF), nhwc)
+    assert torch.equal(plan.convert(nhwc, _lib.LAYOUT_NHWC), ref)
+    assert torch.equal(nhwc.permute(0, 3, 2, 1).contiguous(), ref)
+    bf = plan.stft_strided(x, plan.chunk_size, 2 * plan.chunk_size, 2, torch.bfloat16, _lib.LAYOUT_NHWC)
+    assert torch.equal(bf, nhwc.to(torch.bfloat16))
+    out = emul.empty((2, 2, plan.chunk_size))
+    plan.istft_strided(nhwc, _lib.LAYOUT_NHWC, out, plan.chunk_size, 2 * plan.chunk_size, 0, plan.chunk_size,
+                       3 * plan.chunk_size)
+    g = mo.MDXGeometry(160, 16, 384, 64)
+    want = mo.istft(ref.numpy(), g)
+    assert np.max(np.abs(out.numpy() - want)) < 1e-5
+
+
+def test_unsupported_geometry_raises(emul):
+    from audiolab_amd._lib import AlsepError
+    from audiolab_amd.mdx import StftPlan
+    with pytest.raises(AlsepError):
+        StftPlan(emul, 1000, 64, 96, 16)          # no FFT kernel for n_fft=1000
+    with pytest.raises(AlsepError):
+        StftPlan(emul, 256, 64, 96, 2)            # chunk <= n_fft/2: reflect padding undefined

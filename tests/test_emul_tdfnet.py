@@ -1,0 +1,84 @@
+"""CPU (-m "not gpu"): the unchanged TFC-TDF U-Net kernel sources (MFMA emulated lane by lane)
+against the plain torch fp32 reference forward (oracle/tdfnet_oracle.py) at small sizes."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tdfnet_oracle
+
+
+def make(cfg_kwargs, seed=0):
+    from audiolab_amd.synth import synthetic_state_dict
+    from audiolab_amd.tdfnet import TDFNetConfig
+    cfg = TDFNetConfig(**cfg_kwargs)
+    sd = synthetic_state_dict(cfg, seed=seed, calib_frames=cfg.dim_t)
+    return cfg, sd
+
+
+def run_case(emul, cfg_kwargs, dtype, batch, tol, denoise=False):
+    from audiolab_amd.tdfnet import TDFNet
+    cfg, sd = make(cfg_kwargs)
+    net = TDFNet(cfg, sd, ctx=emul, dtype=dtype, max_batch=2)
+    g = torch.Generator().manual_seed(7)
+    x_ref = torch.randn((batch, 4, cfg.dim_f, cfg.dim_t), generator=g) * 4.0
+    if dtype == torch.bfloat16:
+        x_ref = x_ref.to(torch.bfloat16).float()            # same rounded input for both sides
+    want = tdfnet_oracle.forward(sd, x_ref, cfg.num_blocks, cfg.l, cfg.bn)
+    if denoise:
+        want = 0.5 * want - 0.5 * tdfnet_oracle.forward(sd, -x_ref, cfg.num_blocks, cfg.l, cfg.bn)
+    x = x_ref.permute(0, 3, 2, 1).contiguous().to(dtype)    # NHWC [B,T,F,4]
+    got = net.forward_nhwc(x, denoise=denoise).float().permute(0, 3, 2, 1)
+    scale = float(want.abs().max())
+    err = float((got - want).abs().max())
+    assert scale > 1e-3, "degenerate reference output"
+    assert err < tol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+    return net, x_ref, want
+
+
+def test_net_f32_small_generic_tiles(emul):
+    """g=16: exercises the 16-channel fall-back conv tiles, padded TDF rows (f/bn = 2, 4, 8) and K."""
+    run_case(emul, dict(dim_f=64, dim_t=16, n_fft=256, hop=64, num_blocks=5, g=16), torch.float32, 3, 2e-4)
+
+
+def test_net_f32_g48_main_tiles_and_seam(emul):
+    """g=48: the main fp32 conv tile (KC=16, BN=48), odd tile counts (F=96 -> TW=32), denoise
+    average, and the ORT-shaped run() seam in the reference layout."""
+    kw = dict(dim_f=96, dim_t=8, n_fft=256, hop=64, num_blocks=3, g=48, bn=4)
+    net, x_ref, _ = run_case(emul, kw, torch.float32, 2, 2e-4, denoise=True)
+    cfg, sd = make(kw)
+    plain = tdfnet_oracle.forward(sd, x_ref, cfg.num_blocks, cfg.l, cfg.bn)
+    pred = net.run(None, {"input": x_ref})[0]              # reference layout in/out (patch_separate.py:52)
+    assert pred.shape == x_ref.shape
+    assert float((pred - plain).abs().max()) < 2e-4 * float(plain.abs().max())
+
+
+def test_net_bf16_g48(emul):
+    """bf16 storage + bf16 MFMA (KC=48, BN=48 tile with the zero-padded 14th k-step).  The bound
+    is bf16 rounding (2^-8 per stored activation) amplified by the random-weight network."""
+    from audiolab_amd.tdfnet import TDFNet
+    for nb, tol in ((1, 2e-2), (3, 6e-2)):
+        cfg, sd = make(dict(dim_f=64, dim_t=16, n_fft=256, hop=64, num_blocks=nb, g=48))
+        net = TDFNet(cfg, sd, ctx=emul, dtype=torch.bfloat16, max_batch=2)
+        g = torch.Generator().manual_seed(7)
+        x_ref = (torch.randn((2, 4, cfg.dim_f, cfg.dim_t), generator=g) * 4.0).to(torch.bfloat16)
+        want = tdfnet_oracle.forward(sd, x_ref.float(), cfg.num_blocks, cfg.l, cfg.bn)
+        got = net.forward_nhwc(x_ref.permute(0, 3, 2, 1).contiguous()).float().permute(0, 3, 2, 1)
+        rel = float((got - want).norm() / want.norm())
+        assert rel < tol, f"num_blocks={nb}: rel L2 {rel:.3e}"
+
+
+def test_net_rejects_bad_inputs(emul):
+    from audiolab_amd._lib import AlsepError
+    from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
+    cfg, sd = make(dict(dim_f=64, dim_t=16, n_fft=256, hop=64, num_blocks=3, g=16))
+    net = TDFNet(cfg, sd, ctx=emul)
+    with pytest.raises(AlsepError):
+        net.forward_nhwc(torch.zeros((1, 16, 64, 3)))                  # wrong channel count
+    with pytest.raises(AlsepError):
+        net.forward_nhwc(torch.zeros((1, 16, 64, 4), dtype=torch.bfloat16))   # wrong dtype
+    bad = dict(sd)
+    del bad["ds.0.0.weight"]
+    with pytest.raises((AlsepError, KeyError)):
+        TDFNet(cfg, bad, ctx=emul)
+    with pytest.raises(AlsepError):                                     # dim_f not divisible by 2^n
+        TDFNet(TDFNetConfig(dim_f=36, dim_t=16, n_fft=256, hop=64, num_blocks=5, g=16), sd, ctx=emul)

@@ -1,0 +1,197 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the golden vectors of the
+reference, the CPU oracle, and size-independent properties at BASELINE.json's sizes.
+Tolerances: spectrogram values 3e-6 relative to the largest bin (fp32 FFT), PCM |delta| < 1e-4
+(north_star), bf16 network reported as relative L2 against the fp32 oracle."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from audiolab_amd import _lib
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return _lib.Context("cuda:0")
+
+
+def toy_lin(s):          # torch twins of oracle/toy.py (stand-in networks for the runner seam)
+    return 0.6 * s + 0.3 * torch.roll(s, 1, dims=3) + 0.1 * s[:, [2, 3, 0, 1]]
+
+
+def toy_aff(s):
+    return 0.7 * s + 0.05 * torch.abs(torch.roll(s, 2, dims=2))
+
+
+class Seam:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def run(self, _n, feed):
+        return [self.fn(feed["input"])]
+
+
+NETS = {"lin": toy_lin, "aff": toy_aff}
+
+
+@pytest.mark.parametrize("name", ["p2", "p3", "p15", "full"])
+def test_stft_istft_small_golden(ctx, golden_dir, name):
+    from audiolab_amd.mdx import ConvTDFNetTrim
+    z = np.load(os.path.join(golden_dir, "mdx_small.npz"))
+    n_fft, hop, dta, dim_f = (int(v) for v in z[f"{name}_geom"])
+    net = ConvTDFNetTrim("cuda:0", "Conv-TDF", "vocals", 11, dim_f, dta, n_fft, hop=hop, ctx=ctx)
+    spec = net.stft(torch.from_numpy(z[f"{name}_x"]).cuda()).cpu().numpy()
+    assert np.max(np.abs(spec - z[f"{name}_spec"])) < 3e-6 * np.max(np.abs(z[f"{name}_spec"]))
+    y = net.istft(torch.from_numpy(z[f"{name}_spec"]).cuda()).cpu().numpy()
+    assert np.max(np.abs(y - z[f"{name}_y"])) < 1e-5
+    y2 = net.istft(torch.from_numpy(z[f"{name}_s2"]).cuda()).cpu().numpy()
+    assert np.max(np.abs(y2 - z[f"{name}_y2"])) < 1e-5 * max(1.0, np.max(np.abs(z[f"{name}_y2"])))
+
+
+@pytest.mark.parametrize("name", ["n6144", "n7680", "n4096"])
+def test_stft_istft_real_geometry_golden(ctx, golden_dir, name):
+    from audiolab_amd.mdx import ConvTDFNetTrim
+    z = np.load(os.path.join(golden_dir, "mdx_real.npz"))
+    n_fft, hop, dta, dim_f = (int(v) for v in z[f"{name}_geom"])
+    net = ConvTDFNetTrim("cuda:0", "Conv-TDF", "vocals", 11, dim_f, dta, n_fft, ctx=ctx)
+    x = np.random.default_rng(int(z[f"{name}_seed"])).standard_normal((2, 2, net.chunk_size)).astype(np.float32)
+    spec_d = net.stft(torch.from_numpy(x).cuda())
+    spec = spec_d.cpu().numpy()
+    scale = np.max(np.abs(spec))
+    assert np.max(np.abs(spec[:, :, :8, :4] - z[f"{name}_spec_lo"])) < 3e-6 * scale
+    assert np.max(np.abs(spec[:, :, -8:, -4:] - z[f"{name}_spec_hi"])) < 3e-6 * scale
+    assert np.max(np.abs(spec.reshape(-1)[z[f"{name}_spec_idx"]] - z[f"{name}_spec_val"])) < 3e-6 * scale
+    l2 = float(np.sqrt((spec.astype(np.float64) ** 2).sum()))
+    assert abs(l2 - float(z[f"{name}_spec_l2"])) < 1e-5 * float(z[f"{name}_spec_l2"])
+    y = net.istft(spec_d).cpu().numpy()
+    assert np.max(np.abs(y.reshape(-1)[z[f"{name}_y_idx"]] - z[f"{name}_y_val"])) < 1e-5
+    assert np.max(np.abs(y[:, :, :64] - z[f"{name}_y_head"])) < 1e-5
+    assert np.max(np.abs(y[:, :, -64:] - z[f"{name}_y_tail"])) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
+def test_demix_small_golden(ctx, golden_dir, tag):
+    from audiolab_amd.mdx import Predictor
+    from oracle.toy import synth_mix
+    z = np.load(os.path.join(golden_dir, "demix.npz"))
+    n_fft, hop, dta, dim_f = (int(v) for v in z["small_geom"])
+    n, chunks, margin, denoise = (int(v) for v in z[f"small_{tag}_cfg"])
+    args = types.SimpleNamespace(margin=margin, chunks=chunks, denoise=bool(denoise), dim_f=dim_f, dim_t=dta, n_fft=n_fft)
+    pred = Predictor(args, Seam(NETS[str(z[f"small_{tag}_net"])]), ctx=ctx, hop=hop)
+    out = pred.demix(torch.from_numpy(synth_mix(n, seed=300 + n + chunks)).cuda()).cpu().numpy()
+    assert out.shape == z[f"small_{tag}_out"].shape
+    assert np.max(np.abs(out - z[f"small_{tag}_out"])) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["r0", "r15"])
+def test_demix_30s_real_geometry_golden(ctx, golden_dir, tag):
+    """configs[0] size: 30 s stereo, n_fft 6144, dim_f 3072, dim_t 256 -- the reference's demix output."""
+    from audiolab_amd.mdx import Predictor
+    from oracle.toy import synth_mix
+    z = np.load(os.path.join(golden_dir, "demix.npz"))
+    n, chunks, margin, denoise = (int(v) for v in z[f"real_{tag}_cfg"])
+    args = types.SimpleNamespace(margin=margin, chunks=chunks, denoise=bool(denoise), dim_f=3072, dim_t=8, n_fft=6144)
+    pred = Predictor(args, Seam(NETS[str(z[f"real_{tag}_net"])]), ctx=ctx)
+    out = pred.demix(torch.from_numpy(synth_mix(n)).cuda()).cpu().numpy()
+    assert out.shape == (1, 2, n)
+    tol = 2e-5
+    assert np.max(np.abs(out.reshape(-1)[z[f"real_{tag}_idx"]] - z[f"real_{tag}_val"])) < tol
+    assert np.max(np.abs(out[0, :, ::2003] - z[f"real_{tag}_strided"])) < tol
+    gen = 1024 * 255 - 6144
+    assert np.max(np.abs(out[0, :, gen - 64: gen + 64] - z[f"real_{tag}_seam"])) < tol
+    assert np.max(np.abs(out[0, :, 15 * 44100 - 64: 15 * 44100 + 64] - z[f"real_{tag}_seg"])) < tol
+
+
+def _net_case(ctx, kw, dtype, batch, seed=7):
+    from audiolab_amd.synth import synthetic_state_dict
+    from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
+    from oracle import tdfnet_oracle
+    cfg = TDFNetConfig(**kw)
+    sd = synthetic_state_dict(cfg, seed=0, calib_frames=min(cfg.dim_t, 32))
+    net = TDFNet(cfg, sd, ctx=ctx, dtype=dtype, max_batch=2)
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn((batch, 4, cfg.dim_f, cfg.dim_t), generator=g) * 4.0).to(dtype).float()
+    want = tdfnet_oracle.forward(sd, x, cfg.num_blocks, cfg.l, cfg.bn)
+    got = net.forward_nhwc(x.permute(0, 3, 2, 1).contiguous().to(dtype).cuda()).float().cpu().permute(0, 3, 2, 1)
+    return got, want, net, sd, cfg
+
+
+def test_net_f32_vs_torch_reference(ctx):
+    for kw in (dict(dim_f=64, dim_t=16, n_fft=256, hop=64, num_blocks=5, g=16),
+               dict(dim_f=96, dim_t=8, n_fft=256, hop=64, num_blocks=3, g=48, bn=4),
+               dict(dim_f=256, dim_t=32, n_fft=512, hop=128, num_blocks=7, g=48),
+               dict(dim_f=256, dim_t=64, n_fft=512, hop=128, num_blocks=11, g=32)):
+        got, want, *_ = _net_case(ctx, kw, torch.float32, 3)
+        err = float((got - want).abs().max() / want.abs().max())
+        assert err < 5e-4, f"{kw}: max rel err {err:.3e}"
+
+
+def test_net_bf16_vs_torch_reference(ctx):
+    for nb, tol in ((1, 2e-2), (3, 6e-2), (7, 0.5)):
+        got, want, *_ = _net_case(ctx, dict(dim_f=256, dim_t=32, n_fft=512, hop=128, num_blocks=nb, g=48), torch.bfloat16, 2)
+        rel = float((got - want).norm() / want.norm())
+        print(f"bf16 num_blocks={nb}: rel L2 {rel:.3e}")
+        assert rel < tol
+
+
+def test_full_size_mdx_f32_vs_oracle(ctx):
+    """The bench architecture (L=11, g=48, dim_f 3072, dim_t 256, n_fft 6144) in fp32 on ~9 s of
+    audio (2 model windows) against the CPU oracle end to end: |delta| < 1e-4 PCM (north_star)."""
+    from audiolab_amd.mdx import Predictor
+    from audiolab_amd.synth import synth_mix, synthetic_state_dict
+    from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
+    from oracle import mdx_oracle, tdfnet_oracle
+    cfg = TDFNetConfig()
+    sd = synthetic_state_dict(cfg, seed=0)
+    net = TDFNet(cfg, sd, ctx=ctx, dtype=torch.float32, max_batch=2)
+    n = 400000
+    mix = synth_mix(n)
+    args = types.SimpleNamespace(margin=44100, chunks=0, denoise=False, dim_f=cfg.dim_f, dim_t=8, n_fft=cfg.n_fft)
+    got = Predictor(args, net, ctx=ctx).demix(torch.from_numpy(mix).cuda()).cpu().numpy()
+
+    def model_run(spek):
+        with torch.no_grad():
+            return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)),
+                                         cfg.num_blocks, cfg.l, cfg.bn).numpy()
+    g = mdx_oracle.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
+    want = mdx_oracle.demix(mix, g, model_run, chunks=0, margin=44100, dtype=np.float32)
+    err = float(np.max(np.abs(got - want)))
+    print(f"full-size fp32: max|delta| = {err:.3e}, peak = {np.max(np.abs(want)):.3f}, rms = {np.sqrt(np.mean(want ** 2)):.3f}")
+    assert np.max(np.abs(want)) > 1e-2
+    assert err < 1e-4
+
+
+def test_properties_at_baseline_size(ctx):
+    """configs[1] size (5 min stereo): the runner is linear with a linear network, and shifting the
+    track by one model window (gen samples) shifts the interior of the output by the same amount."""
+    from audiolab_amd.mdx import Predictor
+    from audiolab_amd.synth import synth_mix
+    n = 13230000
+    args = types.SimpleNamespace(margin=44100, chunks=0, denoise=False, dim_f=3072, dim_t=8, n_fft=6144)
+    pred = Predictor(args, Seam(toy_lin), ctx=ctx, max_batch=16)
+    a = torch.from_numpy(synth_mix(n)).cuda()
+    b = torch.from_numpy(synth_mix(n, seed=99)).cuda()
+    ya, yb = pred.demix(a), pred.demix(b)
+    yc = pred.demix(0.5 * a - 2.0 * b)
+    assert float((yc - (0.5 * ya - 2.0 * yb)).abs().max()) < 5e-5
+    gen = 1024 * 255 - 6144
+    shifted = torch.zeros_like(a)
+    shifted[:, gen:] = a[:, :-gen]
+    ys = pred.demix(shifted)
+    lo, hi = 2 * gen, n - 2 * gen
+    assert float((ys[0, :, lo:hi] - ya[0, :, lo - gen:hi - gen]).abs().max()) < 5e-5
+
+
+def test_empty_and_tiny_inputs(ctx):
+    from audiolab_amd.mdx import Predictor
+    args = types.SimpleNamespace(margin=44100, chunks=15, denoise=True, dim_f=3072, dim_t=8, n_fft=6144)
+    pred = Predictor(args, Seam(toy_aff), ctx=ctx)
+    out = pred.demix(torch.zeros((2, 1000), device="cuda"))
+    assert out.shape == (1, 2, 1000) and float(out.abs().max()) == 0.0
+    with pytest.raises(Exception):
+        pred.demix(torch.zeros((3, 1000), device="cuda"))
