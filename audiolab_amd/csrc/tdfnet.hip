@@ -188,6 +188,119 @@ conv3x3_kernel(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 3x3 convolution, main path (Cin, Cout multiples of 48): same tiling as conv3x3_kernel but
+//  * the halo patch chunk and the weight block are written to LDS by LDS-DMA
+//    (global_load_lds_dwordx4: no VGPR staging, all loads of a stage in flight at once); lanes
+//    that fall outside the image read a 16-byte zero page instead, so padding costs no branch
+//    in the math loop;
+//  * LDS images are conflict-free for ds_read_b128 without padding: pixel stride 96 B for the
+//    patch (6 slots: the 16-lane read groups land on 16 distinct slots), weight rows (896 B)
+//    XOR-swizzled by (row>>1)&7 on the 16-byte group index (pre-swizzled in the packed image,
+//    LDS-DMA writes linearly; cdna_hip_programming.md rule 21);
+//  * 79.1 KiB of LDS per workgroup -> two workgroups per CU, so one stages while the other
+//    runs its MFMAs.
+// ------------------------------------------------------------------------------------------
+template <int TW>
+struct ConvB16 {
+    static constexpr int KC = 48, BN = 48, G = 8, CG = 6, NG = 54, NS = 14, WG = 56;   // WG: groups per weight row
+    static constexpr int TH = 256 / TW, PW = TW + 2, PH = TH + 2;
+    static constexpr int PGROUPS = PH * PW * CG;
+    static constexpr int WGROUPS = BN * WG;
+    static constexpr size_t lds_bytes = 16 * (size_t)(PGROUPS + WGROUPS);
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    // per-lane 16-byte source, wave-uniform LDS base: lane l lands at base + 16*l
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int TW>
+__global__ void __launch_bounds__(kThreads, 2)
+conv3x3_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
+                    const float* __restrict__ scale, const float* __restrict__ shift,
+                    const bf16_t* __restrict__ zero_page, int Th, int Fw, int Cin, int Cout, int tiles_t,
+                    int tiles_f, int ntiles) {
+    typedef ConvB16<TW> Cf;
+    bf16_t* patch = reinterpret_cast<bf16_t*>(alsep_smem);
+    bf16_t* wts = patch + (size_t)Cf::PGROUPS * 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    int tile = xcd_remap(blockIdx.x, ntiles);
+    const int tf = tile % tiles_f;  tile /= tiles_f;
+    const int tt = tile % tiles_t;
+    const int64_t b = tile / tiles_t;
+    const int t0 = tt * Cf::TH, f0 = tf * TW;
+    const int ny = blockIdx.y;
+    const int nq = Cin / Cf::KC;
+
+    int pbase[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int pm = wave * 64 + ni * 16 + l15;
+        pbase[ni] = ((pm / TW) * Cf::PW + (pm % TW)) * Cf::KC;
+    }
+    const int wswz = l15 >> 1;                               // (row >> 1) & 7 for row = 16*mi + l15
+    f32x4 acc[3][4];
+#pragma unroll
+    for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bf16_t* xb = X + b * (int64_t)Th * Fw * Cin;
+    for (int q = 0; q < nq; ++q) {
+        __syncthreads();                                     // previous chunk's fragment reads are done
+        for (int i = wave; i * 64 < Cf::PGROUPS; i += 4) {
+            const int gidx = i * 64 + lane;
+            if (gidx < Cf::PGROUPS) {
+                const int pix = gidx / Cf::CG, g = gidx % Cf::CG;
+                const int t = t0 - 1 + pix / Cf::PW, f = f0 - 1 + pix % Cf::PW;
+                const bf16_t* src = (t >= 0 && t < Th && f >= 0 && f < Fw)
+                                        ? xb + ((int64_t)t * Fw + f) * Cin + q * Cf::KC + g * 8
+                                        : zero_page;
+                glds16(src, patch + (size_t)i * 64 * 8);
+            }
+        }
+        const bf16_t* wsrc = Wp + ((int64_t)ny * nq + q) * (Cf::WGROUPS * 8);
+        for (int i = wave; i < Cf::WGROUPS / 64; i += 4) glds16(wsrc + ((size_t)i * 64 + lane) * 8, wts + (size_t)i * 64 * 8);
+        __syncthreads();                                     // drains the LDS-DMA (vmcnt(0)) before the barrier
+#pragma unroll 2
+        for (int s = 0; s < Cf::NS; ++s) {
+            const int grp = 4 * s + lq;
+            const int gc = grp < Cf::NG ? grp : Cf::NG - 1;   // padded groups: weights are zero there
+            const int tap = gc / Cf::CG, cg = gc % Cf::CG;
+            const int koff = ((tap / 3) * Cf::PW + (tap % 3)) * Cf::KC + cg * 8;
+            bf16x8 xf[4], wf[3];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) xf[ni] = lds_frag<bf16_t>(patch + pbase[ni] + koff);
+#pragma unroll
+            for (int mi = 0; mi < 3; ++mi) wf[mi] = lds_frag<bf16_t>(wts + ((mi * 16 + l15) * Cf::WG + (grp ^ wswz)) * 8);
+#pragma unroll
+            for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) mma_step(acc[mi][ni], wf[mi], xf[ni]);
+        }
+    }
+    bf16_t* yb = Y + b * (int64_t)Th * Fw * Cout;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int pm = wave * 64 + ni * 16 + l15;
+        const int t = t0 + pm / TW, f = f0 + pm % TW;
+        if (t < Th && f < Fw) {
+#pragma unroll
+            for (int mi = 0; mi < 3; ++mi) {
+                const int co = ny * Cf::BN + mi * 16 + 4 * lq;
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[mi][ni][r], scale[co + r], shift[co + r]), 0.f);
+                store4(yb + ((int64_t)t * Fw + f) * Cout + co, y);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // generic tile GEMM: 64 weight rows x 128 activation columns per workgroup, BK = 8 k-groups.
 // ------------------------------------------------------------------------------------------
 template <typename T>
@@ -398,6 +511,7 @@ struct DevBuf {
 struct ConvLayer {       // 3x3
     DevBuf w, scale, shift;
     int cin = 0, cout = 0;
+    bool dma_path = false;   // packed for conv3x3_bf16_kernel (swizzled, unpadded)
 };
 struct GemmLayer {       // ds / us / tdf
     DevBuf w, bias, scale, shift;
@@ -416,7 +530,7 @@ struct alsep_net {
     alsep_net_config cfg{};
     int n = 0;
     std::vector<DevBuf> owned;
-    DevBuf first_w, first_scale, first_shift, final_w, final_b;
+    DevBuf first_w, first_scale, first_shift, final_w, final_b, zero_page;
     std::vector<Block> enc, dec;
     Block bott;
     std::vector<GemmLayer> ds, us;
@@ -484,6 +598,28 @@ std::vector<T> pack_conv3x3(const std::vector<float>& w, int cin, int cout) {
     return out;
 }
 
+// packed image for conv3x3_bf16_kernel: [ny][q][48 rows][56 groups of 8], group index XOR (row>>1)&7
+std::vector<bf16_t> pack_conv3x3_dma(const std::vector<float>& w, int cin, int cout) {
+    typedef ConvB16<64> Cf;
+    const int nq = cin / Cf::KC, nn = cout / Cf::BN;
+    std::vector<bf16_t> out((size_t)nn * nq * Cf::WGROUPS * 8, host_cast<bf16_t>(0.f));
+    for (int j = 0; j < nn; ++j)
+        for (int q = 0; q < nq; ++q)
+            for (int r = 0; r < Cf::BN; ++r)
+                for (int grp = 0; grp < Cf::NG; ++grp)
+                    for (int e = 0; e < 8; ++e) {
+                        const int tap = grp / Cf::CG, cg = grp % Cf::CG;
+                        const int ci = q * Cf::KC + cg * 8 + e, co = j * Cf::BN + r;
+                        const float v = w[(((size_t)co * cin + ci) * 3 + tap / 3) * 3 + tap % 3];
+                        const int pg = grp ^ ((r >> 1) & 7);
+                        out[((((size_t)j * nq + q) * Cf::BN + r) * Cf::WG + pg) * 8 + e] = host_cast<bf16_t>(v);
+                    }
+    return out;
+}
+
+template <typename T> constexpr bool is_bf16() { return false; }
+template <> constexpr bool is_bf16<bf16_t>() { return true; }
+
 template <typename T>
 int make_conv(alsep_net* net, const TensorMap& tm, const std::string& p, int c, ConvLayer* L) {
     auto w = find(tm, p + ".weight", (int64_t)c * c * 9, net->ctx);
@@ -492,7 +628,11 @@ int make_conv(alsep_net* net, const TensorMap& tm, const std::string& p, int c, 
     if (!w || !sc || !sh) return ALSEP_ERR_ARG;
     L->cin = L->cout = c;
     int rc;
-    if (conv_uses_main<T>(c, c)) {
+    if (is_bf16<T>() && c % 48 == 0) {
+        L->dma_path = true;
+        auto pk = pack_conv3x3_dma(*w, c, c);
+        rc = upload(net, pk.data(), pk.size() * sizeof(bf16_t), &L->w);
+    } else if (conv_uses_main<T>(c, c)) {
         auto pk = pack_conv3x3<T, ConvSel<T>::KC, ConvSel<T>::BN>(*w, c, c);
         rc = upload(net, pk.data(), pk.size() * sizeof(T), &L->w);
     } else {
@@ -567,6 +707,8 @@ int build_net(alsep_net* net, const TensorMap& tm) {
         if (!fw || !fb) return ALSEP_ERR_ARG;
         if ((rc = upload(net, fw->data(), fw->size() * 4, &net->final_w))) return rc;
         if ((rc = upload(net, fb->data(), 16, &net->final_b))) return rc;
+        const std::vector<char> zeros(256, 0);
+        if ((rc = upload(net, zeros.data(), zeros.size(), &net->zero_page))) return rc;
     }
     net->enc.resize(n); net->dec.resize(n); net->ds.resize(n); net->us.resize(n);
     int c = g, f = cfg.dim_f;
@@ -636,8 +778,35 @@ int run_conv_tw(alsep_ctx* ctx, const ConvLayer& L, const T* X, T* Y, int64_t B,
     return launch_conv<T, KC, BN, 16>(ctx, L, X, Y, B, Th, Fw);
 }
 
+template <int TW>
+int launch_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zero_page, int64_t B,
+                    int Th, int Fw) {
+    typedef ConvB16<TW> Cf;
+    const int tiles_t = (int)ceil_div64(Th, Cf::TH), tiles_f = (int)ceil_div64(Fw, TW);
+    const int64_t ntiles = B * tiles_t * tiles_f;
+    if (ntiles > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "conv3x3: too many tiles");
+    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)Cf::lds_bytes));
+    ProfScope prof(ctx, TW == 64 ? ALSEP_PROF_CONV3X3 : ALSEP_PROF_CONV3X3_SMALL);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<TW>), dim3((unsigned)ntiles, L.cout / Cf::BN), dim3(kThreads), Cf::lds_bytes,
+                       ctx->stream, X, Y, (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page,
+                       Th, Fw, L.cin, L.cout, tiles_t, tiles_f, (int)ntiles);
+    ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_kernel");
+    return ALSEP_OK;
+}
+
+int run_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zp, int64_t B, int Th, int Fw) {
+    if (Fw >= 64 && Fw % 64 == 0) return launch_conv_dma<64>(ctx, L, X, Y, zp, B, Th, Fw);
+    if (Fw >= 32) return launch_conv_dma<32>(ctx, L, X, Y, zp, B, Th, Fw);
+    return launch_conv_dma<16>(ctx, L, X, Y, zp, B, Th, Fw);
+}
+int run_conv_dma(alsep_ctx* ctx, const ConvLayer&, const float*, float*, const float*, int64_t, int, int) {
+    return alsep_fail(ctx, ALSEP_ERR_STATE, "LDS-DMA conv path is bf16 only");
+}
+
 template <typename T>
-int run_conv(alsep_ctx* ctx, const ConvLayer& L, const T* X, T* Y, int64_t B, int Th, int Fw) {
+int run_conv(alsep_ctx* ctx, const ConvLayer& L, const T* X, T* Y, int64_t B, int Th, int Fw, const void* zero_page) {
+    if (L.dma_path) return run_conv_dma(ctx, L, X, Y, (const T*)zero_page, B, Th, Fw);
     if (conv_uses_main<T>(L.cin, L.cout)) return run_conv_tw<T, ConvSel<T>::KC, ConvSel<T>::BN>(ctx, L, X, Y, B, Th, Fw);
     return run_conv_tw<T, ConvSel16<T>::KC, ConvSel16<T>::BN>(ctx, L, X, Y, B, Th, Fw);
 }
@@ -685,7 +854,7 @@ int run_block(alsep_ctx* ctx, const alsep_net* net, const Block& blk, const T* c
     const int l = (int)blk.tfc.size();
     for (int j = 0; j < l; ++j) {
         T* dst = pp[j & 1];
-        if ((rc = run_conv<T>(ctx, blk.tfc[j], src, dst, B, Th, Fw))) return rc;
+        if ((rc = run_conv<T>(ctx, blk.tfc[j], src, dst, B, Th, Fw, net->zero_page.p))) return rc;
         src = dst;
     }
     if (blk.tdf.size() == 2) {

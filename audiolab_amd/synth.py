@@ -39,16 +39,31 @@ def _kaiming_uniform(gen: torch.Generator, shape, fan_in: int) -> torch.Tensor:
     return (torch.rand(shape, generator=gen) * 2 - 1) * bound
 
 
+def proxy_spectrogram(cfg: TDFNetConfig, frames: int, seed: int) -> torch.Tensor:
+    """[1,4,dim_f,frames] spectrogram of the synthetic test signal (torch CPU stft, data only):
+    the statistics the random network is calibrated on must look like its real input --
+    sine peaks ~40x above the noise floor -- because the multiplicative skips make the
+    network's gain depend strongly on the input's magnitude distribution."""
+    n = cfg.hop * (frames - 1)
+    x = torch.from_numpy(synth_mix(n + 4 * cfg.hop, seed=seed + 1234)[:, 2 * cfg.hop: 2 * cfg.hop + n].copy())
+    z = torch.stft(x, cfg.n_fft, cfg.hop, window=torch.hann_window(cfg.n_fft, periodic=True), center=True,
+                   return_complex=True)[:, : cfg.dim_f]                       # [2, dim_f, frames]
+    z = torch.view_as_real(z).permute(0, 3, 1, 2).reshape(1, 4, cfg.dim_f, frames)
+    return z.contiguous().float()
+
+
 def synthetic_state_dict(cfg: TDFNetConfig, seed: int = 0, input_rms: float = 4.0,
-                         calib_frames: int = 32) -> Dict[str, torch.Tensor]:
-    """Random-init TFC-TDF U-Net weights with calibrated BatchNorm statistics (CPU tensors)."""
+                         calib_frames: int = 32, calib: str = "signal") -> Dict[str, torch.Tensor]:
+    """Random-init TFC-TDF U-Net weights with calibrated BatchNorm statistics (CPU tensors).
+    calib="signal": statistics of the synthetic test signal's spectrogram (default);
+    calib="noise": white Gaussian spectrogram of RMS ``input_rms`` (small unit-test nets)."""
     gen = torch.Generator().manual_seed(seed)
     sd: Dict[str, torch.Tensor] = {}
     n, g = cfg.n, cfg.g
 
-    def add_bn(p: str, c: int):
-        sd[p + ".weight"] = torch.ones(c)
-        sd[p + ".bias"] = torch.zeros(c)
+    def add_bn(p: str, c: int, gamma: float = 1.0, beta: float = 0.0):
+        sd[p + ".weight"] = torch.full((c,), gamma)
+        sd[p + ".bias"] = torch.full((c,), beta)
         sd[p + ".running_mean"] = torch.zeros(c)
         sd[p + ".running_var"] = torch.ones(c)
 
@@ -80,23 +95,29 @@ def synthetic_state_dict(cfg: TDFNetConfig, seed: int = 0, input_rms: float = 4.
     add_block("bottleneck_block", c, f)
     for i in range(n):
         add_conv(f"us.{i}.0", c - g, c, 2, 2, c, transposed=True)
-        add_bn(f"us.{i}.1", c - g)
+        # gate-like up path: relu(0.25*z + 1) stays near 1, so the multiplicative skip modulates
+        # instead of squaring magnitudes (a trained model's skips are tame in the same way)
+        add_bn(f"us.{i}.1", c - g, gamma=0.25, beta=1.0)
         c -= g
         f *= 2
         add_block(f"decoding_blocks.{i}", c, f)
     sd["final_conv.0.weight"] = _kaiming_uniform(gen, (cfg.dim_c, g, 1, 1), g) / math.sqrt(2.0)
     sd["final_conv.0.bias"] = torch.zeros(cfg.dim_c)
-    _calibrate(sd, cfg, gen, input_rms, calib_frames)
+    _calibrate(sd, cfg, gen, input_rms, calib_frames, calib, seed)
     return sd
 
 
 @torch.no_grad()
-def _calibrate(sd: Dict[str, torch.Tensor], cfg: TDFNetConfig, gen: torch.Generator, input_rms: float, frames: int) -> None:
+def _calibrate(sd: Dict[str, torch.Tensor], cfg: TDFNetConfig, gen: torch.Generator, input_rms: float, frames: int,
+               calib: str = "signal", seed: int = 0) -> None:
     """Set every BatchNorm's running_mean/var to its batch statistics on a random proxy input
     and scale final_conv so that the output RMS equals the input RMS."""
     frames = max(frames, 2 ** cfg.n)
     frames -= frames % (2 ** cfg.n)
-    x = torch.randn((1, cfg.dim_c, cfg.dim_f, frames), generator=gen) * input_rms
+    if calib == "signal" and cfg.hop * (frames - 1) > cfg.n_fft // 2:
+        x = proxy_spectrogram(cfg, frames, seed)
+    else:
+        x = torch.randn((1, cfg.dim_c, cfg.dim_f, frames), generator=gen) * input_rms
 
     def bn_relu(y: torch.Tensor, p: str) -> torch.Tensor:
         dims = [0, 2, 3]

@@ -128,11 +128,18 @@ class TDFNet:
             raise AlsepError("only k=3 TFC convolutions are implemented")
         if cfg.bn is None:
             raise AlsepError("bn=None (no TDF) is not implemented")
+        if cfg.dim_f % (2 ** cfg.n) or cfg.dim_t % (2 ** cfg.n) or (cfg.bn and (cfg.dim_f >> cfg.n) % cfg.bn):
+            raise AlsepError(f"dim_f={cfg.dim_f} / dim_t={cfg.dim_t} must be divisible by 2^{cfg.n} (and by bn at the bottleneck)")
+        if cfg.g % 16:
+            raise AlsepError("g must be a multiple of 16")
         self.cfg = cfg
         self.ctx = ctx if ctx is not None else _lib.default_context(None)
         self.dtype = dtype
         self.max_batch = max_batch
-        table = folded_tensors(state_dict, cfg)
+        try:
+            table = folded_tensors(state_dict, cfg)
+        except KeyError as e:
+            raise AlsepError(f"state_dict is missing {e} for this TDFNetConfig") from e
         keep: List[torch.Tensor] = []
         entries = (_lib.TensorEntry * len(table))()
         for i, (name, t) in enumerate(table.items()):

@@ -149,6 +149,32 @@ static inline emul_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, 
     return c;
 }
 
+// LDS-DMA: lane l copies `size` bytes from its own global address to (wave-uniform LDS base) + size*l + off.
+template <typename GP, typename LP>
+static inline void __builtin_amdgcn_global_load_lds(GP g, LP l, unsigned size, unsigned off, unsigned) {
+    std::memcpy((char*)(void*)l + off + (size_t)size * emul::lane_id(), (const void*)g, size);
+}
+
+// ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a
+// 4 x 16 block of 16-bit elements; lane i receives column i of the 4 rows (row q in element q).
+typedef __bf16 emul_bf16x4 __attribute__((ext_vector_type(4)));
+template <typename LP>
+static inline emul_bf16x4 __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LP p) {
+    char* slab = emul::wave_slab();
+    const int l = emul::lane_id();
+    std::memcpy(slab + l * 256, (const void*)p, 8);
+    emul::wave_sync();
+    const int base = l & ~15, i = l & 15;
+    emul_bf16x4 out;
+    for (int q = 0; q < 4; ++q) {
+        __bf16 row[4];
+        std::memcpy(row, slab + (base + 4 * q + i / 4) * 256, 8);
+        out[q] = row[i % 4];
+    }
+    emul::wave_sync();
+    return out;
+}
+
 template <typename T>
 static inline T emul_shfl_src(T v, int src_lane) {
     char* slab = emul::wave_slab();
