@@ -501,6 +501,113 @@ tdf_gemm_kernel(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 TDF linear, main path (C multiple of 48):  Y[bt][f'][c] = act(...sum_f W[f'][f] X[bt][f][c])
+// Workgroup tile: 128 weight rows (f') x 4 column units (a unit = 48 channels of one (b,t));
+// wave w owns unit w.  Activations are the MFMA A operand (D rows = channels, so a lane ends up
+// with 4 consecutive channels = one 8-byte store); their k axis (f) is strided in memory, so the
+// tile is copied as it lies -- [64 f][48 c], 6 KiB per unit, by LDS-DMA -- and fragments are
+// gathered with ds_read_b64_tr_b16 (hardware transpose read).  Each lane quarter lq takes
+// k rows {4lq..4lq+3} and {16+4lq..16+4lq+3} of a 32-wide k-step: eight consecutive 96-byte
+// rows per 32-lane half, which is bank-conflict free; the weight image is packed in the same
+// k order, row-swizzled like the conv weights, and read with ds_read_b128.
+// ------------------------------------------------------------------------------------------
+struct TdfB16 {
+    static constexpr int BM = 128, UN = 4, UC = 48, BK = 64;
+    static constexpr int WGROUPS = BM * (BK / 8);              // 1024
+    static constexpr int XGROUPS = BK * (UC / 8);              // 384 per unit
+    static constexpr size_t lds_bytes = 16 * (size_t)(WGROUPS + UN * XGROUPS);   // 40 KiB
+};
+
+template <bool RESIDUAL>
+__global__ void __launch_bounds__(kThreads, 3)
+tdf_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
+                const float* __restrict__ bias, const float* __restrict__ scale, const float* __restrict__ shift,
+                const bf16_t* __restrict__ R, const bf16_t* __restrict__ zero_page, int M, int K, int Kp,
+                int64_t nunits, int C) {
+    typedef TdfB16 Tc;
+    bf16_t* Ws = reinterpret_cast<bf16_t*>(alsep_smem);
+    bf16_t* Xs = Ws + (size_t)Tc::WGROUPS * 8 + (size_t)(threadIdx.x >> 6) * Tc::XGROUPS * 8;   // this wave's unit
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int row0 = blockIdx.y * Tc::BM;
+    const int upc = C / Tc::UC;
+    const int64_t u = (int64_t)blockIdx.x * Tc::UN + wave;
+    const bool uvalid = u < nunits;
+    const int64_t bt = uvalid ? u / upc : 0;
+    const int cb = uvalid ? (int)(u % upc) * Tc::UC : 0;
+    const bf16_t* xu = X + (bt * K) * (int64_t)C + cb;
+
+    f32x4 acc[3][8];
+#pragma unroll
+    for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transpose-read addressing inside the unit tile [64 k][48 c]: lane j of a 16-lane group
+    // supplies row (j>>2), columns 4*(j&3)..+3 of the 4 x 16 block
+    const int trow = l15 >> 2, tcol = (l15 & 3) * 4;
+    const int wswz = l15 >> 1;
+
+    for (int k0 = 0; k0 < Kp; k0 += Tc::BK) {
+        __syncthreads();
+        for (int i = wave; i < Tc::WGROUPS / 64; i += 4) {
+            const int gidx = i * 64 + lane;
+            glds16(Wp + (int64_t)(row0 + (gidx >> 3)) * Kp + k0 + (gidx & 7) * 8, Ws + (size_t)i * 64 * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < Tc::XGROUPS / 64; ++i) {
+            const int gidx = i * 64 + lane;
+            const int kk = gidx / 6, g = gidx % 6;
+            const bf16_t* src = (uvalid && k0 + kk < K) ? xu + (int64_t)(k0 + kk) * C + g * 8 : zero_page;
+            glds16(src, Xs + (size_t)i * 64 * 8);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xf[3], wf[8];
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni) {
+                const bf16_t* p0 = Xs + (ks * 32 + 4 * lq + trow) * Tc::UC + ni * 16 + tcol;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p0 + 16 * Tc::UC));
+                xf[ni] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) wf[mi] = lds_frag<bf16_t>(Ws + ((mi * 16 + l15) * 8 + ((ks * 4 + lq) ^ wswz)) * 8);
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) mma_step(acc[ni][mi], xf[ni], wf[mi]);
+        }
+    }
+    if (!uvalid) return;
+#pragma unroll
+    for (int ni = 0; ni < 3; ++ni) {
+        const int c = cb + ni * 16 + 4 * lq;
+        float sc[4], sh[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sc[r] = scale[c + r]; sh[r] = shift[c + r]; }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int fo = row0 + mi * 16 + l15;
+            if (fo >= M) continue;
+            const float bv = bias ? bias[fo] : 0.f;
+            const int64_t o = (bt * M + fo) * (int64_t)C + c;
+            float y[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[ni][mi][r] + bv, sc[r], sh[r]), 0.f);
+            if (RESIDUAL) {
+                float x[4];
+                load4(R + o, x);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] += x[r];
+            }
+            store4(Y + o, y);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side: packing + orchestration
 // ------------------------------------------------------------------------------------------
 struct DevBuf {
@@ -517,6 +624,7 @@ struct GemmLayer {       // ds / us / tdf
     DevBuf w, bias, scale, shift;
     int M = 0, K = 0, Kp = 0, Mp = 0;
     bool has_bias = false;
+    bool dma_path = false;   // packed for tdf_bf16_kernel
 };
 struct Block {
     std::vector<ConvLayer> tfc;
@@ -657,6 +765,28 @@ int make_gemm_weights(alsep_net* net, const std::vector<float>& wmk, int M, int 
     return upload(net, pk.data(), pk.size() * sizeof(T), &L->w);
 }
 
+// packed image for tdf_bf16_kernel: [Mp=ceil128][Kp=ceil64]; inside every 64-wide k tile the eight
+// 16-byte groups are stored at (group ^ ((row>>1)&7)); group (ks, lq) holds, for a 32-wide k-step ks,
+// k = {4lq..4lq+3, 16+4lq..16+4lq+3} (the order the transposed activation reads deliver).
+int make_tdf_dma_weights(alsep_net* net, const std::vector<float>& wmk, int M, int K, GemmLayer* L) {
+    typedef TdfB16 Tc;
+    L->M = M; L->K = K;
+    L->Mp = (int)ceil_div64(M, Tc::BM) * Tc::BM;
+    L->Kp = (int)ceil_div64(K, Tc::BK) * Tc::BK;
+    L->dma_path = true;
+    std::vector<bf16_t> pk((size_t)L->Mp * L->Kp, host_cast<bf16_t>(0.f));
+    for (int m = 0; m < M; ++m)
+        for (int kt = 0; kt < L->Kp / Tc::BK; ++kt)
+            for (int g = 0; g < 8; ++g) {
+                const int ks = g >> 2, lq = g & 3, pg = g ^ ((m >> 1) & 7);
+                for (int e = 0; e < 8; ++e) {
+                    const int k = kt * Tc::BK + ks * 32 + (e < 4 ? 4 * lq + e : 16 + 4 * lq + (e - 4));
+                    if (k < K) pk[(size_t)m * L->Kp + kt * Tc::BK + pg * 8 + e] = host_cast<bf16_t>(wmk[(size_t)m * K + k]);
+                }
+            }
+    return upload(net, pk.data(), pk.size() * sizeof(bf16_t), &L->w);
+}
+
 template <typename T>
 int make_block(alsep_net* net, const TensorMap& tm, const std::string& p, int c, int f, Block* blk) {
     const alsep_net_config& cfg = net->cfg;
@@ -676,7 +806,8 @@ int make_block(alsep_net* net, const TensorMap& tm, const std::string& p, int c,
         auto sh = find(tm, q + ".shift", c, net->ctx);
         if (!w || !sc || !sh) return ALSEP_ERR_ARG;
         GemmLayer* L = &blk->tdf[j];
-        int rc = make_gemm_weights<T>(net, *w, fo, fi, L);
+        int rc = (is_bf16<T>() && c % 48 == 0) ? make_tdf_dma_weights(net, *w, fo, fi, L)
+                                               : make_gemm_weights<T>(net, *w, fo, fi, L);
         if (rc) return rc;
         if ((rc = upload(net, sc->data(), c * sizeof(float), &L->scale))) return rc;
         if ((rc = upload(net, sh->data(), c * sizeof(float), &L->shift))) return rc;
@@ -824,9 +955,32 @@ int run_pix(alsep_ctx* ctx, const GemmLayer& L, const T* X, T* Y, const T* skip,
     return ALSEP_OK;
 }
 
+int run_tdf_dma(alsep_ctx* ctx, const GemmLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* R, const bf16_t* zp,
+                int64_t BT, int C) {
+    typedef TdfB16 Tc;
+    const int64_t nunits = BT * (C / Tc::UC);
+    const int64_t gx = ceil_div64(nunits, Tc::UN);
+    if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "tdf: too many column tiles");
+    const float* bias = L.has_bias ? (const float*)L.bias.p : nullptr;
+    ProfScope prof(ctx, ALSEP_PROF_TDF);
+    const dim3 grid((unsigned)gx, L.Mp / Tc::BM);
+    if (R)
+        hipLaunchKernelGGL((tdf_bf16_kernel<true>), grid, dim3(kThreads), Tc::lds_bytes, ctx->stream, X, Y, (const bf16_t*)L.w.p,
+                           bias, (const float*)L.scale.p, (const float*)L.shift.p, R, zp, L.M, L.K, L.Kp, nunits, C);
+    else
+        hipLaunchKernelGGL((tdf_bf16_kernel<false>), grid, dim3(kThreads), Tc::lds_bytes, ctx->stream, X, Y, (const bf16_t*)L.w.p,
+                           bias, (const float*)L.scale.p, (const float*)L.shift.p, R, zp, L.M, L.K, L.Kp, nunits, C);
+    ALSEP_LAUNCH_CHECK(ctx, "tdf_bf16_kernel");
+    return ALSEP_OK;
+}
+int run_tdf_dma(alsep_ctx* ctx, const GemmLayer&, const float*, float*, const float*, const float*, int64_t, int) {
+    return alsep_fail(ctx, ALSEP_ERR_STATE, "LDS-DMA TDF path is bf16 only");
+}
+
 template <typename T>
-int run_tdf(alsep_ctx* ctx, const GemmLayer& L, const T* X, T* Y, const T* R, int64_t BT, int C) {
+int run_tdf(alsep_ctx* ctx, const GemmLayer& L, const T* X, T* Y, const T* R, int64_t BT, int C, const void* zero_page) {
     typedef GemmCfg<T> Gc;
+    if (L.dma_path) return run_tdf_dma(ctx, L, X, Y, R, (const T*)zero_page, BT, C);
     const int64_t nunits = BT * (C / 16);
     const int64_t gx = ceil_div64(nunits, 8);
     if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "tdf_gemm: too many column tiles");
@@ -858,10 +1012,10 @@ int run_block(alsep_ctx* ctx, const alsep_net* net, const Block& blk, const T* c
         src = dst;
     }
     if (blk.tdf.size() == 2) {
-        if ((rc = run_tdf<T>(ctx, blk.tdf[0], src, h, (const T*)nullptr, B * Th, c))) return rc;
-        return run_tdf<T>(ctx, blk.tdf[1], h, dest, src, B * Th, c);
+        if ((rc = run_tdf<T>(ctx, blk.tdf[0], src, h, (const T*)nullptr, B * Th, c, net->zero_page.p))) return rc;
+        return run_tdf<T>(ctx, blk.tdf[1], h, dest, src, B * Th, c, net->zero_page.p);
     }
-    return run_tdf<T>(ctx, blk.tdf[0], src, dest, src, B * Th, c);
+    return run_tdf<T>(ctx, blk.tdf[0], src, dest, src, B * Th, c, net->zero_page.p);
 }
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
