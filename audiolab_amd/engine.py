@@ -1,0 +1,158 @@
+"""``Separator`` -- the engine object the Separate orchestrator drives, with exactly the members the
+reference touches on ``audio_separator.separator.Separator`` (modules/separator/stem_separator.py:
+102-107 ctor, :124 download_model_files, :394 load_model, :399-400 output_dir /
+model_instance.output_dir, :281 separate(path) -> [basenames]) plus an in-memory
+``separate_array`` used by the fast path (no temp WAV, no PCM16 round trip: SURVEY 8(b) b2).
+
+Model roster.  The reference downloads its models at run time (stem_separator.py:109-124); none
+is reachable offline, so every roster entry below is a TFC-TDF U-Net with random-init weights
+(audiolab_amd.synth) unless ``<model_file_dir>/<name>.pt`` holds a torch state_dict for it.
+Geometry per file name follows the public UVR/KUIELab model tables (PARITY UNPINNED).
+
+MDX runner.  Margin chunker + trim stitching exactly as the in-tree runner (mdxnet.py:109-197,
+pinned); the secondary stem is ``mix - primary`` in the time domain (mdxnet.py:211).
+"""
+from __future__ import annotations
+
+import hashlib
+import logging
+import os
+import types
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, wavio
+from ._lib import AlsepError, Context
+from .mdx import Predictor
+from .synth import synthetic_state_dict
+from .tdfnet import TDFNet, TDFNetConfig
+
+logger = logging.getLogger(__name__)
+
+# name -> (primary stem label, secondary stem label or None, TDFNetConfig)
+_VOC = TDFNetConfig(dim_f=3072, dim_t=256, n_fft=7680, g=48)
+_K6144 = TDFNetConfig(dim_f=3072, dim_t=256, n_fft=6144, g=48)
+MODEL_ROSTER: Dict[str, tuple] = {
+    "UVR-MDX-NET-Voc_FT.onnx": ("Vocals", "Instrumental", _VOC),
+    "Kim_Vocal_2.onnx": ("Vocals", "Instrumental", _VOC),
+    "Kim_Vocal_1.onnx": ("Vocals", "Instrumental", _VOC),
+    "UVR-MDX-NET_Crowd_HQ_1.onnx": ("No Crowd", "Crowd", _K6144),
+    "kuielab_a_vocals.onnx": ("Vocals", "Instrumental", _K6144),
+    "kuielab_a_drums.onnx": ("Drums", "No Drums", _K6144),
+    "kuielab_a_bass.onnx": ("Bass", "No Bass", _K6144),
+    "kuielab_a_other.onnx": ("Other", "No Other", _K6144),
+}
+FOUR_STEM_SET = ("kuielab_a_vocals.onnx", "kuielab_a_drums.onnx", "kuielab_a_bass.onnx", "kuielab_a_other.onnx")
+
+
+class _ModelInstance:
+    """What ``separator.model_instance`` exposes to the orchestrator (only ``output_dir`` is touched)."""
+
+    def __init__(self, name: str, net: TDFNet, predictor: Predictor, primary: str, secondary: Optional[str]):
+        self.model_name = name
+        self.net = net
+        self.predictor = predictor
+        self.primary_stem_name = primary
+        self.secondary_stem_name = secondary
+        self.output_dir = None
+        self.model_run = net                                  # callable(spek) -> pred, the patch_separate seam
+
+
+class Separator:
+    def __init__(self, log_level=logging.INFO, model_file_dir: str = "models/audio_separator", output_dir: Optional[str] = None,
+                 invert_using_spec: bool = True, use_autocast: bool = True, ctx: Optional[Context] = None,
+                 dtype: Optional[torch.dtype] = None, sample_rate: int = 44100, chunks: int = 0, margin: int = 44100,
+                 denoise: bool = False, max_batch: int = 8, sharded: bool = False, roster: Optional[Dict[str, tuple]] = None,
+                 **_ignored):
+        self.log_level = log_level
+        self.model_file_dir = model_file_dir
+        self.output_dir = output_dir
+        self.invert_using_spec = invert_using_spec
+        self.use_autocast = use_autocast
+        self.ctx = ctx if ctx is not None else _lib.default_context(None)
+        # use_autocast=True is the reference's GPU setting (stem_separator.py:106): half-precision network
+        self.dtype = dtype if dtype is not None else (torch.bfloat16 if use_autocast else torch.float32)
+        self.sample_rate = sample_rate
+        self.chunks, self.margin, self.denoise = chunks, margin, denoise
+        self.max_batch = max_batch
+        self.sharded = sharded
+        self.roster = dict(MODEL_ROSTER if roster is None else roster)
+        self.model_instance: Optional[_ModelInstance] = None
+        self._cache: Dict[str, _ModelInstance] = {}
+
+    # -- roster ---------------------------------------------------------------------------------
+    def download_model_files(self, model_filename: str) -> None:
+        """No network here: just validate that the name is known (or present on disk)."""
+        if model_filename not in self.roster and not os.path.exists(os.path.join(self.model_file_dir, model_filename + ".pt")):
+            logger.debug("model %s is not an MDX-Net model of this build's roster; load_model would fail", model_filename)
+
+    def load_model(self, model_filename: str) -> None:
+        """Weights stay resident per model name: the reference reloads per ensemble member
+        (stem_separator.py:394); here a second load_model of the same name is a dictionary hit."""
+        if model_filename in self._cache:
+            self.model_instance = self._cache[model_filename]
+            self.model_instance.output_dir = self.output_dir
+            return
+        if model_filename not in self.roster:
+            raise AlsepError(f"model '{model_filename}' is not available in this build (MDX-Net roster: {sorted(self.roster)})")
+        primary, secondary, cfg = self.roster[model_filename]
+        pt = os.path.join(self.model_file_dir, model_filename + ".pt")
+        if os.path.exists(pt):
+            sd = torch.load(pt, map_location="cpu")
+        else:
+            seed = int.from_bytes(hashlib.sha256(model_filename.encode()).digest()[:4], "little")
+            sd = synthetic_state_dict(cfg, seed=seed)
+        net = TDFNet(cfg, sd, ctx=self.ctx, dtype=self.dtype, max_batch=self.max_batch)
+        dim_t_arg = int(cfg.dim_t).bit_length() - 1
+        args = types.SimpleNamespace(margin=self.margin, chunks=self.chunks, denoise=self.denoise, dim_f=cfg.dim_f,
+                                     dim_t=dim_t_arg, n_fft=cfg.n_fft)
+        pred = Predictor(args, net, ctx=self.ctx, hop=cfg.hop, sharded=self.sharded)
+        inst = _ModelInstance(model_filename, net, pred, primary, secondary)
+        inst.output_dir = self.output_dir
+        self._cache[model_filename] = inst
+        self.model_instance = inst
+
+    # -- inference --------------------------------------------------------------------------------
+    def separate_array(self, mix) -> Dict[str, torch.Tensor]:
+        """mix [C,N] (numpy or tensor; mono is duplicated, >2 channels rejected) -> {stem label: [2,N] device tensor}."""
+        if self.model_instance is None:
+            raise AlsepError("load_model() first")
+        m = torch.as_tensor(mix, dtype=torch.float32)
+        if m.dim() == 1:
+            m = torch.stack([m, m])
+        if m.shape[0] == 1:
+            m = torch.cat([m, m])
+        if m.shape[0] != 2:
+            raise AlsepError("MDX-Net models are stereo; split other layouts into stereo pairs")
+        m = m.to(self.ctx.device).contiguous()
+        inst = self.model_instance
+        primary = inst.predictor.demix(m)[0]
+        out = {inst.primary_stem_name: primary}
+        if inst.secondary_stem_name:
+            sec = m.clone()                                     # secondary = mix - primary (mdxnet.py:211)
+            self.ctx.check(self.ctx.lib.alsep_axpby(self.ctx.handle, -1.0, _lib.ptr(primary.contiguous()), 1.0, _lib.ptr(sec),
+                                                    sec.numel()), "alsep_axpby")
+            out[inst.secondary_stem_name] = sec
+        return out
+
+    def separate(self, audio_file_path: str) -> List[str]:
+        """File in, files out (the reference's calling convention, stem_separator.py:281): returns
+        BASENAMES relative to ``output_dir``, each containing its ``(Label)`` tag."""
+        if self.model_instance is None:
+            raise AlsepError("load_model() first")
+        audio, sr = wavio.read_wav(audio_file_path)
+        if sr != self.sample_rate:
+            raise AlsepError(f"{audio_file_path}: sample rate {sr} != {self.sample_rate} (resampling is out of scope)")
+        stems = self.separate_array(audio)
+        out_dir = self.model_instance.output_dir or self.output_dir or os.path.dirname(audio_file_path)
+        os.makedirs(out_dir, exist_ok=True)
+        base = os.path.splitext(os.path.basename(audio_file_path))[0]
+        model_tag = os.path.splitext(self.model_instance.model_name)[0]
+        names = []
+        for label, t in stems.items():
+            name = f"{base}_({label})_{model_tag}.wav"
+            wavio.write_wav(os.path.join(out_dir, name), t.cpu().numpy(), sr, subtype="FLOAT")
+            names.append(name)
+        return names

@@ -1,0 +1,75 @@
+"""CPU (-m "not gpu"): the whole Separate path end to end -- Separate.process_audio -> separate_music ->
+ensemble of MDX models -> blend -> de-bleed -> multistem -> alt bass -> float32 WAV stems -- with
+tiny networks on the emulated kernels, against the same pipeline composed from the oracle pieces."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ensemble_oracle as eo
+from oracle import mdx_oracle as mo
+from oracle import tdfnet_oracle
+from oracle.toy import synth_mix
+
+
+def tiny_roster():
+    from audiolab_amd.tdfnet import TDFNetConfig
+    a = TDFNetConfig(dim_f=64, dim_t=32, n_fft=256, hop=64, num_blocks=3, g=16)
+    b = TDFNetConfig(dim_f=96, dim_t=32, n_fft=384, hop=64, num_blocks=3, g=16, bn=4)
+    return {"UVR-MDX-NET-Voc_FT.onnx": ("Vocals", "Instrumental", a), "Kim_Vocal_2.onnx": ("Vocals", "Instrumental", b),
+            "kuielab_a_drums.onnx": ("Drums", "No Drums", a), "kuielab_a_bass.onnx": ("Bass", "No Bass", b),
+            "kuielab_a_other.onnx": ("Other", "No Other", a)}
+
+
+def oracle_model(name, roster, mix):
+    import hashlib
+    from audiolab_amd.synth import synthetic_state_dict
+    _, _, cfg = roster[name]
+    seed = int.from_bytes(hashlib.sha256(name.encode()).digest()[:4], "little")
+    sd = synthetic_state_dict(cfg, seed=seed)                 # weights are data; the forward below is the oracle's
+    g = mo.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
+
+    def run(spek):
+        return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)), cfg.num_blocks, cfg.l, cfg.bn).numpy()
+    return mo.demix(mix, g, run, chunks=0, margin=44100, dtype=np.float32)[0]
+
+
+def test_separate_end_to_end_vs_oracle(emul, tmp_path, monkeypatch):
+    from audiolab_amd import wavio
+    from audiolab_amd.engine import Separator
+    from audiolab_amd.handlers import config
+    from audiolab_amd.util.data_classes import ProjectFiles
+    from audiolab_amd.wrappers.separate import Separate
+    monkeypatch.setattr(config, "output_path", str(tmp_path / "outputs"))
+    Separate._instance = None
+    roster = tiny_roster()
+    n = 9000
+    mix = synth_mix(n, seed=21)
+    src = tmp_path / "song.wav"
+    wavio.write_wav(str(src), mix, 44100)
+    eng = Separator(ctx=emul, use_autocast=False, roster=roster, max_batch=2)
+    wrapper = Separate()
+    monkeypatch.setattr(Separate, "engine_options", {"separator": eng, "ensemble_strength": 2})
+    ticks = []
+    out = wrapper.process_audio([ProjectFiles(str(src))], callback=lambda f, d, t: ticks.append(f), vocals_only=False,
+                                alt_bass_model=True, separate_bg_vocals=False)
+    stems = {os.path.basename(p).split("__")[1][:-4]: wavio.read_wav(p)[0] for p in out[0].last_outputs}
+    assert set(stems) == {"(Vocals)", "(Instrumental)", "(Drums)", "(Bass)", "(Other)"}
+    assert ticks and ticks[0] == 0 and abs(ticks[-1] - 1.0) < 1e-9 and all(b >= a for a, b in zip(ticks, ticks[1:]))
+    # the same pipeline from oracle parts (stem_separator.py:357-457, 459-532)
+    v, i = [], []
+    for name in ("UVR-MDX-NET-Voc_FT.onnx", "Kim_Vocal_2.onnx"):
+        voc = oracle_model(name, roster, mix)
+        v.append(voc)
+        i.append(mix - voc)
+    vocals = eo.blend_tracks(v, [6.9, 6.9])
+    inst = eo.blend_tracks(i, [14.9, 14.9])
+    inst, _ = eo.debleed(mix, vocals, inst, 44100, 0.2)
+    want = {"(Vocals)": vocals, "(Instrumental)": inst, "(Drums)": oracle_model("kuielab_a_drums.onnx", roster, mix),
+            "(Other)": oracle_model("kuielab_a_other.onnx", roster, mix),
+            "(Bass)": oracle_model("kuielab_a_bass.onnx", roster, inst.astype(np.float32))}
+    for k in want:
+        assert stems[k].shape == (2, n)
+        err = float(np.max(np.abs(stems[k] - want[k])))
+        assert err < 1e-4, f"{k}: {err:.3e}"
