@@ -73,7 +73,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--batch", type=int, default=4, help="model windows per network launch")
+    ap.add_argument("--batch", type=int, default=8, help="model windows per network launch")
     ap.add_argument("--seconds", type=int, default=TRACK_SECONDS, help="audio seconds per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=1)
