@@ -25,6 +25,7 @@ struct alsep_plan {
     int n_fft = 0, hop = 0, dim_f = 0, dim_t = 0;
     int chunk = 0;
     float2* tw = nullptr;     // W_N^j = exp(-2*pi*i*j/N), j in [0,N)
+    float* win = nullptr;     // periodic Hann window, N floats
     float* env = nullptr;     // sum_t w^2 over the padded chunk timeline, N + hop*(T-1)
     int64_t env_len = 0;
 };
@@ -118,8 +119,13 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* __restrict__
         if (i < M) {
             const int k = i % P;
             if (P > 1) {
+                // one table read per butterfly; W^r by products (depth <= 3 complex multiplies)
+                float2 w[R];
+                w[1] = tw[k * TWS];
 #pragma unroll
-                for (int r = 1; r < R; ++r) u[b][r] = cmul(u[b][r], tw[k * r * TWS]);
+                for (int r = 2; r < R; ++r) w[r] = (r & 1) ? cmul(w[r - 1], w[1]) : cmul(w[r >> 1], w[r >> 1]);
+#pragma unroll
+                for (int r = 1; r < R; ++r) u[b][r] = cmul(u[b][r], w[r]);
             }
             dft<R>(u[b]);
             const int j = (i - k) * R + k;
@@ -150,14 +156,14 @@ template <int N, int NT> struct Fft;
         }                                                                                  \
     };
 ALSEP_FFT(256, 8, 8, 4)
-ALSEP_FFT(384, 8, 8, 2, 3)
-ALSEP_FFT(480, 8, 4, 5, 3)
+ALSEP_FFT(384, 3, 2, 8, 8)
+ALSEP_FFT(480, 5, 3, 8, 4)
 ALSEP_FFT(512, 8, 8, 8)
 ALSEP_FFT(1024, 8, 8, 8, 2)
 ALSEP_FFT(2048, 8, 8, 8, 4)
 ALSEP_FFT(4096, 8, 8, 8, 8)
-ALSEP_FFT(6144, 8, 8, 8, 4, 3)
-ALSEP_FFT(7680, 8, 8, 8, 5, 3)
+ALSEP_FFT(6144, 3, 4, 8, 8, 8)
+ALSEP_FFT(7680, 5, 8, 3, 8, 8)
 ALSEP_FFT(8192, 8, 8, 8, 8, 2)
 #undef ALSEP_FFT
 
@@ -190,7 +196,7 @@ template <> __device__ __forceinline__ void load_spec4<bf16_t>(const bf16_t* p, 
 template <int N, typename OutT, int LAYOUT>
 __global__ void __launch_bounds__(kFftThreads)
 stft_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_stride, int chunk, int hop,
-            int dim_f, int T, const float2* __restrict__ tw, OutT* __restrict__ spec) {
+            int dim_f, int T, const float2* __restrict__ tw, const float* __restrict__ win, OutT* __restrict__ spec) {
     constexpr int NT = kFftThreads;
     float2* buf = reinterpret_cast<float2*>(alsep_smem);
     const int tid = threadIdx.x;
@@ -203,7 +209,7 @@ stft_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_stri
         int p = p0 + n;
         if (p < 0) p = -p;                                   // reflect (center=True)
         if (p >= chunk) p = 2 * (chunk - 1) - p;
-        const float w = 0.5f - 0.5f * tw[n].x;               // periodic Hann = (1 - cos(2 pi n/N))/2
+        const float w = win[n];
         buf[n] = make_float2(xl[p] * w, xr[p] * w);
     }
     __syncthreads();
@@ -234,7 +240,7 @@ stft_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_stri
 template <int N, typename InT, int LAYOUT>
 __global__ void __launch_bounds__(kFftThreads)
 istft_kernel(const InT* __restrict__ spec, int hop, int dim_f, int T, const float2* __restrict__ tw,
-             const float* __restrict__ env, int j_lo, int j_hi, int run, float* __restrict__ out,
+             const float* __restrict__ win, const float* __restrict__ env, int j_lo, int j_hi, int run, float* __restrict__ out,
              int64_t out_ch_stride, int64_t out_chunk_stride, int64_t keep_lo, int64_t keep_hi,
              int64_t out_limit) {
     constexpr int NT = kFftThreads;
@@ -276,7 +282,7 @@ istft_kernel(const InT* __restrict__ spec, int hop, int dim_f, int T, const floa
             Fft<N, NT>::run(buf, tw, tid);
             const int base = (t % Q) * hop;                  // (t*hop) mod RN
             for (int n = tid; n < N; n += NT) {
-                const float w = (0.5f - 0.5f * tw[n].x) * inv_n;
+                const float w = win[n] * inv_n;
                 int r = base + n;
                 if (r >= RN) r -= RN;
                 float2 a = ring[r];
@@ -378,12 +384,14 @@ extern "C" int alsep_plan_create(alsep_ctx* ctx, int n_fft, int hop, int dim_f, 
     alsep_plan* p = new alsep_plan();
     p->ctx = ctx; p->n_fft = n_fft; p->hop = hop; p->dim_f = dim_f; p->dim_t = dim_t; p->chunk = (int)chunk;
     std::vector<float2> tw(n_fft);
+    std::vector<float> win(n_fft);
     std::vector<double> w2(n_fft);
     for (int j = 0; j < n_fft; ++j) {
         const double a = -2.0 * M_PI * (double)j / (double)n_fft;
         tw[j] = make_float2((float)cos(a), (float)sin(a));
         const double w = 0.5 - 0.5 * cos(2.0 * M_PI * (double)j / (double)n_fft);
-        w2[j] = w * w;
+        win[j] = (float)w;
+        w2[j] = (double)win[j] * (double)win[j];
     }
     p->env_len = (int64_t)n_fft + (int64_t)hop * (dim_t - 1);
     std::vector<double> envd(p->env_len, 0.0);
@@ -392,12 +400,14 @@ extern "C" int alsep_plan_create(alsep_ctx* ctx, int n_fft, int hop, int dim_f, 
     std::vector<float> env(p->env_len);
     for (int64_t i = 0; i < p->env_len; ++i) env[i] = (float)envd[i];
     if (hipMalloc((void**)&p->tw, sizeof(float2) * n_fft) != hipSuccess ||
+        hipMalloc((void**)&p->win, sizeof(float) * n_fft) != hipSuccess ||
         hipMalloc((void**)&p->env, sizeof(float) * p->env_len) != hipSuccess) {
         alsep_plan_destroy(p);
         return alsep_fail(ctx, ALSEP_ERR_NOMEM, "plan tables: hipMalloc failed");
     }
     // blocking copies on purpose: the host vectors die at return
     ALSEP_HIP(ctx, hipMemcpy(p->tw, tw.data(), sizeof(float2) * n_fft, hipMemcpyHostToDevice));
+    ALSEP_HIP(ctx, hipMemcpy(p->win, win.data(), sizeof(float) * n_fft, hipMemcpyHostToDevice));
     ALSEP_HIP(ctx, hipMemcpy(p->env, env.data(), sizeof(float) * p->env_len, hipMemcpyHostToDevice));
     *out = p;
     return ALSEP_OK;
@@ -406,6 +416,7 @@ extern "C" int alsep_plan_create(alsep_ctx* ctx, int n_fft, int hop, int dim_f, 
 extern "C" int alsep_plan_destroy(alsep_plan* plan) {
     if (!plan) return ALSEP_OK;
     if (plan->tw) (void)hipFree(plan->tw);
+    if (plan->win) (void)hipFree(plan->win);
     if (plan->env) (void)hipFree(plan->env);
     delete plan;
     return ALSEP_OK;
@@ -424,7 +435,7 @@ static int launch_stft(alsep_ctx* ctx, const alsep_plan* p, const float* pcm, in
         const int64_t spec_off = b0 * 4 * (int64_t)p->dim_f * p->dim_t;
         hipLaunchKernelGGL((stft_kernel<N, OutT, LAYOUT>), dim3(p->dim_t, (unsigned)nb), dim3(kFftThreads), lds,
                            ctx->stream, pcm + b0 * chunk_stride, ch_stride, chunk_stride, p->chunk, p->hop,
-                           p->dim_f, p->dim_t, (const float2*)p->tw, (OutT*)spec + spec_off);
+                           p->dim_f, p->dim_t, (const float2*)p->tw, (const float*)p->win, (OutT*)spec + spec_off);
     }
     ALSEP_LAUNCH_CHECK(ctx, "stft_kernel");
     return ALSEP_OK;
@@ -471,7 +482,7 @@ static int launch_istft(alsep_ctx* ctx, const alsep_plan* p, const void* spec, i
         const int64_t spec_off = b0 * 4 * (int64_t)p->dim_f * p->dim_t;
         hipLaunchKernelGGL((istft_kernel<N, InT, LAYOUT>), dim3(groups, (unsigned)nb), dim3(kFftThreads), lds,
                            ctx->stream, (const InT*)spec + spec_off, p->hop, p->dim_f, p->dim_t,
-                           (const float2*)p->tw, (const float*)p->env, j_lo, j_hi, kIstftRun,
+                           (const float2*)p->tw, (const float*)p->win, (const float*)p->env, j_lo, j_hi, kIstftRun,
                            out + b0 * out_chunk_stride, out_ch_stride, out_chunk_stride, keep_lo, keep_hi,
                            out_limit - b0 * out_chunk_stride);
     }

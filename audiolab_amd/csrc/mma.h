@@ -55,3 +55,17 @@ __device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
     const bf16x4 q = *reinterpret_cast<const bf16x4*>(p);
     v[0] = (float)q[0]; v[1] = (float)q[1]; v[2] = (float)q[2]; v[3] = (float)q[3];
 }
+
+// s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields left at their maxima); gfx9+ encoding:
+// vmcnt = simm16[3:0] | simm16[15:14] << 4, expcnt = [6:4], lgkmcnt = [11:8].
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+// workgroup barrier that does NOT drain outstanding LDS-DMA / global loads: LDS operations of this
+// wave are completed (lgkmcnt(0)), vmcnt is left to the caller's counted waits.
+__device__ __forceinline__ void barrier_nodrain() {
+    __builtin_amdgcn_s_waitcnt((63 & 15) | ((63 >> 4) << 14) | (7 << 4) | (0 << 8));
+    __builtin_amdgcn_s_barrier();
+}

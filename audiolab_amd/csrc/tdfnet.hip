@@ -17,6 +17,7 @@
 // Weights are always the operand with rows = output features; the epilogue therefore holds
 // 4 consecutive output channels per lane and stores them as one 8/16-byte vector.
 #include "mma.h"
+#include <alsep_gfx950_asm.h>
 
 #include <map>
 
@@ -27,50 +28,95 @@ constexpr int kThreads = 256;
 // ------------------------------------------------------------------------------------------
 // first 1x1 conv (4 -> g) + BN + ReLU, and final 1x1 conv (c -> 4) + bias: memory-bound VALU.
 // ------------------------------------------------------------------------------------------
+// 16-byte vectors of T
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { static constexpr int N = 4; };
+template <> struct Vec16<bf16_t> { static constexpr int N = 8; };
+__device__ __forceinline__ void store_vec(float* p, const float* y) { *reinterpret_cast<float4*>(p) = make_float4(y[0], y[1], y[2], y[3]); }
+__device__ __forceinline__ void store_vec(bf16_t* p, const float* y) {
+    bf16x8 q;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[e] = (bf16_t)y[e];
+    *reinterpret_cast<bf16x8*>(p) = q;
+}
+__device__ __forceinline__ void load_vec(const float* p, float* x) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+}
+__device__ __forceinline__ void load_vec(const bf16_t* p, float* x) {
+    const bf16x8 q = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (float)q[e];
+}
+
+// first 1x1 conv: a thread owns one 16-byte group of output channels for its whole life (its
+// 4 x VN weights, scales and shifts stay in registers) and walks pixels with a grid stride;
+// consecutive threads hold consecutive groups of one pixel, so a wave's stores are contiguous.
+constexpr int kFirstThreads = 192;                          // divisible by g/VN = 6 (bf16) and 12 (f32) at g = 48
 template <typename T>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kFirstThreads)
 first_conv_kernel(const T* __restrict__ X, T* __restrict__ Y, const float* __restrict__ W,
                   const float* __restrict__ scale, const float* __restrict__ shift, int64_t npix, int g,
                   float in_scale) {
-    const int q = g >> 2;                                     // groups of 4 output channels
-    const int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (idx >= npix * q) return;
-    const int64_t p = idx / q;
-    const int co = (int)(idx % q) * 4;
-    float x[4];
-    load4(X + p * 4, x);
-    float y[4];
+    constexpr int VN = Vec16<T>::N;
+    const int q = g / VN;                                    // groups per pixel
+    const int ppb = kFirstThreads / q;                       // pixels per block per pass (threads beyond ppb*q idle)
+    const int tg = threadIdx.x % q, tp = threadIdx.x / q;
+    if (tp >= ppb) return;
+    const int co = tg * VN;
+    float4 w[VN];
+    float sc[VN], sh[VN];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float* w = W + (co + r) * 4;
-        float a = w[0] * x[0];
-        a = fmaf(w[1], x[1], a);
-        a = fmaf(w[2], x[2], a);
-        a = fmaf(w[3], x[3], a);
-        y[r] = fmaxf(fmaf(a * in_scale, scale[co + r], shift[co + r]), 0.f);
+    for (int r = 0; r < VN; ++r) {
+        w[r] = *reinterpret_cast<const float4*>(W + (co + r) * 4);
+        sc[r] = scale[co + r] * in_scale;                    // scale * (in_scale * a) + shift
+        sh[r] = shift[co + r];
     }
-    store4(Y + p * g + co, y);
+    for (int64_t p = (int64_t)blockIdx.x * ppb + tp; p < npix; p += (int64_t)gridDim.x * ppb) {
+        float x[4];
+        load4(X + p * 4, x);
+        float y[VN];
+#pragma unroll
+        for (int r = 0; r < VN; ++r) {
+            float a = w[r].x * x[0];
+            a = fmaf(w[r].y, x[1], a);
+            a = fmaf(w[r].z, x[2], a);
+            a = fmaf(w[r].w, x[3], a);
+            y[r] = fmaxf(fmaf(a, sc[r], sh[r]), 0.f);
+        }
+        store_vec(Y + p * g + co, y);
+    }
 }
 
+// final 1x1 conv (c -> 4) + bias: a wave copies 64 pixels x c channels (contiguous) into LDS with
+// coalesced 16-byte loads, then every lane reduces its own pixel from LDS and writes 4 values.
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 final_conv_kernel(const T* __restrict__ X, T* __restrict__ Y, const float* __restrict__ W,
                   const float* __restrict__ bias, int64_t npix, int c, float alpha, float beta) {
-    const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (p >= npix) return;
-    float y[4] = {bias[0], bias[1], bias[2], bias[3]};
-    for (int ci = 0; ci < c; ci += 4) {
-        float x[4];
-        load4(X + p * c + ci, x);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float* w = W + r * c + ci;
-            y[r] = fmaf(w[0], x[0], y[r]);
-            y[r] = fmaf(w[1], x[1], y[r]);
-            y[r] = fmaf(w[2], x[2], y[r]);
-            y[r] = fmaf(w[3], x[3], y[r]);
-        }
+    constexpr int VN = Vec16<T>::N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gpp = c / VN;                                   // 16-byte groups per pixel
+    T* stg = reinterpret_cast<T*>(alsep_smem) + (size_t)wave * 64 * c;
+    const int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    for (int i = lane; i < 64 * gpp; i += 64) {
+        const int64_t pix = p0 + i / gpp;
+        vec16 v = zero16();
+        if (pix < npix) v = *reinterpret_cast<const vec16*>(X + p0 * c + (int64_t)i * VN);
+        *reinterpret_cast<vec16*>(stg + (size_t)i * VN) = v;
     }
+    __builtin_amdgcn_wave_barrier();                          // wave-private staging
+    const int64_t p = p0 + lane;
+    float y[4] = {bias[0], bias[1], bias[2], bias[3]};
+    for (int ci = 0; ci < c; ci += VN) {
+        float x[VN];
+        load_vec(stg + (size_t)lane * c + ci, x);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < VN; ++e) y[r] = fmaf(W[r * c + ci + e], x[e], y[r]);
+    }
+    if (p >= npix) return;
     if (beta != 0.f) {                                      // Y = alpha * net + beta * Y (denoise average)
         float o[4];
         load4(Y + p * 4, o);
@@ -220,7 +266,7 @@ __global__ void __launch_bounds__(kThreads, 2)
 conv3x3_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
                     const float* __restrict__ scale, const float* __restrict__ shift,
                     const bf16_t* __restrict__ zero_page, int Th, int Fw, int Cin, int Cout, int tiles_t,
-                    int tiles_f, int ntiles) {
+                    int tiles_f, int ntiles, int ablate) {
     typedef ConvB16<TW> Cf;
     bf16_t* patch = reinterpret_cast<bf16_t*>(alsep_smem);
     bf16_t* wts = patch + (size_t)Cf::PGROUPS * 8;
@@ -251,6 +297,7 @@ conv3x3_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const 
     const bf16_t* xb = X + b * (int64_t)Th * Fw * Cin;
     for (int q = 0; q < nq; ++q) {
         __syncthreads();                                     // previous chunk's fragment reads are done
+        if (!(ablate & 1))
         for (int i = wave; i * 64 < Cf::PGROUPS; i += 4) {
             const int gidx = i * 64 + lane;
             if (gidx < Cf::PGROUPS) {
@@ -263,8 +310,10 @@ conv3x3_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const 
             }
         }
         const bf16_t* wsrc = Wp + ((int64_t)ny * nq + q) * (Cf::WGROUPS * 8);
+        if (!(ablate & 1))
         for (int i = wave; i < Cf::WGROUPS / 64; i += 4) glds16(wsrc + ((size_t)i * 64 + lane) * 8, wts + (size_t)i * 64 * 8);
         __syncthreads();                                     // drains the LDS-DMA (vmcnt(0)) before the barrier
+        if (!(ablate & 2))
 #pragma unroll 2
         for (int s = 0; s < Cf::NS; ++s) {
             const int grp = 4 * s + lq;
@@ -283,6 +332,7 @@ conv3x3_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const 
         }
     }
     bf16_t* yb = Y + b * (int64_t)Th * Fw * Cout;
+    if (ablate & 4) return;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         const int pm = wave * 64 + ni * 16 + l15;
@@ -298,6 +348,172 @@ conv3x3_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const 
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 3x3 convolution, shallow levels (Cin = 48 or 96): persistent, weights in registers.
+// Measured on conv3x3_bf16_kernel (ALSEP_CONV_ABLATE): a workgroup's LDS fill, MFMA and store
+// phases do not overlap (the two co-resident workgroups run in lockstep), and the fill is the
+// longest phase because every 256-pixel tile re-stages its 43 KiB weight block.  Here
+//  * a workgroup owns one 48-channel output block (ny = blockIdx.y) for its whole life and keeps
+//    that block's weights for all NQ input chunks in VGPRs (NQ x 14 k-steps x 3 fragments), read
+//    once from the packed image -- LDS carries only halo patches;
+//  * it walks tiles blockIdx.x, +gridDim.x, ... with a 3-deep ring of patch chunks filled by
+//    LDS-DMA two stages ahead: counted s_waitcnt vmcnt + raw s_barrier keep the DMA in flight
+//    across barriers while the MFMAs of the current stage and the stores of the last tile run.
+// vmcnt bookkeeping (in-order counter; every wave issues exactly GL LDS-DMA per stage and ST
+// stores per tile, tiles are never partial): see wait_stage below.
+// ------------------------------------------------------------------------------------------
+template <int NQ>
+struct ConvRW {
+    static constexpr int TW = 64, TH = 4, KC = 48, BN = 48, CG = 6, NG = 54, NS = 14, WGRP = 56;
+    static constexpr int PW = TW + 2, PH = TH + 2;
+    static constexpr int PGROUPS = PH * PW * CG;            // 2376 real 16-byte groups per patch chunk
+    static constexpr int GL = 10;                           // LDS-DMA instructions per wave per stage (40 KiB stage)
+    static constexpr int STAGE_GROUPS = GL * 4 * 64;        // 2560
+    static constexpr int RING = 3;
+    static constexpr int ST = 12;                           // stores per wave per tile
+    static constexpr size_t ring_bytes = 16 * (size_t)STAGE_GROUPS * RING;  // 120 KiB
+    static constexpr size_t lds_bytes = ring_bytes + 2 * BN * sizeof(float);   // + scale/shift of this output block
+};
+
+template <int NQ>
+__global__ void __launch_bounds__(kThreads, 1)
+conv3x3_bf16_regw_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
+                         const float* __restrict__ scale, const float* __restrict__ shift,
+                         const bf16_t* __restrict__ zero_page, int Th, int Fw, int Cin, int Cout, int tiles_t,
+                         int tiles_f, int ntiles, int ablate) {
+    typedef ConvRW<NQ> Cf;
+    bf16_t* ring = reinterpret_cast<bf16_t*>(alsep_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int ny = blockIdx.y;
+
+    // weights of this output block, straight from the packed (swizzled) image into registers
+    bf16x8 wf[NQ][Cf::NS][3];
+    {
+        const int wswz = l15 >> 1;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const bf16_t* wsrc = Wp + ((int64_t)ny * NQ + q) * (Cf::BN * Cf::WGRP * 8);
+#pragma unroll
+            for (int s = 0; s < Cf::NS; ++s)
+#pragma unroll
+                for (int mi = 0; mi < 3; ++mi)
+                    wf[q][s][mi] = *reinterpret_cast<const bf16x8*>(wsrc + ((mi * 16 + l15) * Cf::WGRP + ((4 * s + lq) ^ wswz)) * 8);
+        }
+    }
+    float* ss = reinterpret_cast<float*>(alsep_smem + Cf::ring_bytes);      // [scale 48 | shift 48]
+    if (tid < Cf::BN) {
+        ss[tid] = scale[ny * Cf::BN + tid];
+        ss[Cf::BN + tid] = shift[ny * Cf::BN + tid];
+    }
+    int pbase[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) pbase[ni] = (wave * Cf::PW + ni * 16 + l15) * Cf::KC;   // wave w = tile row w
+    // patch offset of k-group (4s + lq): groups advance by 4 per step -> (tap, cg) by incremental update
+    auto koff_of = [&](int s) {
+        const int grp = 4 * s + lq;
+        const int gc = grp < Cf::NG ? grp : Cf::NG - 1;
+        const int tap = gc / Cf::CG, cg = gc % Cf::CG;
+        return ((tap / 3) * Cf::PW + (tap % 3)) * Cf::KC + cg * 8;
+    };
+    wait_vmcnt<0>();                                         // weights are in registers, scale/shift on their way to LDS
+    __syncthreads();
+
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nstage = my_tiles * NQ;
+
+    // LDS-DMA of stage st (tile st / NQ of this workgroup, input chunk st % NQ) into ring slot
+    auto issue = [&](int st, int slot) {
+        int tile = (int)blockIdx.x + (st / NQ) * (int)gridDim.x;
+        const int q = st % NQ;
+        const int tf = tile % tiles_f;  tile /= tiles_f;
+        const int tt = tile % tiles_t;
+        const int64_t b = tile / tiles_t;
+        const int t0 = tt * Cf::TH, f0 = tf * Cf::TW;
+        const bf16_t* xb = X + b * (int64_t)Th * Fw * Cin + q * Cf::KC;
+        bf16_t* dst = ring + (size_t)slot * Cf::STAGE_GROUPS * 8;
+        if (ablate & 1) return;                              // timing-only diagnostic
+#pragma unroll
+        for (int j = 0; j < Cf::GL; ++j) {
+            const int i = wave + 4 * j;
+            const int gidx = i * 64 + lane;
+            const int pix = gidx / Cf::CG, g = gidx % Cf::CG;
+            const int t = t0 - 1 + pix / Cf::PW, f = f0 - 1 + pix % Cf::PW;
+            const bool inb = gidx < Cf::PGROUPS && t >= 0 && t < Th && f >= 0 && f < Fw;
+            const bf16_t* src = inb ? xb + ((int64_t)t * Fw + f) * Cin + g * 8 : zero_page;
+            glds16(src, dst + (size_t)i * 64 * 8);
+        }
+    };
+
+    f32x4 acc[3][4];
+    // stage body; SLOT and the position of the stage in the pattern are compile-time constants
+#define ALSEP_RW_STAGE(st_, SLOT_, Q_)                                                             \
+    do {                                                                                           \
+        if ((st_) + 2 < nstage) issue((st_) + 2, ((SLOT_) + 2) % Cf::RING);                        \
+        /* ops issued after stage st_'s LDS-DMA: the DMA of st_+1 and st_+2 and the stores of   */ \
+        /* every tile finished in between (one per NQ stages); tail stages have fewer -> wait 0 */ \
+        if ((st_) + 2 < nstage) wait_vmcnt<2 * Cf::GL + ((Q_) == 0 ? (NQ == 1 ? 2 : 1) : 1) * Cf::ST>();   \
+        else wait_vmcnt<0>();                                                                      \
+        barrier_nodrain();                                                                         \
+        {                                                                                          \
+            const bf16_t* patch = ring + (size_t)(SLOT_) * Cf::STAGE_GROUPS * 8;                   \
+            if ((Q_) == 0) {                                                                       \
+                _Pragma("unroll") for (int mi = 0; mi < 3; ++mi)                                   \
+                    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+            }                                                                                      \
+            if (!(ablate & 2))                                                                     \
+            _Pragma("unroll") for (int s = 0; s < Cf::NS; ++s) {                                   \
+                bf16x8 xf[4];                                                                      \
+                const int ko = koff_of(s);                                                         \
+                _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) xf[ni] = lds_frag<bf16_t>(patch + pbase[ni] + ko); \
+                _Pragma("unroll") for (int mi = 0; mi < 3; ++mi)                                   \
+                    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) mma_step(acc[mi][ni], wf[Q_][s][mi], xf[ni]); \
+            }                                                                                      \
+        }                                                                                          \
+        barrier_nodrain();                        /* slot SLOT_ may be refilled (by stage st_+3) */ \
+        if ((Q_) == NQ - 1) store_tile((st_) / NQ);                                                \
+    } while (0)
+
+    auto store_tile = [&](int k) {
+        if (ablate & 4) return;                              // timing-only diagnostic
+        int tile = (int)blockIdx.x + k * (int)gridDim.x;
+        const int tf = tile % tiles_f;  tile /= tiles_f;
+        const int tt = tile % tiles_t;
+        const int64_t b = tile / tiles_t;
+        bf16_t* yb = Y + ((b * Th + tt * Cf::TH + wave) * (int64_t)Fw + tf * Cf::TW) * Cout + ny * Cf::BN;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 3; ++mi) {
+                const float4 scv = *reinterpret_cast<const float4*>(ss + mi * 16 + 4 * lq);
+                const float4 shv = *reinterpret_cast<const float4*>(ss + Cf::BN + mi * 16 + 4 * lq);
+                float y[4];
+                y[0] = fmaxf(fmaf(acc[mi][ni][0], scv.x, shv.x), 0.f);
+                y[1] = fmaxf(fmaf(acc[mi][ni][1], scv.y, shv.y), 0.f);
+                y[2] = fmaxf(fmaf(acc[mi][ni][2], scv.z, shv.z), 0.f);
+                y[3] = fmaxf(fmaf(acc[mi][ni][3], scv.w, shv.w), 0.f);
+                store4(yb + (int64_t)(ni * 16 + l15) * Cout + mi * 16 + 4 * lq, y);
+            }
+    };
+
+    if (nstage > 0) issue(0, 0);
+    if (nstage > 1) issue(1, 1);
+    // the ring slot advances by one per stage and the chunk index by one mod NQ: period lcm(3, NQ)
+    for (int st = 0; st < nstage; st += 3 * NQ) {
+        if (NQ == 1) {
+            ALSEP_RW_STAGE(st, 0, 0);
+            if (st + 1 < nstage) ALSEP_RW_STAGE(st + 1, 1, 0);
+            if (st + 2 < nstage) ALSEP_RW_STAGE(st + 2, 2, 0);
+        } else {
+            ALSEP_RW_STAGE(st, 0, 0);
+            ALSEP_RW_STAGE(st + 1, 1, 1);
+            if (st + 2 < nstage) { ALSEP_RW_STAGE(st + 2, 2, 0); ALSEP_RW_STAGE(st + 3, 0, 1); }
+            if (st + 4 < nstage) { ALSEP_RW_STAGE(st + 4, 1, 0); ALSEP_RW_STAGE(st + 5, 2, 1); }
+        }
+    }
+#undef ALSEP_RW_STAGE
 }
 
 // ------------------------------------------------------------------------------------------
@@ -515,11 +731,12 @@ struct TdfB16 {
     static constexpr int BM = 128, UN = 4, UC = 48, BK = 64;
     static constexpr int WGROUPS = BM * (BK / 8);              // 1024
     static constexpr int XGROUPS = BK * (UC / 8);              // 384 per unit
-    static constexpr size_t lds_bytes = 16 * (size_t)(WGROUPS + UN * XGROUPS);   // 40 KiB
+    static constexpr int STAGE_ELEMS = 8 * (WGROUPS + UN * XGROUPS);             // one stage: W tile + 4 unit tiles
+    static constexpr size_t lds_bytes = 2 * sizeof(bf16_t) * (size_t)STAGE_ELEMS;  // two stages: 80 KiB
 };
 
 template <bool RESIDUAL>
-__global__ void __launch_bounds__(kThreads, 3)
+__global__ void __launch_bounds__(kThreads, 2)
 tdf_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
                 const float* __restrict__ bias, const float* __restrict__ scale, const float* __restrict__ shift,
                 const bf16_t* __restrict__ R, const bf16_t* __restrict__ zero_page, int M, int K, int Kp,
@@ -536,6 +753,7 @@ tdf_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16
     const int64_t bt = uvalid ? u / upc : 0;
     const int cb = uvalid ? (int)(u % upc) * Tc::UC : 0;
     const bf16_t* xu = X + (bt * K) * (int64_t)C + cb;
+    const int klim = uvalid ? K : 0;
 
     f32x4 acc[3][8];
 #pragma unroll
@@ -548,62 +766,137 @@ tdf_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16
     const int trow = l15 >> 2, tcol = (l15 & 3) * 4;
     const int wswz = l15 >> 1;
 
-    for (int k0 = 0; k0 < Kp; k0 += Tc::BK) {
-        __syncthreads();
-        for (int i = wave; i < Tc::WGROUPS / 64; i += 4) {
+    // Two-stage LDS ring over the K tiles: the LDS-DMA of tile it+1 is issued before tile it is
+    // consumed and stays in flight across the barriers (counted vmcnt + raw s_barrier; a
+    // __syncthreads() here would drain vmcnt(0), cdna_hip_programming.md "Pipelining across barriers").
+    // Every wave issues exactly GLDS_PER_TILE LDS-DMA instructions per tile and nothing else that
+    // counts on vmcnt inside the loop.
+    constexpr int GLDS_PER_TILE = Tc::WGROUPS / 64 / 4 + Tc::XGROUPS / 64;      // 4 + 6
+    const int ntile = Kp / Tc::BK;
+    // the stage index is a compile-time constant in every access (loop unrolled by two): with a
+    // run-time stage offset hipcc cannot tell the stage being read from the one in flight and
+    // puts s_waitcnt vmcnt(0) in front of the first ds_read
+    auto issue = [&](int it, int stage) {
+        const int k0 = it * Tc::BK;
+        bf16_t* wdst = Ws + (size_t)stage * Tc::STAGE_ELEMS;
+        bf16_t* xdst = Xs + (size_t)stage * Tc::STAGE_ELEMS;
+#pragma unroll
+        for (int j = 0; j < Tc::WGROUPS / 64 / 4; ++j) {
+            const int i = wave + 4 * j;
             const int gidx = i * 64 + lane;
-            glds16(Wp + (int64_t)(row0 + (gidx >> 3)) * Kp + k0 + (gidx & 7) * 8, Ws + (size_t)i * 64 * 8);
+            glds16(Wp + (int64_t)(row0 + (gidx >> 3)) * Kp + k0 + (gidx & 7) * 8, wdst + (size_t)i * 64 * 8);
         }
 #pragma unroll
         for (int i = 0; i < Tc::XGROUPS / 64; ++i) {
             const int gidx = i * 64 + lane;
             const int kk = gidx / 6, g = gidx % 6;
-            const bf16_t* src = (uvalid && k0 + kk < K) ? xu + (int64_t)(k0 + kk) * C + g * 8 : zero_page;
-            glds16(src, Xs + (size_t)i * 64 * 8);
+            // one per-lane select, no wave-uniform branch: every wave issues every LDS-DMA (klim = 0 for a
+            // wave without a unit), which is what the counted waits below rely on
+            const bf16_t* src = (k0 + kk < klim) ? xu + (int64_t)(k0 + kk) * C + g * 8 : zero_page;
+            glds16(src, xdst + (size_t)i * 64 * 8);
         }
-        __syncthreads();
+    };
+    auto compute = [&](int stage) {
+        const bf16_t* Wc = Ws + (size_t)stage * Tc::STAGE_ELEMS;
+        const bf16_t* Xc = Xs + (size_t)stage * Tc::STAGE_ELEMS;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 xf[3], wf[8];
 #pragma unroll
             for (int ni = 0; ni < 3; ++ni) {
-                const bf16_t* p0 = Xs + (ks * 32 + 4 * lq + trow) * Tc::UC + ni * 16 + tcol;
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p0 + 16 * Tc::UC));
+                const bf16_t* p0 = Xc + (ks * 32 + 4 * lq + trow) * Tc::UC + ni * 16 + tcol;
+                const bf16x4 lo = lds_read_tr16_b64(p0);
+                const bf16x4 hi = lds_read_tr16_b64(p0 + 16 * Tc::UC);
                 xf[ni] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) wf[mi] = lds_frag<bf16_t>(Ws + ((mi * 16 + l15) * 8 + ((ks * 4 + lq) ^ wswz)) * 8);
+            for (int mi = 0; mi < 8; ++mi) wf[mi] = lds_frag<bf16_t>(Wc + ((mi * 16 + l15) * 8 + ((ks * 4 + lq) ^ wswz)) * 8);
+            lds_read_tr16_wait();
 #pragma unroll
             for (int ni = 0; ni < 3; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi) mma_step(acc[ni][mi], xf[ni], wf[mi]);
         }
+    };
+    // step(it, S): tile it sits in stage S; prefetch tile it+1 into stage 1-S, consume, release
+#define ALSEP_TDF_STEP(it_, S_)                                                                   \
+    do {                                                                                          \
+        if ((it_) + 1 < ntile) {                                                                  \
+            issue((it_) + 1, 1 - (S_));                                                           \
+            wait_vmcnt<GLDS_PER_TILE>();          /* this wave's tile it_ has landed */           \
+        } else {                                                                                  \
+            wait_vmcnt<0>();                                                                      \
+        }                                                                                         \
+        barrier_nodrain();                        /* ... and every other wave's */                \
+        compute(S_);                                                                              \
+        barrier_nodrain();                        /* stage S_ is free for tile it_+2 */           \
+    } while (0)
+    issue(0, 0);
+    for (int it = 0; it < ntile; it += 2) {
+        ALSEP_TDF_STEP(it, 0);
+        if (it + 1 < ntile) ALSEP_TDF_STEP(it + 1, 1);
     }
-    if (!uvalid) return;
+#undef ALSEP_TDF_STEP
+    // Epilogue through LDS: a lane's accumulator fragment is 4 channels of one f' row (8 bytes,
+    // 16 different rows per store instruction); re-laid out as [f'][48 c] in this wave's private
+    // 12 KiB of LDS it leaves as whole 96-byte rows -- 16-byte loads of the residual and 16-byte
+    // stores, contiguous across lanes (a full 6 KiB run when C = 48).  fp32 staging, two halves of
+    // 64 rows, so the residual add and the single bf16 rounding stay exactly as before.
+    // (all waves are past the last barrier of the k loop: the stage buffers are free; the region is
+    // private to the wave, so only its own LDS operations need ordering)
+    float* stg = reinterpret_cast<float*>(alsep_smem) + (size_t)wave * (64 * Tc::UC);
+    float bvv[8];
 #pragma unroll
-    for (int ni = 0; ni < 3; ++ni) {
-        const int c = cb + ni * 16 + 4 * lq;
-        float sc[4], sh[4];
+    for (int mi = 0; mi < 8; ++mi) {
+        const int fo = row0 + mi * 16 + l15;
+        bvv[mi] = (bias && fo < M) ? bias[fo] : 0.f;
+    }
+    float sc[3][4], sh[3][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { sc[r] = scale[c + r]; sh[r] = shift[c + r]; }
+    for (int ni = 0; ni < 3; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int fo = row0 + mi * 16 + l15;
-            if (fo >= M) continue;
-            const float bv = bias ? bias[fo] : 0.f;
-            const int64_t o = (bt * M + fo) * (int64_t)C + c;
-            float y[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[ni][mi][r] + bv, sc[r], sh[r]), 0.f);
-            if (RESIDUAL) {
-                float x[4];
-                load4(R + o, x);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] += x[r];
-            }
-            store4(Y + o, y);
+        for (int r = 0; r < 4; ++r) {
+            sc[ni][r] = uvalid ? scale[cb + ni * 16 + 4 * lq + r] : 0.f;
+            sh[ni][r] = uvalid ? shift[cb + ni * 16 + 4 * lq + r] : 0.f;
         }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+            for (int m4 = 0; m4 < 4; ++m4) {
+                const int mi = half * 4 + m4;
+                float4 v;
+                v.x = fmaxf(fmaf(acc[ni][mi][0] + bvv[mi], sc[ni][0], sh[ni][0]), 0.f);
+                v.y = fmaxf(fmaf(acc[ni][mi][1] + bvv[mi], sc[ni][1], sh[ni][1]), 0.f);
+                v.z = fmaxf(fmaf(acc[ni][mi][2] + bvv[mi], sc[ni][2], sh[ni][2]), 0.f);
+                v.w = fmaxf(fmaf(acc[ni][mi][3] + bvv[mi], sc[ni][3], sh[ni][3]), 0.f);
+                *reinterpret_cast<float4*>(stg + (m4 * 16 + l15) * Tc::UC + ni * 16 + 4 * lq) = v;
+            }
+        __builtin_amdgcn_wave_barrier();                    // wave-private region: program order suffices on hardware
+        // rows [half*64, half*64+64) x 6 groups of 8 channels = 384 16-byte output groups
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int gidx = it * 64 + lane;
+            const int fr = gidx / 6, cg = gidx % 6;
+            const int fo = row0 + half * 64 + fr;
+            const float4 lo = *reinterpret_cast<const float4*>(stg + fr * Tc::UC + cg * 8);
+            const float4 hi = *reinterpret_cast<const float4*>(stg + fr * Tc::UC + cg * 8 + 4);
+            if (uvalid && fo < M) {
+                const int64_t o = (bt * M + fo) * (int64_t)C + cb + cg * 8;
+                float y[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                if (RESIDUAL) {
+                    const bf16x8 xr = *reinterpret_cast<const bf16x8*>(R + o);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] += (float)xr[e];
+                }
+                bf16x8 q;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[e] = (bf16_t)y[e];
+                *reinterpret_cast<bf16x8*>(Y + o) = q;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -909,6 +1202,12 @@ int run_conv_tw(alsep_ctx* ctx, const ConvLayer& L, const T* X, T* Y, int64_t B,
     return launch_conv<T, KC, BN, 16>(ctx, L, X, Y, B, Th, Fw);
 }
 
+// timing-only diagnostic (ALSEP_CONV_ABLATE=1|2|4: skip LDS-DMA / MFMA loop / stores); results are wrong when set
+int conv_ablate() {
+    static const int v = [] { const char* e = getenv("ALSEP_CONV_ABLATE"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 template <int TW>
 int launch_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zero_page, int64_t B,
                     int Th, int Fw) {
@@ -921,12 +1220,41 @@ int launch_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     ProfScope prof(ctx, TW == 64 ? ALSEP_PROF_CONV3X3 : ALSEP_PROF_CONV3X3_SMALL);
     hipLaunchKernelGGL((conv3x3_bf16_kernel<TW>), dim3((unsigned)ntiles, L.cout / Cf::BN), dim3(kThreads), Cf::lds_bytes,
                        ctx->stream, X, Y, (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page,
-                       Th, Fw, L.cin, L.cout, tiles_t, tiles_f, (int)ntiles);
+                       Th, Fw, L.cin, L.cout, tiles_t, tiles_f, (int)ntiles, conv_ablate());
     ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_kernel");
     return ALSEP_OK;
 }
 
+template <int NQ>
+int launch_conv_regw(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zero_page, int64_t B,
+                     int Th, int Fw) {
+    typedef ConvRW<NQ> Cf;
+    const int tiles_t = Th / Cf::TH, tiles_f = Fw / Cf::TW;
+    const int64_t ntiles = B * tiles_t * tiles_f;
+    if (ntiles > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "conv3x3: too many tiles");
+    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_regw_kernel<NQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)Cf::lds_bytes));
+    const int ny = L.cout / Cf::BN;
+    int gx = 256 / ny;                                      // one workgroup per CU over the whole grid
+    if (gx > ntiles) gx = (int)ntiles;
+    ProfScope prof(ctx, ALSEP_PROF_CONV3X3);
+    hipLaunchKernelGGL((conv3x3_bf16_regw_kernel<NQ>), dim3((unsigned)gx, ny), dim3(kThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                       (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
+                       L.cout, tiles_t, tiles_f, (int)ntiles, conv_ablate());
+    ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_regw_kernel");
+    return ALSEP_OK;
+}
+
+int conv_regw_enabled() {
+    static const int v = [] { const char* e = getenv("ALSEP_CONV_REGW"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 int run_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zp, int64_t B, int Th, int Fw) {
+    if (conv_regw_enabled() && Th % 4 == 0 && Fw % 64 == 0 && L.cin == L.cout) {
+        if (L.cin == 48) return launch_conv_regw<1>(ctx, L, X, Y, zp, B, Th, Fw);
+        if (L.cin == 96 && conv_regw_enabled() >= 2) return launch_conv_regw<2>(ctx, L, X, Y, zp, B, Th, Fw);
+    }
     if (Fw >= 64 && Fw % 64 == 0) return launch_conv_dma<64>(ctx, L, X, Y, zp, B, Th, Fw);
     if (Fw >= 32) return launch_conv_dma<32>(ctx, L, X, Y, zp, B, Th, Fw);
     return launch_conv_dma<16>(ctx, L, X, Y, zp, B, Th, Fw);
@@ -1058,8 +1386,9 @@ int forward_impl(alsep_ctx* ctx, const alsep_net* net, const T* in, T* out, int6
     int rc;
     {
         ProfScope prof(ctx, ALSEP_PROF_POINTWISE);
-        const int64_t nthr = npix0 * (cfg.g / 4);
-        hipLaunchKernelGGL((first_conv_kernel<T>), dim3((unsigned)ceil_div64(nthr, kThreads)), dim3(kThreads), 0,
+        const int ppb = kFirstThreads / (cfg.g / Vec16<T>::N);
+        const int64_t nblk = std::min<int64_t>(ceil_div64(npix0, ppb), 256 * 16);
+        hipLaunchKernelGGL((first_conv_kernel<T>), dim3((unsigned)nblk), dim3(kFirstThreads), 0,
                            ctx->stream, in, P[0], (const float*)net->first_w.p, (const float*)net->first_scale.p,
                            (const float*)net->first_shift.p, npix0, cfg.g, in_scale);
         ALSEP_LAUNCH_CHECK(ctx, "first_conv_kernel");
@@ -1090,7 +1419,8 @@ int forward_impl(alsep_ctx* ctx, const alsep_net* net, const T* in, T* out, int6
         if ((rc = run_block<T>(ctx, net, net->dec[i], up, P[(ic + 2) % 3], up, H, dest, B, Th, Fw, c))) return rc;
     }
     ProfScope prof(ctx, ALSEP_PROF_POINTWISE);
-    hipLaunchKernelGGL((final_conv_kernel<T>), dim3((unsigned)ceil_div64(npix0, kThreads)), dim3(kThreads), 0, ctx->stream,
+    hipLaunchKernelGGL((final_conv_kernel<T>), dim3((unsigned)ceil_div64(npix0, kThreads)), dim3(kThreads),
+                       (size_t)kThreads * cfg.g * sizeof(T), ctx->stream,
                        (const T*)P[ic], out, (const float*)net->final_w.p, (const float*)net->final_b.p, npix0, cfg.g, out_alpha, out_beta);
     ALSEP_LAUNCH_CHECK(ctx, "final_conv_kernel");
     return ALSEP_OK;

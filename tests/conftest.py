@@ -34,6 +34,7 @@ def _emul_stale() -> bool:
     built = os.path.getmtime(EMUL_SO)
     srcs = [os.path.join(ROOT, "audiolab_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "audiolab_amd", "csrc"))]
     srcs += [os.path.join(EMUL_DIR, "emul_runtime.cpp"), os.path.join(EMUL_DIR, "hip", "hip_runtime.h"),
+             os.path.join(EMUL_DIR, "alsep_gfx950_asm.h"),
              os.path.join(ROOT, "include", "alsep.h")]
     return any(os.path.getmtime(s) > built for s in srcs)
 

@@ -149,6 +149,13 @@ static inline emul_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, 
     return c;
 }
 
+// The emulation executes memory operations synchronously: counted waits are no-ops, the raw
+// barrier is the workgroup barrier.
+static inline void __builtin_amdgcn_s_waitcnt(int) {}
+static inline void __builtin_amdgcn_s_barrier() { emul::sync_block(); }
+// lanes are separate fibers here: a wave-level ordering point must actually rendezvous
+static inline void __builtin_amdgcn_wave_barrier() { emul::wave_sync(); }
+
 // LDS-DMA: lane l copies `size` bytes from its own global address to (wave-uniform LDS base) + size*l + off.
 template <typename GP, typename LP>
 static inline void __builtin_amdgcn_global_load_lds(GP g, LP l, unsigned size, unsigned off, unsigned) {

@@ -1,0 +1,45 @@
+"""GPU (-m gpu): the persistent register-weight 3x3 conv (counted vmcnt, LDS-DMA ring) must be
+bit-identical to the plain LDS-DMA kernel (same MFMA order), on several batches -- a race in the
+asynchronous ring would show up as a mismatch."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+from audiolab_amd import _lib
+from audiolab_amd.synth import synthetic_state_dict
+from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
+ctx = _lib.Context("cuda:0")
+cfg = TDFNetConfig(dim_f=512, dim_t=64, n_fft=1024, hop=256, num_blocks=5, g=48)
+sd = synthetic_state_dict(cfg, seed=1, calib_frames=32)
+net = TDFNet(cfg, sd, ctx=ctx, dtype=torch.bfloat16, max_batch=6)
+outs = []
+for rep in range(4):
+    g = torch.Generator().manual_seed(100 + rep)
+    x = (torch.randn((11, cfg.dim_t, cfg.dim_f, 4), generator=g) * 4).to(torch.bfloat16).cuda()
+    outs.append(net.forward_nhwc(x).float().cpu().numpy())
+np.save(sys.argv[1], np.stack(outs))
+"""
+
+
+def run_mode(mode, path):
+    env = dict(os.environ, ALSEP_CONV_REGW=str(mode))
+    r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}, path], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(path)
+
+
+def test_persistent_conv_bit_identical(tmp_path):
+    base = run_mode(0, str(tmp_path / "m0.npy"))
+    assert np.isfinite(base).all() and np.abs(base).max() > 1e-3
+    for mode in (1, 2):
+        got = run_mode(mode, str(tmp_path / f"m{mode}.npy"))
+        assert np.array_equal(base, got), f"ALSEP_CONV_REGW={mode}: max diff {np.abs(base - got).max()}"
