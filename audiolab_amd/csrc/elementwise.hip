@@ -116,6 +116,55 @@ shift_subtract_kernel(const float* __restrict__ ref, const float* __restrict__ s
     }
 }
 
+// Hann-window overlap-add of model chunks (the chunker of audio-separator's MDXSeparator.demix; see
+// oracle/mdx_oracle.py demix_ola -- parity unpinned).  Gather form, no atomics: output sample p sums
+// the chunks that cover it, each weighted by np.hanning(n_act_b)[p - start_b] (n_act_b = chunk, or less
+// for chunks cut by the end of the padded mixture), and is divided by the sum of the weights.
+__global__ void __launch_bounds__(kThreads)
+ola_combine_kernel(const float* __restrict__ chunks, int64_t n_chunks, int64_t chunk, int64_t step, int64_t total,
+                   int use_window, float gain, float* __restrict__ out, int64_t out_stride, int64_t p_lo, int64_t n_out) {
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_out; i += stride) {
+        const int64_t p = p_lo + i;
+        int64_t b_hi = p / step;
+        if (b_hi > n_chunks - 1) b_hi = n_chunks - 1;
+        int64_t b_lo = (p - chunk + step) / step;           // ceil((p - chunk + 1) / step)
+        if (p - chunk + 1 <= 0) b_lo = 0;
+        float accl = 0.f, accr = 0.f, div = 0.f;
+        for (int64_t b = b_lo; b <= b_hi; ++b) {
+            const int64_t start = b * step, j = p - start;
+            int64_t n_act = total - start;
+            if (n_act > chunk) n_act = chunk;
+            if (j < 0 || j >= n_act) continue;
+            float w = 1.f;
+            if (use_window) w = n_act > 1 ? 0.5f - 0.5f * cosf(6.28318530717958647692f * (float)j / (float)(n_act - 1)) : 1.f;
+            accl += w * chunks[(b * 2 + 0) * chunk + j];
+            accr += w * chunks[(b * 2 + 1) * chunk + j];
+            div += w;
+        }
+        out[i] = gain * (accl / div);                       // div == 0 only where np.hanning is 0 on every cover: NaN as the reference
+        out[out_stride + i] = gain * (accr / div);
+    }
+}
+
+// zero the lowest `nbins` frequency bins of a spectrogram (MDXSeparator.run_model: spek[:, :, :3, :] *= 0)
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+zero_low_bins_kernel(T* __restrict__ spec, int layout, int64_t B, int dim_f, int Tn, int nbins) {
+    const int64_t n = B * 4 * (int64_t)nbins * Tn;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        int64_t r = i;
+        const int c = (int)(r % 4); r /= 4;
+        const int f = (int)(r % nbins); r /= nbins;
+        const int t = (int)(r % Tn);
+        const int64_t b = r / Tn;
+        const int64_t o = layout == ALSEP_LAYOUT_NHWC ? ((b * Tn + t) * (int64_t)dim_f + f) * 4 + c
+                                                      : ((b * 4 + c) * (int64_t)dim_f + f) * Tn + t;
+        spec[o] = (T)0.f;
+    }
+}
+
 unsigned grid_for(int64_t n, int per_thread = 1) {
     int64_t b = ceil_div64(n, (int64_t)kThreads * per_thread);
     if (b < 1) b = 1;
@@ -216,5 +265,32 @@ extern "C" int alsep_shift_subtract(alsep_ctx* ctx, const float* ref, const floa
     if (len == 0) return ALSEP_OK;
     hipLaunchKernelGGL(shift_subtract_kernel, dim3(grid_for(len, 4)), dim3(kThreads), 0, ctx->stream, ref, sig, len, lag, alpha, out);
     ALSEP_LAUNCH_CHECK(ctx, "shift_subtract_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_ola_combine(alsep_ctx* ctx, const float* chunks, int64_t n_chunks, int64_t chunk, int64_t step,
+                                 int64_t total, int use_window, float gain, float* out, int64_t out_stride, int64_t p_lo,
+                                 int64_t n_out) {
+    if (!ctx || !chunks || !out || n_chunks <= 0 || chunk <= 0 || step <= 0 || step > chunk || total <= 0 || p_lo < 0 ||
+        n_out < 0 || p_lo + n_out > total || (n_chunks - 1) * step >= total)
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_ola_combine: bad argument");
+    if (n_out == 0) return ALSEP_OK;
+    hipLaunchKernelGGL(ola_combine_kernel, dim3(grid_for(n_out, 2)), dim3(kThreads), 0, ctx->stream, chunks, n_chunks, chunk,
+                       step, total, use_window, gain, out, out_stride, p_lo, n_out);
+    ALSEP_LAUNCH_CHECK(ctx, "ola_combine_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_zero_low_bins(alsep_ctx* ctx, void* spec, int dtype, int layout, int64_t B, int64_t dim_f, int64_t T,
+                                   int nbins) {
+    if (!ctx || !spec || B < 0 || nbins < 0 || nbins > dim_f || (dtype != ALSEP_F32 && dtype != ALSEP_BF16))
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_zero_low_bins: bad argument");
+    if (B == 0 || nbins == 0) return ALSEP_OK;
+    const int64_t n = B * 4 * nbins * T;
+    if (dtype == ALSEP_F32)
+        hipLaunchKernelGGL((zero_low_bins_kernel<float>), dim3(grid_for(n)), dim3(kThreads), 0, ctx->stream, (float*)spec, layout, B, (int)dim_f, (int)T, nbins);
+    else
+        hipLaunchKernelGGL((zero_low_bins_kernel<bf16_t>), dim3(grid_for(n)), dim3(kThreads), 0, ctx->stream, (bf16_t*)spec, layout, B, (int)dim_f, (int)T, nbins);
+    ALSEP_LAUNCH_CHECK(ctx, "zero_low_bins_kernel");
     return ALSEP_OK;
 }

@@ -9,8 +9,10 @@ is reachable offline, so every roster entry below is a TFC-TDF U-Net with random
 (audiolab_amd.synth) unless ``<model_file_dir>/<name>.pt`` holds a torch state_dict for it.
 Geometry per file name follows the public UVR/KUIELab model tables (PARITY UNPINNED).
 
-MDX runner.  Margin chunker + trim stitching exactly as the in-tree runner (mdxnet.py:109-197,
-pinned); the secondary stem is ``mix - primary`` in the time domain (mdxnet.py:211).
+MDX runner.  ``chunker="margin"`` (default): margin chunker + trim stitching exactly as the in-tree
+runner (mdxnet.py:109-197, pinned).  ``chunker="ola"``: Hann-window overlap-add with ``overlap`` and
+``compensate`` as the third-party MDXSeparator does (unpinned).  The secondary stem is
+``mix - primary`` in the time domain (mdxnet.py:211).
 """
 from __future__ import annotations
 
@@ -65,7 +67,7 @@ class Separator:
                  invert_using_spec: bool = True, use_autocast: bool = True, ctx: Optional[Context] = None,
                  dtype: Optional[torch.dtype] = None, sample_rate: int = 44100, chunks: int = 0, margin: int = 44100,
                  denoise: bool = False, max_batch: int = 8, sharded: bool = False, roster: Optional[Dict[str, tuple]] = None,
-                 **_ignored):
+                 chunker: str = "margin", overlap: float = 0.25, compensate: float = 1.0, **_ignored):
         self.log_level = log_level
         self.model_file_dir = model_file_dir
         self.output_dir = output_dir
@@ -79,6 +81,9 @@ class Separator:
         self.max_batch = max_batch
         self.sharded = sharded
         self.roster = dict(MODEL_ROSTER if roster is None else roster)
+        if chunker not in ("margin", "ola"):
+            raise AlsepError("chunker must be 'margin' (in-tree runner, pinned) or 'ola' (audio-separator style, unpinned)")
+        self.chunker, self.overlap, self.compensate = chunker, overlap, compensate
         self.model_instance: Optional[_ModelInstance] = None
         self._cache: Dict[str, _ModelInstance] = {}
 
@@ -108,7 +113,12 @@ class Separator:
         dim_t_arg = int(cfg.dim_t).bit_length() - 1
         args = types.SimpleNamespace(margin=self.margin, chunks=self.chunks, denoise=self.denoise, dim_f=cfg.dim_f,
                                      dim_t=dim_t_arg, n_fft=cfg.n_fft)
-        pred = Predictor(args, net, ctx=self.ctx, hop=cfg.hop, sharded=self.sharded)
+        if self.chunker == "ola":
+            from .mdx import OlaRunner
+            pred = OlaRunner(net, ctx=self.ctx, overlap=self.overlap, compensate=self.compensate, denoise=self.denoise,
+                             max_batch=self.max_batch)
+        else:
+            pred = Predictor(args, net, ctx=self.ctx, hop=cfg.hop, sharded=self.sharded)
         inst = _ModelInstance(model_filename, net, pred, primary, secondary)
         inst.output_dir = self.output_dir
         self._cache[model_filename] = inst
@@ -128,7 +138,9 @@ class Separator:
             raise AlsepError("MDX-Net models are stereo; split other layouts into stereo pairs")
         m = m.to(self.ctx.device).contiguous()
         inst = self.model_instance
-        primary = inst.predictor.demix(m)[0]
+        primary = inst.predictor.demix(m)
+        if primary.dim() == 3:                                  # Predictor returns [1,2,N] like the reference
+            primary = primary[0]
         out = {inst.primary_stem_name: primary}
         if inst.secondary_stem_name:
             sec = m.clone()                                     # secondary = mix - primary (mdxnet.py:211)

@@ -259,3 +259,50 @@ class Predictor:
                 pred = torch.as_tensor(pred, device=self.ctx.device).contiguous()
                 plan.istft_strided(pred, _lib.LAYOUT_REF, seg_out, ld, gen, trim, plan.chunk_size - trim,
                                    limit, out_offset=w0 * gen - s_lo)
+
+
+class OlaRunner:
+    """Hann-window overlap-add runner: the chunker ``Separator.separate`` executes today for MDX models
+    (third-party ``MDXSeparator.demix`` / ``run_model``, reached at stem_separator.py:281; PARITY UNPINNED --
+    restated in oracle/mdx_oracle.py ``demix_ola``).  Windows start every ``(1-overlap)*chunk`` samples of
+    the padded mixture, the lowest ``zero_low_bins`` bins are zeroed before the network, outputs are
+    weighted by np.hanning, summed, divided by the summed weights, and scaled by ``compensate``."""
+
+    def __init__(self, net, ctx: Optional[Context] = None, overlap: float = 0.25, zero_low_bins: int = 3,
+                 compensate: float = 1.0, denoise: bool = False, max_batch: int = 8):
+        self.net = net
+        self.ctx = ctx if ctx is not None else net.ctx
+        cfg = net.cfg
+        self.plan = StftPlan(self.ctx, cfg.n_fft, cfg.hop, cfg.dim_f, cfg.dim_t)
+        self.overlap, self.zero_low_bins, self.compensate, self.denoise = overlap, zero_low_bins, compensate, denoise
+        self.max_batch = max_batch
+
+    def demix(self, mix: torch.Tensor) -> torch.Tensor:
+        """mix [2,N] float32 on the device -> [2,N]."""
+        plan, ctx = self.plan, self.ctx
+        mix = mix.contiguous().float()
+        n = mix.shape[-1]
+        chunk, trim, gen = plan.chunk_size, plan.trim, plan.gen_size
+        pad = gen + trim - (n % gen)
+        total = trim + n + pad
+        step = int((1 - self.overlap) * chunk)
+        n_chunks = (total + step - 1) // step
+        buf_len = (n_chunks - 1) * step + chunk              # chunks cut by the end see zeros
+        mixture = ctx.zeros((2, buf_len), torch.float32)
+        mixture[:, trim:trim + n] = mix
+        waves = ctx.empty((n_chunks, 2, chunk), torch.float32)
+        bstep = self.max_batch if self.max_batch > 0 else n_chunks
+        for b0 in range(0, n_chunks, bstep):
+            nb = min(bstep, n_chunks - b0)
+            spek = plan.stft_strided(mixture, buf_len, step, nb, self.net.dtype, _lib.LAYOUT_NHWC, pcm_offset=b0 * step)
+            if self.zero_low_bins:
+                ctx.check(ctx.lib.alsep_zero_low_bins(ctx.handle, _lib.ptr(spek), _lib.dtype_code(spek.dtype), _lib.LAYOUT_NHWC,
+                                                      nb, plan.dim_f, plan.dim_t, self.zero_low_bins), "alsep_zero_low_bins")
+            pred = self.net.forward_nhwc(spek, denoise=self.denoise)
+            plan.istft_strided(pred, _lib.LAYOUT_NHWC, waves, chunk, 2 * chunk, 0, chunk, (nb - 1) * 2 * chunk + chunk,
+                               out_offset=b0 * 2 * chunk)
+        out = ctx.empty((2, n), torch.float32)
+        ctx.check(ctx.lib.alsep_ola_combine(ctx.handle, _lib.ptr(waves), n_chunks, chunk, step, total,
+                                            1 if self.overlap != 0 else 0, float(self.compensate), _lib.ptr(out), n, trim, n),
+                  "alsep_ola_combine")
+        return out

@@ -92,6 +92,18 @@ int alsep_istft(alsep_ctx* ctx, const alsep_plan* plan, const void* spec, int dt
                 int64_t n_chunks, float* out, int64_t out_ch_stride, int64_t out_chunk_stride,
                 int64_t keep_lo, int64_t keep_hi, int64_t out_limit);
 
+/* Hann-window overlap-add chunker of the third-party MDXSeparator.demix (what Separator.separate runs
+ * today, stem_separator.py:281; package audio-separator>=0.32.0, setup.sh:96 -- PARITY UNPINNED):
+ * chunks [n_chunks,2,chunk] are the model outputs of windows starting every `step` samples of the padded
+ * mixture of length `total`; out[c*out_stride + i] = gain * sum_b w_b y_b / sum_b w_b at mixture position
+ * p_lo + i, w_b = np.hanning(min(chunk, total - b*step)) (or 1 when use_window == 0). */
+int alsep_ola_combine(alsep_ctx* ctx, const float* chunks, int64_t n_chunks, int64_t chunk, int64_t step,
+                      int64_t total, int use_window, float gain, float* out, int64_t out_stride, int64_t p_lo,
+                      int64_t n_out);
+/* zero the lowest nbins bins of a spectrogram in place (MDXSeparator.run_model zeroes bins 0..2). */
+int alsep_zero_low_bins(alsep_ctx* ctx, void* spec, int dtype, int layout, int64_t B, int64_t dim_f, int64_t T,
+                        int nbins);
+
 /* Spectrogram layout conversion REF <-> NHWC (same dtype). */
 int alsep_spec_convert(alsep_ctx* ctx, const void* src, void* dst, int dtype, int src_layout,
                        int64_t B, int64_t dim_f, int64_t T);

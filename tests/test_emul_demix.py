@@ -35,3 +35,26 @@ def test_demix_small_vs_reference(emul, golden_dir, tag):
     ref = z[f"small_{tag}_out"]
     assert out.shape == ref.shape
     assert np.max(np.abs(out - ref)) < 1e-5
+
+
+def test_ola_runner_vs_oracle(emul):
+    """Hann overlap-add chunker (unpinned upstream algorithm) against oracle/mdx_oracle.demix_ola, with a
+    small random-init TFC-TDF network on both sides."""
+    from audiolab_amd.mdx import OlaRunner
+    from audiolab_amd.synth import synthetic_state_dict
+    from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
+    from oracle import mdx_oracle as mo
+    from oracle import tdfnet_oracle
+    cfg = TDFNetConfig(dim_f=64, dim_t=32, n_fft=256, hop=64, num_blocks=3, g=16)
+    sd = synthetic_state_dict(cfg, seed=5)
+    net = TDFNet(cfg, sd, ctx=emul, max_batch=3)
+    g = mo.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
+
+    def run(spek):
+        return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)), cfg.num_blocks, cfg.l, cfg.bn).numpy()
+    for n, overlap, denoise in ((9000, 0.25, False), (5000, 0.75, True)):
+        mix = synth_mix(n, seed=40 + n)
+        want = mo.demix_ola(mix, g, run, overlap=overlap, denoise=denoise, zero_low_bins=3, compensate=1.035)
+        got = OlaRunner(net, overlap=overlap, denoise=denoise, compensate=1.035, max_batch=4).demix(torch.from_numpy(mix)).numpy()
+        assert got.shape == want.shape == (2, n)
+        assert np.max(np.abs(got - want)) < 1e-4
