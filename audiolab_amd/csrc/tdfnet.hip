@@ -487,13 +487,13 @@ conv3x3_bf16_regw_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, c
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 3; ++mi) {
-                const float4 scv = *reinterpret_cast<const float4*>(ss + mi * 16 + 4 * lq);
-                const float4 shv = *reinterpret_cast<const float4*>(ss + Cf::BN + mi * 16 + 4 * lq);
+                // ext-vector loads on purpose: a HIP float4 (struct) load from LDS makes hipcc put
+                // s_waitcnt vmcnt(0) in front of it while an LDS-DMA is in flight, draining the ring
+                const f32x4 scv = *reinterpret_cast<const f32x4*>(ss + mi * 16 + 4 * lq);
+                const f32x4 shv = *reinterpret_cast<const f32x4*>(ss + Cf::BN + mi * 16 + 4 * lq);
                 float y[4];
-                y[0] = fmaxf(fmaf(acc[mi][ni][0], scv.x, shv.x), 0.f);
-                y[1] = fmaxf(fmaf(acc[mi][ni][1], scv.y, shv.y), 0.f);
-                y[2] = fmaxf(fmaf(acc[mi][ni][2], scv.z, shv.z), 0.f);
-                y[3] = fmaxf(fmaf(acc[mi][ni][3], scv.w, shv.w), 0.f);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[mi][ni][r], scv[r], shv[r]), 0.f);
                 store4(yb + (int64_t)(ni * 16 + l15) * Cout + mi * 16 + 4 * lq, y);
             }
     };
@@ -514,6 +514,194 @@ conv3x3_bf16_regw_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, c
         }
     }
 #undef ALSEP_RW_STAGE
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 3x3 convolution, deeper levels (Cout = 48*NY, NY = 2..6): persistent + software-pipelined.
+// One workgroup per CU walks tiles; for each tile and input chunk q the halo patch is staged ONCE
+// and all NY 48-channel weight blocks are streamed against it (accumulators for all NY blocks live
+// in registers), instead of re-staging the patch per output block.  Patch and weight blocks each
+// have a 2-slot LDS ring (2*38,016 + 2*43,008 B = 158.3 KiB); the LDS-DMA of the next weight block
+// -- and, on the first block of a patch, of the next patch -- is in flight while the MFMAs of the
+// current one run (counted s_waitcnt vmcnt + raw s_barrier), and a tile's stores drain under the next
+// tile's first stage.
+// Stage s of a workgroup: ny = s % NY, q = (s / NY) % nq, tile = s / (NY*nq).
+// ------------------------------------------------------------------------------------------
+template <int NY>
+struct ConvPipe {
+    static constexpr int TW = 64, TH = 4, KC = 48, BN = 48, CG = 6, NG = 54, NS = 14, WGRP = 56;
+    static constexpr int PW = TW + 2, PH = TH + 2;
+    static constexpr int PGROUPS = PH * PW * CG;            // 2376
+    static constexpr int WGROUPS = BN * WGRP;               // 2688
+    static constexpr int PINST = (PGROUPS + 63) / 64;       // 38 LDS-DMA instructions per patch (last one partial)
+    static constexpr int WINST = WGROUPS / 64;              // 42 per weight block
+    static constexpr int ST = NY * 12;                      // stores per wave per tile
+    static constexpr size_t ring_bytes = 16 * (size_t)(2 * PGROUPS + 2 * WGROUPS);     // 162,048
+    static constexpr size_t lds_bytes = ring_bytes + 2 * NY * BN * sizeof(float);      // + scale/shift (NY <= 4 fits 160 KiB)
+    static_assert(lds_bytes <= 160 * 1024, "ConvPipe: LDS budget");
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt_capped() { wait_vmcnt<(N > 63 ? 63 : N)>(); }
+
+template <int NY>
+__global__ void __launch_bounds__(kThreads, 1)
+conv3x3_bf16_pipe_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
+                         const float* __restrict__ scale, const float* __restrict__ shift,
+                         const bf16_t* __restrict__ zero_page, int Th, int Fw, int Cin, int Cout, int tiles_t,
+                         int tiles_f, int ntiles) {
+    typedef ConvPipe<NY> Cf;
+    bf16_t* pring = reinterpret_cast<bf16_t*>(alsep_smem);
+    bf16_t* wring = pring + (size_t)2 * Cf::PGROUPS * 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int nq = Cin / Cf::KC;
+    const int wswz = l15 >> 1;
+
+    int pbase[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) pbase[ni] = (wave * Cf::PW + ni * 16 + l15) * Cf::KC;
+    auto koff_of = [&](int s) {
+        const int grp = 4 * s + lq;
+        const int gc = grp < Cf::NG ? grp : Cf::NG - 1;
+        const int tap = gc / Cf::CG, cg = gc % Cf::CG;
+        return ((tap / 3) * Cf::PW + (tap % 3)) * Cf::KC + cg * 8;
+    };
+
+    // scale/shift of all output channels sit in LDS: an ordinary global load inside the stage loop
+    // would make hipcc drain vmcnt(0) (and with it the ring) at its first use
+    float* ss = reinterpret_cast<float*>(alsep_smem + Cf::ring_bytes);
+    for (int i = tid; i < NY * Cf::BN; i += kThreads) {
+        ss[i] = scale[i];
+        ss[NY * Cf::BN + i] = shift[i];
+    }
+    __syncthreads();
+
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int spt = NY * nq;                                 // stages per tile
+    const int nstage = my_tiles * spt;
+    const int npatch = my_tiles * nq;
+
+    auto tile_coords = [&](int k, int& t0, int& f0, int64_t& b) {
+        int tile = (int)blockIdx.x + k * (int)gridDim.x;
+        const int tf = tile % tiles_f;  tile /= tiles_f;
+        const int tt = tile % tiles_t;
+        b = tile / tiles_t;
+        t0 = tt * Cf::TH;
+        f0 = tf * Cf::TW;
+    };
+    // patch-stage ps = (tile k = ps / nq, chunk q = ps % nq) -> slot ps & 1.  Waves 0,1 issue 10, waves 2,3 issue 9.
+    auto issue_patch = [&](int ps) {
+        int t0, f0; int64_t b;
+        tile_coords(ps / nq, t0, f0, b);
+        const bf16_t* xb = X + b * (int64_t)Th * Fw * Cin + (ps % nq) * Cf::KC;
+        bf16_t* dst = pring + (size_t)(ps & 1) * Cf::PGROUPS * 8;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const int i = wave + 4 * j;
+            if (i < Cf::PINST) {                             // wave-uniform: i = 38, 39 do not exist
+                const int gidx = i * 64 + lane;
+                if (gidx < Cf::PGROUPS) {
+                    const int pix = gidx / Cf::CG, g = gidx % Cf::CG;
+                    const int t = t0 - 1 + pix / Cf::PW, f = f0 - 1 + pix % Cf::PW;
+                    const bool inb = t >= 0 && t < Th && f >= 0 && f < Fw;
+                    const bf16_t* src = inb ? xb + ((int64_t)t * Fw + f) * Cin + g * 8 : zero_page;
+                    glds16(src, dst + (size_t)i * 64 * 8);
+                }
+            }
+        }
+    };
+    // weight block of stage s -> slot s & 1.  Waves 0,1 issue 11, waves 2,3 issue 10.
+    auto issue_weights = [&](int s) {
+        const int ny = s % NY, q = (s / NY) % nq;
+        const bf16_t* wsrc = Wp + ((int64_t)ny * nq + q) * (Cf::WGROUPS * 8);
+        bf16_t* dst = wring + (size_t)(s & 1) * Cf::WGROUPS * 8;
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+            const int i = wave + 4 * j;
+            if (i < Cf::WINST) glds16(wsrc + ((size_t)i * 64 + lane) * 8, dst + (size_t)i * 64 * 8);
+        }
+    };
+
+    f32x4 acc[NY][3][4];
+
+    // What is younger than stage s's weight block when we wait for it (in issue order):
+    //   [patch ps+1, issued at stage s-1 when ny(s-1) == 0]  [stores of the tile that ended at s-1]
+    //   [weights s+1]  [patch ps+1, issued now when ny(s) == 0]
+    // HI = waves 0,1 (11 weight / 10 patch instructions), else 10 / 9.
+#define ALSEP_PIPE_WAIT(HI_)                                                                        \
+    do {                                                                                            \
+        constexpr int GW = (HI_) ? 11 : 10, GP = (HI_) ? 10 : 9;                                    \
+        if (last) wait_vmcnt<0>();                                                                  \
+        else if (ny == 0 && newtile && havep) wait_vmcnt_capped<Cf::ST + GW + GP>();                \
+        else if (ny == 0 && newtile) wait_vmcnt_capped<Cf::ST + GW>();                              \
+        else if (ny == 0 && havep) wait_vmcnt_capped<GW + GP>();                                    \
+        else if (ny == 0) wait_vmcnt_capped<GW>();                                                  \
+        else if (ny == 1 && hadp) wait_vmcnt_capped<GP + GW>();                                     \
+        else wait_vmcnt_capped<GW>();                                                               \
+    } while (0)
+
+    if (nstage > 0) { issue_patch(0); issue_weights(0); }
+    for (int s = 0; s < nstage; ++s) {
+        const int ny = s % NY, ps = s / NY, q = ps % nq;
+        const bool last = s + 1 >= nstage;
+        const bool havep = ny == 0 && ps + 1 < npatch;      // this stage prefetches the next patch
+        const bool hadp = ny == 1 && ps + 1 < npatch;       // the previous stage did
+        const bool newtile = ny == 0 && q == 0 && s > 0;    // the previous stage ended a tile (stores were issued)
+        if (!last) issue_weights(s + 1);
+        if (havep) issue_patch(ps + 1);
+        if (wave < 2) ALSEP_PIPE_WAIT(true); else ALSEP_PIPE_WAIT(false);
+        barrier_nodrain();
+        {
+            const bf16_t* patch = pring + (size_t)(ps & 1) * Cf::PGROUPS * 8;
+            const bf16_t* wts = wring + (size_t)(s & 1) * Cf::WGROUPS * 8;
+            // ny is a run-time value but acc must be indexed statically: dispatch over NY
+#pragma unroll
+            for (int yy = 0; yy < NY; ++yy) {
+                if (yy == ny) {
+                    if (q == 0) {
+#pragma unroll
+                        for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni) acc[yy][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll 2
+                    for (int st = 0; st < Cf::NS; ++st) {
+                        const int ko = koff_of(st);
+                        bf16x8 xf[4], wf[3];
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) xf[ni] = lds_frag<bf16_t>(patch + pbase[ni] + ko);
+#pragma unroll
+                        for (int mi = 0; mi < 3; ++mi) wf[mi] = lds_frag<bf16_t>(wts + ((mi * 16 + l15) * Cf::WGRP + ((4 * st + lq) ^ wswz)) * 8);
+#pragma unroll
+                        for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni) mma_step(acc[yy][mi][ni], wf[mi], xf[ni]);
+                    }
+                }
+            }
+        }
+        barrier_nodrain();                                   // both slots read by this stage may be refilled
+        if (ny == NY - 1 && q == nq - 1) {                   // tile finished: NY*12 stores per wave
+            int t0, f0; int64_t b;
+            tile_coords(ps / nq, t0, f0, b);
+            bf16_t* yb = Y + ((b * Th + t0 + wave) * (int64_t)Fw + f0) * Cout;
+#pragma unroll
+            for (int yy = 0; yy < NY; ++yy)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 3; ++mi) {
+                        const int co = yy * Cf::BN + mi * 16 + 4 * lq;
+                        const f32x4 scv = *reinterpret_cast<const f32x4*>(ss + co);      // ext-vector load: see regw kernel
+                        const f32x4 shv = *reinterpret_cast<const f32x4*>(ss + NY * Cf::BN + co);
+                        float y[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[yy][mi][ni][r], scv[r], shv[r]), 0.f);
+                        store4(yb + (int64_t)(ni * 16 + l15) * Cout + co, y);
+                    }
+        }
+    }
+#undef ALSEP_PIPE_WAIT
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1245,6 +1433,31 @@ int launch_conv_regw(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t
     return ALSEP_OK;
 }
 
+template <int NY>
+int launch_conv_pipe(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zero_page, int64_t B,
+                     int Th, int Fw) {
+    typedef ConvPipe<NY> Cf;
+    const int tiles_t = Th / Cf::TH, tiles_f = Fw / Cf::TW;
+    const int64_t ntiles = B * tiles_t * tiles_f;
+    if (ntiles > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "conv3x3: too many tiles");
+    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_pipe_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)Cf::lds_bytes));
+    const int gx = ntiles < 256 ? (int)ntiles : 256;        // one persistent workgroup per CU
+    ProfScope prof(ctx, ALSEP_PROF_CONV3X3);
+    hipLaunchKernelGGL((conv3x3_bf16_pipe_kernel<NY>), dim3((unsigned)gx), dim3(kThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                       (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
+                       L.cout, tiles_t, tiles_f, (int)ntiles);
+    ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_pipe_kernel");
+    return ALSEP_OK;
+}
+
+int conv_pipe_enabled() {
+    // opt-in: bit-identical to the plain kernel but not faster on MI355X (profiles/r01_conv_variants.txt):
+    // the per-CU LDS-DMA intake, not the missing overlap, bounds these levels
+    static const int v = [] { const char* e = getenv("ALSEP_CONV_PIPE"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 int conv_regw_enabled() {
     static const int v = [] { const char* e = getenv("ALSEP_CONV_REGW"); return e ? atoi(e) : 1; }();
     return v;
@@ -1254,6 +1467,14 @@ int run_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y,
     if (conv_regw_enabled() && Th % 4 == 0 && Fw % 64 == 0 && L.cin == L.cout) {
         if (L.cin == 48) return launch_conv_regw<1>(ctx, L, X, Y, zp, B, Th, Fw);
         if (L.cin == 96 && conv_regw_enabled() >= 2) return launch_conv_regw<2>(ctx, L, X, Y, zp, B, Th, Fw);
+    }
+    if (conv_pipe_enabled() && Th % 4 == 0 && Fw % 64 == 0 && L.cin == L.cout &&
+        (conv_pipe_enabled() >= 2 || B * (Th / 4) * (Fw / 64) >= 128)) {   // =2: no minimum tile count (tests)
+        switch (L.cout / 48) {
+            case 2: return launch_conv_pipe<2>(ctx, L, X, Y, zp, B, Th, Fw);
+            case 3: return launch_conv_pipe<3>(ctx, L, X, Y, zp, B, Th, Fw);
+            default: break;                                  // NY = 4 spills registers with ROCm 7.2: stays on the plain kernel
+        }
     }
     if (Fw >= 64 && Fw % 64 == 0) return launch_conv_dma<64>(ctx, L, X, Y, zp, B, Th, Fw);
     if (Fw >= 32) return launch_conv_dma<32>(ctx, L, X, Y, zp, B, Th, Fw);

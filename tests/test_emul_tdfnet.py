@@ -68,22 +68,23 @@ def test_net_bf16_g48(emul):
 
 
 def test_net_bf16_persistent_conv_two_chunks(emul, monkeypatch):
-    """Cin = 96 variant of the persistent register-weight conv (two input chunks per tile; opt-in)."""
+    """Persistent conv variants: register-weight kernel with two input chunks (opt-in) and the software-
+    pipelined kernel for Cout = 96 / 144 (level 1: 9*4*4 = 144 tiles >= 128; level 2 falls back)."""
     import subprocess, sys, os
     code = (
-        "import os, sys, torch; sys.path.insert(0, %r); os.environ['ALSEP_CONV_REGW']='2'\n"
+        "import os, sys, torch; sys.path.insert(0, %r); os.environ['ALSEP_CONV_REGW']='2'; os.environ['ALSEP_CONV_PIPE']='2'\n"
         "from audiolab_amd import _lib\n"
         "_lib._LIB=_lib.bind(%r); _lib.DEVICE_TYPE='cpu'\n"
         "from audiolab_amd.synth import synthetic_state_dict\n"
         "from audiolab_amd.tdfnet import TDFNet, TDFNetConfig\n"
         "from oracle import tdfnet_oracle\n"
-        "cfg=TDFNetConfig(dim_f=128, dim_t=8, n_fft=256, hop=64, num_blocks=3, g=48)\n"
-        "sd=synthetic_state_dict(cfg, calib_frames=8)\n"
-        "net=TDFNet(cfg, sd, ctx=_lib.Context('cpu'), dtype=torch.bfloat16, max_batch=3)\n"
-        "x=(torch.randn((3,4,128,8), generator=torch.Generator().manual_seed(3))*4).to(torch.bfloat16)\n"
-        "want=tdfnet_oracle.forward(sd, x.float(), 3, 3, 8)\n"
+        "cfg=TDFNetConfig(dim_f=256, dim_t=16, n_fft=512, hop=64, num_blocks=5, g=48)\n"
+        "sd=synthetic_state_dict(cfg, calib_frames=16)\n"
+        "net=TDFNet(cfg, sd, ctx=_lib.Context('cpu'), dtype=torch.bfloat16, max_batch=9)\n"
+        "x=(torch.randn((9,4,256,16), generator=torch.Generator().manual_seed(3))*4).to(torch.bfloat16)\n"
+        "want=tdfnet_oracle.forward(sd, x.float(), 5, 3, 8)\n"
         "got=net.forward_nhwc(x.permute(0,3,2,1).contiguous()).float().permute(0,3,2,1)\n"
-        "rel=float((got-want).norm()/want.norm()); print('rel', rel); assert rel < 6e-2\n"
+        "rel=float((got-want).norm()/want.norm()); print('rel', rel); assert rel < 8e-2\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpu_emul", "libalsep_emul.so"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
