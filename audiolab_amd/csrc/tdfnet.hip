@@ -1089,6 +1089,146 @@ tdf_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 ds (2x2/2 conv, 48 -> 96) and us (2x2 transposed conv, 96 -> 48, * skip) between levels 0 and 1,
+// the two largest resampling layers.  Every input element feeds exactly one output pixel (no halo,
+// no reuse), so nothing is staged: a wave keeps its weight fragments in registers for its whole
+// life, reads activation fragments (16 contiguous bytes per lane) straight from global memory into
+// the MFMA B operand, and only the epilogue goes through LDS to leave as whole contiguous rows.
+// Weights are packed in fragment order [m-tile][k-step][lane][8].
+// ------------------------------------------------------------------------------------------
+struct Ds48 { static constexpr int C = 48, M = 96, K = 192, MT = 6, KS = 6; };
+struct Us48 { static constexpr int C = 96, C2 = 48, K = 96, MT = 3, KS = 3; };
+
+__global__ void __launch_bounds__(kThreads, 1)
+ds48_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wf,
+                   const float* __restrict__ scale, const float* __restrict__ shift, int64_t npix, int Tp, int Fp) {
+    typedef Ds48 D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    bf16_t* stg = reinterpret_cast<bf16_t*>(alsep_smem) + (size_t)wave * 64 * D::M;     // wave-private [64 px][96 ch]
+    bf16x8 wf[D::MT][D::KS];
+#pragma unroll
+    for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < D::KS; ++ks)
+            wf[mt][ks] = *reinterpret_cast<const bf16x8*>(Wf + ((size_t)(mt * D::KS + ks) * 64 + lane) * 8);
+    float sc[D::MT][4], sh[D::MT][4];
+#pragma unroll
+    for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sc[mt][r] = scale[mt * 16 + 4 * lq + r]; sh[mt][r] = shift[mt * 16 + 4 * lq + r]; }
+    const int64_t ntile = npix / 64;                         // Fp % 64 == 0: a tile is 64 consecutive f' of one row
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntile; tile += (int64_t)gridDim.x * 4) {
+        const int64_t p0 = tile * 64;
+        const int64_t fp0 = p0 % Fp, tp = (p0 / Fp) % Tp, bb = p0 / ((int64_t)Fp * Tp);
+        // input pixel (2tp + dy, 2(fp0 + j) + dx): k = (dy*2 + dx)*48 + ci -> two runs of 96 per dy
+        const bf16_t* xrow = X + ((bb * 2 * Tp + 2 * tp) * (2 * (int64_t)Fp) + 2 * fp0) * D::C;
+        f32x4 acc[D::MT][4];
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mt][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < D::KS; ++ks) {
+            const int k = ks * 32 + lq * 8;
+            const int dy = k / (2 * D::C), rem = k % (2 * D::C);
+            bf16x8 xf[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                xf[ni] = *reinterpret_cast<const bf16x8*>(xrow + (int64_t)dy * (2 * (int64_t)Fp * D::C) + (int64_t)(ni * 16 + l15) * (2 * D::C) + rem);
+#pragma unroll
+            for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) mma_step(acc[mt][ni], wf[mt][ks], xf[ni]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < D::MT; ++mt)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[mt][ni][r], sc[mt][r], sh[mt][r]), 0.f);
+                store4(stg + (ni * 16 + l15) * D::M + mt * 16 + 4 * lq, y);
+            }
+        __builtin_amdgcn_wave_barrier();
+        bf16_t* yrow = Y + p0 * D::M;                        // 64 pixels x 96 channels = 12 KiB contiguous
+#pragma unroll
+        for (int it = 0; it < 64 * D::M / 8 / 64; ++it)
+            *reinterpret_cast<vec16*>(yrow + ((size_t)it * 64 + lane) * 8) = *reinterpret_cast<const vec16*>(stg + ((size_t)it * 64 + lane) * 8);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ void __launch_bounds__(kThreads, 1)
+us48_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wf,
+                   const float* __restrict__ scale, const float* __restrict__ shift, const bf16_t* __restrict__ skip,
+                   int64_t npix, int Tp, int Fp) {
+    typedef Us48 U;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int dy = wave >> 1, dx = wave & 1;                 // this wave's tap of the 2x2 transposed kernel
+    float* stg = reinterpret_cast<float*>(alsep_smem);       // [dy][128 output pixels][48 ch] fp32 = 48 KiB
+    bf16x8 wf[U::MT][U::KS];
+#pragma unroll
+    for (int mt = 0; mt < U::MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < U::KS; ++ks)
+            wf[mt][ks] = *reinterpret_cast<const bf16x8*>(Wf + ((size_t)((wave * U::MT + mt) * U::KS + ks) * 64 + lane) * 8);
+    float sc[U::MT][4], sh[U::MT][4];
+#pragma unroll
+    for (int mt = 0; mt < U::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sc[mt][r] = scale[mt * 16 + 4 * lq + r]; sh[mt][r] = shift[mt * 16 + 4 * lq + r]; }
+    const int64_t ntile = npix / 64;
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int64_t p0 = tile * 64;
+        const int64_t fp0 = p0 % Fp, tp = (p0 / Fp) % Tp, bb = p0 / ((int64_t)Fp * Tp);
+        f32x4 acc[U::MT][4];
+#pragma unroll
+        for (int mt = 0; mt < U::MT; ++mt)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mt][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < U::KS; ++ks) {
+            bf16x8 xf[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                xf[ni] = *reinterpret_cast<const bf16x8*>(X + (p0 + ni * 16 + l15) * U::C + ks * 32 + lq * 8);
+#pragma unroll
+            for (int mt = 0; mt < U::MT; ++mt)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) mma_step(acc[mt][ni], wf[mt][ks], xf[ni]);
+        }
+        // relu(bn(.)) in fp32 to LDS at output pixel 2j + dx of row dy
+#pragma unroll
+        for (int mt = 0; mt < U::MT; ++mt)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                f32x4 y;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[mt][ni][r], sc[mt][r], sh[mt][r]), 0.f);
+                *reinterpret_cast<f32x4*>(stg + ((size_t)dy * 128 + 2 * (ni * 16 + l15) + dx) * U::C2 + mt * 16 + 4 * lq) = y;
+            }
+        __syncthreads();
+        // 2 rows x 128 pixels x 6 groups of 8 channels; output rows are contiguous (128 x 96 B)
+#pragma unroll
+        for (int it = 0; it < 2 * 128 * 6 / kThreads; ++it) {
+            const int gidx = it * kThreads + tid;
+            const int row = gidx / (128 * 6), rem = gidx % (128 * 6);
+            const int64_t o = ((bb * 2 * Tp + 2 * tp + row) * (2 * (int64_t)Fp) + 2 * fp0) * U::C2 + (int64_t)rem * 8;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + (size_t)row * 128 * U::C2 + (size_t)rem * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + (size_t)row * 128 * U::C2 + (size_t)rem * 8 + 4);
+            const bf16x8 sk = *reinterpret_cast<const bf16x8*>(skip + o);
+            bf16x8 q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { q[e] = (bf16_t)(lo[e] * (float)sk[e]); q[4 + e] = (bf16_t)(hi[e] * (float)sk[4 + e]); }
+            *reinterpret_cast<bf16x8*>(Y + o) = q;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side: packing + orchestration
 // ------------------------------------------------------------------------------------------
 struct DevBuf {
@@ -1106,6 +1246,7 @@ struct GemmLayer {       // ds / us / tdf
     int M = 0, K = 0, Kp = 0, Mp = 0;
     bool has_bias = false;
     bool dma_path = false;   // packed for tdf_bf16_kernel
+    DevBuf wfrag;            // [m-tile][k-step][lane][8] for the streaming ds/us kernels (bf16, level 0 <-> 1 only)
 };
 struct Block {
     std::vector<ConvLayer> tfc;
@@ -1268,6 +1409,21 @@ int make_tdf_dma_weights(alsep_net* net, const std::vector<float>& wmk, int M, i
     return upload(net, pk.data(), pk.size() * sizeof(bf16_t), &L->w);
 }
 
+// fragment-order image of a [M][K] matrix for register-resident A operands: lane l of (m-tile, k-step) holds
+// W[16*mt + (l & 15)][32*ks + 8*(l >> 4) + e], e < 8 (zero beyond M / K)
+int make_frag_weights(alsep_net* net, const std::vector<float>& wmk, int M, int K, DevBuf* out) {
+    const int MT = (M + 15) / 16, KS = (K + 31) / 32;
+    std::vector<bf16_t> pk((size_t)MT * KS * 64 * 8, host_cast<bf16_t>(0.f));
+    for (int mt = 0; mt < MT; ++mt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int m = mt * 16 + (l & 15), k = ks * 32 + (l >> 4) * 8 + e;
+                    if (m < M && k < K) pk[(((size_t)mt * KS + ks) * 64 + l) * 8 + e] = host_cast<bf16_t>(wmk[(size_t)m * K + k]);
+                }
+    return upload(net, pk.data(), pk.size() * sizeof(bf16_t), out);
+}
+
 template <typename T>
 int make_block(alsep_net* net, const TensorMap& tm, const std::string& p, int c, int f, Block* blk) {
     const alsep_net_config& cfg = net->cfg;
@@ -1338,6 +1494,7 @@ int build_net(alsep_net* net, const TensorMap& tm) {
             for (int ci = 0; ci < c; ++ci)
                 for (int d = 0; d < 4; ++d) mk[(size_t)co * 4 * c + d * c + ci] = (*w)[((size_t)co * c + ci) * 4 + d];
         if ((rc = make_gemm_weights<T>(net, mk, c2, 4 * c, &net->ds[i]))) return rc;
+        if (is_bf16<T>() && c == 48 && c2 == 96 && (rc = make_frag_weights(net, mk, c2, 4 * c, &net->ds[i].wfrag))) return rc;
         if ((rc = upload(net, sc->data(), c2 * 4, &net->ds[i].scale))) return rc;
         if ((rc = upload(net, sh->data(), c2 * 4, &net->ds[i].shift))) return rc;
         c = c2; f /= 2;
@@ -1358,6 +1515,7 @@ int build_net(alsep_net* net, const TensorMap& tm) {
         for (int d = 0; d < 4; ++d)
             for (int co = 0; co < c2; ++co) { sc4[d * c2 + co] = (*sc)[co]; sh4[d * c2 + co] = (*sh)[co]; }
         if ((rc = make_gemm_weights<T>(net, mk, 4 * c2, c, &net->us[i]))) return rc;
+        if (is_bf16<T>() && c == 96 && c2 == 48 && (rc = make_frag_weights(net, mk, 4 * c2, c, &net->us[i].wfrag))) return rc;
         if ((rc = upload(net, sc4.data(), sc4.size() * 4, &net->us[i].scale))) return rc;
         if ((rc = upload(net, sh4.data(), sh4.size() * 4, &net->us[i].shift))) return rc;
         c = c2; f *= 2;
@@ -1491,9 +1649,36 @@ int run_conv(alsep_ctx* ctx, const ConvLayer& L, const T* X, T* Y, int64_t B, in
     return run_conv_tw<T, ConvSel16<T>::KC, ConvSel16<T>::BN>(ctx, L, X, Y, B, Th, Fw);
 }
 
+int pix_stream_enabled() {
+    static const int v = [] { const char* e = getenv("ALSEP_PIX_STREAM"); return e ? atoi(e) : 1; }();
+    return v;
+}
+int run_pix_stream(alsep_ctx* ctx, int mode, const GemmLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* skip, int64_t ncols,
+                   int Tp, int Fp) {
+    ProfScope prof(ctx, ALSEP_PROF_PIX);
+    const int64_t ntile = ncols / 64;
+    if (mode == PIX_DS) {
+        const size_t lds = 4 * 64 * Ds48::M * sizeof(bf16_t);
+        const int64_t gx = std::min<int64_t>(ceil_div64(ntile, 4), 256);
+        hipLaunchKernelGGL(ds48_stream_kernel, dim3((unsigned)gx), dim3(kThreads), lds, ctx->stream, X, Y, (const bf16_t*)L.wfrag.p,
+                           (const float*)L.scale.p, (const float*)L.shift.p, ncols, Tp, Fp);
+    } else {
+        const size_t lds = 2 * 128 * Us48::C2 * sizeof(float);
+        const int64_t gx = std::min<int64_t>(ntile, 512);
+        hipLaunchKernelGGL(us48_stream_kernel, dim3((unsigned)gx), dim3(kThreads), lds, ctx->stream, X, Y, (const bf16_t*)L.wfrag.p,
+                           (const float*)L.scale.p, (const float*)L.shift.p, skip, ncols, Tp, Fp);
+    }
+    ALSEP_LAUNCH_CHECK(ctx, "pix stream kernel");
+    return ALSEP_OK;
+}
+int run_pix_stream(alsep_ctx* ctx, int, const GemmLayer&, const float*, float*, const float*, int64_t, int, int) {
+    return alsep_fail(ctx, ALSEP_ERR_STATE, "streaming ds/us path is bf16 only");
+}
+
 template <typename T, int MODE>
 int run_pix(alsep_ctx* ctx, const GemmLayer& L, const T* X, T* Y, const T* skip, int64_t ncols, int Tp, int Fp, int C, int C2) {
     typedef GemmCfg<T> Gc;
+    if (L.wfrag.p && pix_stream_enabled() && Fp % 64 == 0) return run_pix_stream(ctx, MODE, L, X, Y, skip, ncols, Tp, Fp);
     const int64_t gx = ceil_div64(ncols, Gc::BC);
     if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "pix_gemm: too many column tiles");
     ProfScope prof(ctx, ALSEP_PROF_PIX);
