@@ -98,11 +98,12 @@ template <> __device__ __forceinline__ void dft<8>(float2 (&u)[8]) {
 // One Stockham pass of radix R over the LDS buffer; P = product of the radices already done.
 // Butterfly i reads buf[i + r*N/R], twiddles by W_{P*R}^{k*r} (k = i mod P) and writes
 // buf[(i-k)*R + k + r*P].  All reads precede all writes (barrier), so one buffer suffices.
+// w1[b] = W_{P*R}^{k} of this thread's b-th butterfly, preloaded into registers (FftRegs): a table
+// read inside the pass would put one dependent memory latency on every pass of the chain.
 template <int N, int NT, int P, int R>
-__device__ __forceinline__ void fft_pass(float2* buf, const float2* __restrict__ tw, int tid) {
+__device__ __forceinline__ void fft_pass(float2* buf, const float2 (&w1)[(N / R + NT - 1) / NT], int tid) {
     constexpr int M = N / R;
     constexpr int NB = (M + NT - 1) / NT;
-    constexpr int TWS = N / (P * R);
     float2 u[NB][R];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -119,9 +120,9 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* __restrict__
         if (i < M) {
             const int k = i % P;
             if (P > 1) {
-                // one table read per butterfly; W^r by products (depth <= 3 complex multiplies)
+                // W^r by products of W^1 (depth <= 3 complex multiplies)
                 float2 w[R];
-                w[1] = tw[k * TWS];
+                w[1] = w1[b];
 #pragma unroll
                 for (int r = 2; r < R; ++r) w[r] = (r & 1) ? cmul(w[r - 1], w[1]) : cmul(w[r >> 1], w[r >> 1]);
 #pragma unroll
@@ -136,25 +137,36 @@ __device__ __forceinline__ void fft_pass(float2* buf, const float2* __restrict__
     __syncthreads();
 }
 
-template <int N, int NT, int P, int... Rs> struct FftRun;
-template <int N, int NT, int P> struct FftRun<N, NT, P> {
-    static __device__ __forceinline__ void run(float2*, const float2*, int) { static_assert(P == N, "radices must multiply to N"); }
+// The whole transform as a chain of passes, each with its first-order twiddles in registers:
+// load() once per workgroup (all table reads issued together, before the first pass), run() per frame.
+template <int N, int NT, int P, int... Rs> struct FftRegs;
+template <int N, int NT, int P> struct FftRegs<N, NT, P> {
+    static_assert(P == N, "radices must multiply to N");
+    __device__ __forceinline__ void load(const float2*, int) {}
+    __device__ __forceinline__ void run(float2*, int) const {}
 };
-template <int N, int NT, int P, int R0, int... Rs> struct FftRun<N, NT, P, R0, Rs...> {
-    static __device__ __forceinline__ void run(float2* buf, const float2* tw, int tid) {
-        fft_pass<N, NT, P, R0>(buf, tw, tid);
-        FftRun<N, NT, P * R0, Rs...>::run(buf, tw, tid);
+template <int N, int NT, int P, int R0, int... Rs> struct FftRegs<N, NT, P, R0, Rs...> {
+    static constexpr int M = N / R0, NB = (M + NT - 1) / NT, TWS = N / (P * R0);
+    float2 w1[NB];
+    FftRegs<N, NT, P * R0, Rs...> next;
+    __device__ __forceinline__ void load(const float2* __restrict__ tw, int tid) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int i = tid + b * NT;
+            w1[b] = (P > 1 && i < M) ? tw[(i % P) * TWS] : make_float2(1.f, 0.f);
+        }
+        next.load(tw, tid);
+    }
+    __device__ __forceinline__ void run(float2* buf, int tid) const {
+        fft_pass<N, NT, P, R0>(buf, w1, tid);
+        next.run(buf, tid);
     }
 };
 
 // radix sequences per supported n_fft
 template <int N, int NT> struct Fft;
 #define ALSEP_FFT(N_, ...)                                                                 \
-    template <int NT> struct Fft<N_, NT> {                                                 \
-        static __device__ __forceinline__ void run(float2* buf, const float2* tw, int tid) { \
-            FftRun<N_, NT, 1, __VA_ARGS__>::run(buf, tw, tid);                             \
-        }                                                                                  \
-    };
+    template <int NT> struct Fft<N_, NT> { typedef FftRegs<N_, NT, 1, __VA_ARGS__> Regs; };
 ALSEP_FFT(256, 8, 8, 4)
 ALSEP_FFT(384, 3, 2, 8, 8)
 ALSEP_FFT(480, 5, 3, 8, 4)
@@ -204,6 +216,8 @@ stft_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_stri
     const int64_t b = blockIdx.y;
     const float* xl = pcm + b * chunk_stride;
     const float* xr = xl + ch_stride;
+    typename Fft<N, NT>::Regs fft;
+    fft.load(tw, tid);
     const int p0 = t * hop - N / 2;
     for (int n = tid; n < N; n += NT) {
         int p = p0 + n;
@@ -213,7 +227,7 @@ stft_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_stri
         buf[n] = make_float2(xl[p] * w, xr[p] * w);
     }
     __syncthreads();
-    Fft<N, NT>::run(buf, tw, tid);
+    fft.run(buf, tid);
     for (int k = tid; k < dim_f; k += NT) {
         const float2 zk = buf[k];
         const float2 zn = buf[k == 0 ? 0 : N - k];
@@ -258,6 +272,8 @@ istft_kernel(const InT* __restrict__ spec, int hop, int dim_f, int T, const floa
     const int t_start = max(0, j0 - Q + 1);
     for (int t = t_start; t < j1; ++t) {
         if (t < T) {
+            typename Fft<N, NT>::Regs fft;                   // twiddle reads issued with the spectrogram loads,
+            fft.load(tw, tid);                               // not kept live across frames (register pressure)
             // conj(Z) with Z[k] = XL[k] + i XR[k], Hermitian-extended; bins >= dim_f are zero.
             for (int k = tid; k <= N / 2; k += NT) {
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -279,7 +295,7 @@ istft_kernel(const InT* __restrict__ spec, int hop, int dim_f, int T, const floa
                 }
             }
             __syncthreads();
-            Fft<N, NT>::run(buf, tw, tid);
+            fft.run(buf, tid);
             const int base = (t % Q) * hop;                  // (t*hop) mod RN
             for (int n = tid; n < N; n += NT) {
                 const float w = win[n] * inv_n;
@@ -312,6 +328,90 @@ istft_kernel(const InT* __restrict__ spec, int hop, int dim_f, int T, const floa
         }
         for (int i = tid; i < hop; i += NT) ring[slot + i] = make_float2(0.f, 0.f);
         __syncthreads();
+    }
+}
+
+// iSTFT with the overlap-add accumulator in REGISTERS (hop and n_fft multiples of the 256 threads):
+// thread tid owns window positions j*256 + tid, j < N/256; after each frame the first hop/256 entries
+// (the finished hop-block) are written out and the array slides down.  LDS then holds only the FFT
+// buffer (48 KiB at 6144), so three workgroups fit a CU instead of one -- the kernel is a chain of
+// dependent passes per frame and needs the other workgroups to hide its latency.
+template <int N, int HOP, typename InT, int LAYOUT>
+__global__ void __launch_bounds__(kFftThreads)
+istft_regring_kernel(const InT* __restrict__ spec, int dim_f, int T, const float2* __restrict__ tw,
+                     const float* __restrict__ win, const float* __restrict__ env, int j_lo, int j_hi, int run,
+                     float* __restrict__ out, int64_t out_ch_stride, int64_t out_chunk_stride, int64_t keep_lo,
+                     int64_t keep_hi, int64_t out_limit) {
+    constexpr int NT = kFftThreads;
+    constexpr int NA = N / NT, NB = HOP / NT;               // accumulator entries, entries per hop-block
+    constexpr int Q = (N + HOP - 1) / HOP;
+    static_assert(N % NT == 0 && HOP % NT == 0, "register ring needs hop and n_fft to be multiples of 256");
+    float2* buf = reinterpret_cast<float2*>(alsep_smem);
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.y;
+    const int j0 = j_lo + blockIdx.x * run;
+    const int j1 = min(j0 + run, j_hi);
+    if (j0 >= j1) return;
+    float2 acc[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) acc[j] = make_float2(0.f, 0.f);
+    float wv[NA];
+    const float inv_n = 1.0f / (float)N;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) wv[j] = win[j * NT + tid] * inv_n;
+    const int t_start = max(0, j0 - Q + 1);
+    for (int t = t_start; t < j1; ++t) {
+        if (t < T) {
+            typename Fft<N, NT>::Regs fft;
+            fft.load(tw, tid);
+            for (int k = tid; k <= N / 2; k += NT) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (k < dim_f) {
+                    if (LAYOUT == ALSEP_LAYOUT_NHWC) {
+                        load_spec4<InT>(spec + ((b * T + t) * (int64_t)dim_f + k) * 4, v);
+                    } else {
+                        const int64_t plane = (int64_t)dim_f * T;
+                        const InT* s = spec + b * 4 * plane + (int64_t)k * T + t;
+                        v[0] = to_f32(s[0]); v[1] = to_f32(s[plane]);
+                        v[2] = to_f32(s[2 * plane]); v[3] = to_f32(s[3 * plane]);
+                    }
+                }
+                if (k == 0 || k == N / 2) {
+                    buf[k] = make_float2(v[0], -v[2]);
+                } else {
+                    buf[k] = make_float2(v[0] - v[3], -(v[1] + v[2]));
+                    buf[N - k] = make_float2(v[0] + v[3], v[1] - v[2]);
+                }
+            }
+            __syncthreads();
+            fft.run(buf, tid);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const float2 z = buf[j * NT + tid];
+                acc[j].x += wv[j] * z.x;
+                acc[j].y -= wv[j] * z.y;
+            }
+            __syncthreads();                                 // buf is rewritten by the next frame
+        }
+        if (t >= j0) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int64_t p = (int64_t)t * HOP + j * NT + tid;
+                const int64_t s = p - N / 2;
+                if (s >= keep_lo && s < keep_hi) {
+                    const int64_t o = b * out_chunk_stride + (s - keep_lo);
+                    if (o < out_limit) {
+                        const float e = 1.0f / env[p];
+                        out[o] = acc[j].x * e;
+                        out[out_ch_stride + o] = acc[j].y * e;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NA - NB; ++j) acc[j] = acc[j + NB];
+#pragma unroll
+        for (int j = NA - NB; j < NA; ++j) acc[j] = make_float2(0.f, 0.f);
     }
 }
 
@@ -470,13 +570,32 @@ static int launch_istft(alsep_ctx* ctx, const alsep_plan* p, const void* spec, i
                         int64_t out_ch_stride, int64_t out_chunk_stride, int64_t keep_lo, int64_t keep_hi,
                         int64_t out_limit) {
     const int Q = (N + p->hop - 1) / p->hop;
+    const int j_lo = (int)((keep_lo + N / 2) / p->hop);
+    const int j_hi = (int)((keep_hi - 1 + N / 2) / p->hop) + 1;
+    ProfScope prof(ctx, ALSEP_PROF_ISTFT);
+    if constexpr (N % 1024 == 0 || N == 7680) {
+        if (p->hop == 1024) {                                // production geometry: register ring, 3 workgroups per CU
+            const size_t lds_r = sizeof(float2) * (size_t)N;
+            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)istft_regring_kernel<N, 1024, InT, LAYOUT>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+            const int run = 16;
+            const int groups_r = (j_hi - j_lo + run - 1) / run;
+            for (int64_t b0 = 0; b0 < n_chunks; b0 += 32768) {
+                const int64_t nb = std::min<int64_t>(32768, n_chunks - b0);
+                const int64_t spec_off = b0 * 4 * (int64_t)p->dim_f * p->dim_t;
+                hipLaunchKernelGGL((istft_regring_kernel<N, 1024, InT, LAYOUT>), dim3(groups_r, (unsigned)nb), dim3(kFftThreads),
+                                   lds_r, ctx->stream, (const InT*)spec + spec_off, p->dim_f, p->dim_t, (const float2*)p->tw,
+                                   (const float*)p->win, (const float*)p->env, j_lo, j_hi, run, out + b0 * out_chunk_stride,
+                                   out_ch_stride, out_chunk_stride, keep_lo, keep_hi, out_limit - b0 * out_chunk_stride);
+            }
+            ALSEP_LAUNCH_CHECK(ctx, "istft_regring_kernel");
+            return ALSEP_OK;
+        }
+    }
     const size_t lds = sizeof(float2) * (size_t)(N + Q * p->hop);
     ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)istft_kernel<N, InT, LAYOUT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int j_lo = (int)((keep_lo + N / 2) / p->hop);
-    const int j_hi = (int)((keep_hi - 1 + N / 2) / p->hop) + 1;
     const int groups = (j_hi - j_lo + kIstftRun - 1) / kIstftRun;
-    ProfScope prof(ctx, ALSEP_PROF_ISTFT);
     for (int64_t b0 = 0; b0 < n_chunks; b0 += 32768) {
         const int64_t nb = std::min<int64_t>(32768, n_chunks - b0);
         const int64_t spec_off = b0 * 4 * (int64_t)p->dim_f * p->dim_t;

@@ -26,11 +26,27 @@ def sample_range(n_win: int, gen: int, n_sample: int, world: int, rank: int) -> 
     return min(w_lo * gen, n_sample), min(w_hi * gen, n_sample)
 
 
+class PendingGather:
+    """An all-gather in flight (RCCL runs it on its own stream): ``result()`` waits and assembles."""
+
+    def __init__(self, work, recv, ranges, lead, n_sample):
+        self.work, self.recv, self.ranges, self.lead, self.n_sample = work, recv, ranges, lead, n_sample
+
+    def result(self) -> torch.Tensor:
+        if self.work is not None:
+            self.work.wait()
+        out = torch.empty(self.lead + (self.n_sample,), dtype=self.recv.dtype, device=self.recv.device)
+        for r, (l, h) in enumerate(self.ranges):
+            out[..., l:h] = self.recv[r][..., : h - l]
+        return out
+
+
 def all_gather_segments(local: torch.Tensor, n_win: int, gen: int, n_sample: int,
-                        group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+                        group: Optional[dist.ProcessGroup] = None, async_op: bool = False):
     """local: [..., n_local] this rank's stem samples (its ``sample_range``) -> [..., n_sample] on
     every rank.  One collective: shards are padded to the largest shard so that a single
-    ``all_gather_into_tensor`` moves everything (each peer's shard travels its own xGMI link)."""
+    ``all_gather_into_tensor`` moves everything (each peer's shard travels its own xGMI link).
+    ``async_op=True`` returns a :class:`PendingGather` so the next model's kernels overlap the transfer."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     ranges = [sample_range(n_win, gen, n_sample, world, r) for r in range(world)]
@@ -43,10 +59,8 @@ def all_gather_segments(local: torch.Tensor, n_win: int, gen: int, n_sample: int
     send[..., : hi - lo] = local
     recv = torch.empty((world,) + lead + (width,), dtype=local.dtype, device=local.device)
     if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(recv, send.contiguous(), group=group)     # one ncclAllGather (RCCL)
+        work = dist.all_gather_into_tensor(recv, send.contiguous(), group=group, async_op=async_op)   # one ncclAllGather (RCCL)
     else:                                                                     # gloo has no _allgather_base
-        dist.all_gather(list(recv.unbind(0)), send.contiguous(), group=group)
-    out = torch.empty(lead + (n_sample,), dtype=local.dtype, device=local.device)
-    for r, (l, h) in enumerate(ranges):
-        out[..., l:h] = recv[r][..., : h - l]
-    return out
+        work = dist.all_gather(list(recv.unbind(0)), send.contiguous(), group=group, async_op=async_op)
+    pending = PendingGather(work if async_op else None, recv, ranges, lead, n_sample)
+    return pending if async_op else pending.result()

@@ -185,18 +185,27 @@ class Predictor:
                 break
         return segs, margin
 
-    def demix(self, mix: torch.Tensor) -> torch.Tensor:
-        """mix [2,N] float32 on the device -> sources [1,2,N] (mdxnet.py:109-141)."""
+    def demix(self, mix: torch.Tensor, defer: bool = False):
+        """mix [2,N] float32 on the device -> sources [1,2,N] (mdxnet.py:109-141).
+        ``defer=True`` (sharded runs): returns a callable; the all-gathers of the segments stay in
+        flight (RCCL stream) while the caller launches the next model, and the callable assembles."""
         if mix.dim() != 2 or mix.shape[0] != 2:
             raise AlsepError("demix expects a [2,N] stereo tensor")
         mix = mix.contiguous().float()
         samples = mix.shape[-1]
         segs, margin = self.segments(samples)
+        pending = [self.demix_segment(mix[:, start:end], async_gather=defer and self.sharded) for (_s, start, end) in segs]
+
+        def assemble() -> torch.Tensor:
+            return self._assemble(pending, segs, margin, samples)
+        return assemble if defer else assemble()
+
+    def _assemble(self, pending, segs, margin, samples) -> torch.Tensor:
         out = self.ctx.empty((1, 2, samples), torch.float32)
         pos = 0
         for idx, (skip, start, end) in enumerate(segs):
             first, last = idx == 0, idx == len(segs) - 1
-            seg = self.demix_segment(mix[:, start:end])            # [2, end-start]
+            seg = pending[idx].result() if hasattr(pending[idx], "result") else pending[idx]   # [2, end-start]
             lo = 0 if first else margin                            # :185
             hi = seg.shape[-1] if (last or margin == 0) else seg.shape[-1] - margin   # :186-188
             n = hi - lo
@@ -207,7 +216,7 @@ class Predictor:
         return out
 
     # -- inner framing + inference + stitch of one segment, mdxnet.py:147-183 -------------------
-    def demix_segment(self, cmix: torch.Tensor) -> torch.Tensor:
+    def demix_segment(self, cmix: torch.Tensor, async_gather: bool = False):
         m = self.model_
         plan = m.plan
         n_sample = cmix.shape[1]
@@ -230,7 +239,7 @@ class Predictor:
             self._run_windows(mix_p, total, seg_out, n_local, w_lo, w_hi, s_lo, n_sample)
         seg_out = seg_out[:, :n_local]
         if self.sharded:
-            seg_out = adist.all_gather_segments(seg_out.contiguous(), n_win, gen, n_sample, self.group)
+            seg_out = adist.all_gather_segments(seg_out.contiguous(), n_win, gen, n_sample, self.group, async_op=async_gather)
         return seg_out
 
     def _run_windows(self, mix_p, total, seg_out, n_local, w_lo, w_hi, s_lo, n_sample) -> None:

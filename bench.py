@@ -112,6 +112,9 @@ def main() -> None:
     preds = [Predictor(pargs, net, ctx=ctx, max_batch=0, sharded=world > 1) for net in nets]
 
     def step():
+        if world > 1:                                       # keep each model's all-gather in flight under the next model
+            pending = [p.demix(mix, defer=True) for p in preds]
+            return [f() for f in pending]
         return [p.demix(mix) for p in preds]
 
     def fence():

@@ -42,6 +42,8 @@ def _worker(rank, world, port, emul_so, out_path):
     pred = Predictor(args, Seam(), ctx=ctx, hop=hop, max_batch=3, sharded=True)
     out = pred.demix(torch.from_numpy(synth_mix(n, seed=300 + n + chunks))).numpy()
     err = float(np.max(np.abs(out - z["small_a_out"])))
+    deferred = pred.demix(torch.from_numpy(synth_mix(n, seed=300 + n + chunks)), defer=True)   # async all-gather path
+    err = max(err, float(np.max(np.abs(deferred().numpy() - z["small_a_out"]))))
     res = torch.tensor([err])
     dist.all_reduce(res, op=dist.ReduceOp.MAX)
     if rank == 0:

@@ -60,3 +60,27 @@ def test_unsupported_geometry_raises(emul):
         StftPlan(emul, 1000, 64, 96, 16)          # no FFT kernel for n_fft=1000
     with pytest.raises(AlsepError):
         StftPlan(emul, 256, 64, 96, 2)            # chunk <= n_fft/2: reflect padding undefined
+
+
+def test_istft_register_ring_hop1024(emul):
+    """hop = 1024 geometries take the register-ring iSTFT kernel: check it (plain and stitched stores)
+    against the oracle, including an arbitrary (non-consistent) spectrogram."""
+    from audiolab_amd import _lib
+    from audiolab_amd.mdx import StftPlan
+    plan = StftPlan(emul, 2048, 1024, 640, 20)
+    g = mo.MDXGeometry(640, 20, 2048, 1024)
+    rng = np.random.default_rng(11)
+    spec = torch.from_numpy(rng.standard_normal((3, 4, 640, 20)).astype(np.float32))
+    want = mo.istft(spec.numpy(), g)
+    nhwc = plan.convert(spec, _lib.LAYOUT_REF)
+    out = emul.empty((3, 2, plan.chunk_size))
+    plan.istft_strided(nhwc, _lib.LAYOUT_NHWC, out, plan.chunk_size, 2 * plan.chunk_size, 0, plan.chunk_size, 5 * plan.chunk_size)
+    assert np.max(np.abs(out.numpy() - want)) < 2e-5 * max(1.0, np.max(np.abs(want)))
+    # stitched: keep [trim, chunk-trim), windows abut every gen samples, output cut at `limit`
+    trim, gen = plan.trim, plan.gen_size
+    limit = 2 * gen + 777
+    st = emul.zeros((2, 3 * gen))
+    plan.istft_strided(nhwc, _lib.LAYOUT_NHWC, st, 3 * gen, gen, trim, plan.chunk_size - trim, limit)
+    ref = want[:, :, trim:-trim].transpose(1, 0, 2).reshape(2, -1)
+    assert np.max(np.abs(st.numpy()[:, :limit] - ref[:, :limit])) < 2e-5 * max(1.0, np.max(np.abs(want)))
+    assert float(st[:, limit:].abs().max()) == 0.0
