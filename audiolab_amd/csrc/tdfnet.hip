@@ -266,8 +266,12 @@ __global__ void __launch_bounds__(kThreads, 2)
 conv3x3_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
                     const float* __restrict__ scale, const float* __restrict__ shift,
                     const bf16_t* __restrict__ zero_page, int Th, int Fw, int Cin, int Cout, int tiles_t,
-                    int tiles_f, int ntiles, int ablate) {
+                    int tiles_f, int ntiles, int ablate, int stagger) {
     typedef ConvB16<TW> Cf;
+    // co-resident workgroups start together and would run their fill / MFMA / store phases in lockstep:
+    // delay every other workgroup by about half a stage so that one fills while the other computes
+    if (stagger > 0 && (blockIdx.x & 1))
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(16);
     bf16_t* patch = reinterpret_cast<bf16_t*>(alsep_smem);
     bf16_t* wts = patch + (size_t)Cf::PGROUPS * 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1554,6 +1558,11 @@ int conv_ablate() {
     return v;
 }
 
+int conv_stagger() {
+    static const int v = [] { const char* e = getenv("ALSEP_CONV_STAGGER"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 template <int TW>
 int launch_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zero_page, int64_t B,
                     int Th, int Fw) {
@@ -1566,7 +1575,7 @@ int launch_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     ProfScope prof(ctx, TW == 64 ? ALSEP_PROF_CONV3X3 : ALSEP_PROF_CONV3X3_SMALL);
     hipLaunchKernelGGL((conv3x3_bf16_kernel<TW>), dim3((unsigned)ntiles, L.cout / Cf::BN), dim3(kThreads), Cf::lds_bytes,
                        ctx->stream, X, Y, (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page,
-                       Th, Fw, L.cin, L.cout, tiles_t, tiles_f, (int)ntiles, conv_ablate());
+                       Th, Fw, L.cin, L.cout, tiles_t, tiles_f, (int)ntiles, conv_ablate(), conv_stagger());
     ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_kernel");
     return ALSEP_OK;
 }
@@ -1583,7 +1592,7 @@ int launch_conv_regw(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t
     const int ny = L.cout / Cf::BN;
     int gx = 256 / ny;                                      // one workgroup per CU over the whole grid
     if (gx > ntiles) gx = (int)ntiles;
-    ProfScope prof(ctx, ALSEP_PROF_CONV3X3);
+    ProfScope prof(ctx, ALSEP_PROF_CONV3X3_REGW);
     hipLaunchKernelGGL((conv3x3_bf16_regw_kernel<NQ>), dim3((unsigned)gx, ny), dim3(kThreads), Cf::lds_bytes, ctx->stream, X, Y,
                        (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
                        L.cout, tiles_t, tiles_f, (int)ntiles, conv_ablate());
@@ -1601,7 +1610,7 @@ int launch_conv_pipe(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t
     ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_pipe_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)Cf::lds_bytes));
     const int gx = ntiles < 256 ? (int)ntiles : 256;        // one persistent workgroup per CU
-    ProfScope prof(ctx, ALSEP_PROF_CONV3X3);
+    ProfScope prof(ctx, ALSEP_PROF_CONV3X3_PIPE);
     hipLaunchKernelGGL((conv3x3_bf16_pipe_kernel<NY>), dim3((unsigned)gx), dim3(kThreads), Cf::lds_bytes, ctx->stream, X, Y,
                        (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
                        L.cout, tiles_t, tiles_f, (int)ntiles);

@@ -35,13 +35,36 @@ PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
-def conv_main_flops_per_chunk(cfg) -> float:
-    """FLOPs of the conv3x3 launches that use the main (TW=64) tile, per chunk-forward."""
+def conv_flops_per_chunk(cfg, levels) -> float:
+    """FLOPs of the 3x3 conv launches of the given U-Net levels, per chunk-forward."""
     total = 0.0
     for i, (c, t, f) in enumerate(cfg.levels()):
-        if f % 64 == 0:
+        if i in levels:
             total += (1 if i == cfg.n else 2) * cfg.l * 2.0 * 9 * c * c * t * f
     return total
+
+
+def conv_kernel_levels(cfg, bf16: bool):
+    """Which levels run which 3x3 kernel (tdfnet.hip run_conv_dma): level 0 (c = 48) -> persistent
+    register-weight kernel; deeper levels with F % 64 == 0 -> conv3x3_bf16_kernel<64>."""
+    lv = cfg.levels()
+    regw = [0] if (bf16 and lv[0][0] == 48 and lv[0][2] % 64 == 0) else []
+    main = [i for i, (c, t, f) in enumerate(lv) if f % 64 == 0 and i not in regw]
+    return main, regw
+
+
+def pmc_traffic(kernel_prefix: str):
+    """HBM bytes per launch of a kernel from the committed PMC summary (profiles/r01_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for 16-byte-per-lane streams on gfx950).  None if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        return d.get(kernel_prefix, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
 
 
 def cpu_baseline(cfg, sd, mix_np, n_windows: int):
@@ -144,9 +167,25 @@ def main() -> None:
     from audiolab_amd.dist import window_range
     w_lo, w_hi = window_range(n_win, world, rank)
     local_windows = (w_hi - w_lo) * N_STEMS * args.steps
-    conv_flops = conv_main_flops_per_chunk(cfg) * local_windows
+    main_levels, regw_levels = conv_kernel_levels(cfg, dtype == torch.bfloat16)
+    conv_flops = conv_flops_per_chunk(cfg, main_levels) * local_windows
     achieved_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+    # the other 3x3 kernel class (level 0), one extra untimed pass
+    other = {}
+    if regw_levels:
+        ctx.profile_begin(_lib.PROF_CONV3X3_REGW)
+        step()
+        fence()
+        ms, launches = ctx.profile_end()
+        fl = conv_flops_per_chunk(cfg, regw_levels) * (w_hi - w_lo) * N_STEMS
+        lv0 = cfg.levels()[0]
+        byts = 2.0 * lv0[0] * lv0[1] * lv0[2] * (2 if dtype == torch.bfloat16 else 4) * 2 * cfg.l * (w_hi - w_lo) * N_STEMS
+        other["conv3x3_bf16_regw_kernel<1>"] = {
+            "bound": "hbm", "achieved": round(byts / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 1),
+            "launches": launches, "avg_us": round(ms * 1e3 / max(launches, 1), 2),
+            "traffic": pmc_traffic("conv3x3_bf16_regw_kernel<1>")}
 
     # per-stage HBM rooflines (outside the timed region): STFT and iSTFT over this rank's windows
     stages = {}
@@ -202,11 +241,13 @@ def main() -> None:
                                    f"{args.seconds} s 44.1 kHz stereo per GPU, margin chunker, windows/launch={args.batch}",
                        "stems": N_STEMS, "audio_seconds": audio_seconds, "sharding": f"windows/{world} + all_gather"},
             "realtime_factor_4stem": round(audio_seconds * args.steps / dt, 2),
-            "roofline": {"kernel": "conv3x3_kernel<bf16,48,48,64>" if dtype == torch.bfloat16 else "conv3x3_kernel<f32,16,48,64>",
+            "roofline": {"kernel": "conv3x3_bf16_kernel<64>" if dtype == torch.bfloat16 else "conv3x3_kernel<f32,16,48,64>",
                          "bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved_tflops / peak, 4), "traffic": None,
+                         "frac": round(achieved_tflops / peak, 4),
+                         "traffic": pmc_traffic("conv3x3_bf16_kernel<64>") if dtype == torch.bfloat16 else None,
                          "launches": conv_launches, "avg_us": round(conv_ms * 1e3 / max(conv_launches, 1), 2),
-                         "flops_per_chunk": conv_main_flops_per_chunk(cfg)},
+                         "flops_per_chunk": conv_flops_per_chunk(cfg, main_levels), "levels": main_levels},
+            "kernels": other,
             "stages": stages,
             "cpu_baseline": cpu,
         }

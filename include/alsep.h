@@ -57,13 +57,15 @@ const char* alsep_last_error(const alsep_ctx* ctx);
  * end synchronises, returns the summed kernel time and launch count, and switches timing off. */
 enum {
     ALSEP_PROF_NONE = 0,
-    ALSEP_PROF_CONV3X3 = 1,      /* conv3x3_kernel, main tile (TW=64) */
+    ALSEP_PROF_CONV3X3 = 1,      /* conv3x3_bf16_kernel<64> / conv3x3_kernel<...,64>: the plain main-tile kernel */
     ALSEP_PROF_CONV3X3_SMALL = 2,/* conv3x3_kernel, TW<64 tiles (deep levels) */
     ALSEP_PROF_TDF = 3,          /* tdf_gemm_kernel */
     ALSEP_PROF_PIX = 4,          /* pix_gemm_kernel (ds / us) */
     ALSEP_PROF_POINTWISE = 5,    /* first / final 1x1 conv */
     ALSEP_PROF_STFT = 6,
-    ALSEP_PROF_ISTFT = 7
+    ALSEP_PROF_ISTFT = 7,
+    ALSEP_PROF_CONV3X3_REGW = 8, /* conv3x3_bf16_regw_kernel (persistent, level 0) */
+    ALSEP_PROF_CONV3X3_PIPE = 9  /* conv3x3_bf16_pipe_kernel (opt-in) */
 };
 int alsep_profile_begin(alsep_ctx* ctx, int category);
 int alsep_profile_end(alsep_ctx* ctx, double* total_ms, int64_t* launches);
