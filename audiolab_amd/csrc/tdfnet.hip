@@ -709,6 +709,170 @@ conv3x3_bf16_pipe_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, c
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 3x3 convolution, levels >= 1 (Cout = 48*NY, NY = 2..4): big-tile persistent kernel.
+// The ablations (profiles/r01_conv_ablation_*) show the plain kernel bounded by what goes through
+// LDS: 81 KB of LDS-DMA per 10.6 MFLOP stage plus 7 fragment reads per 12 MFMAs.  This kernel cuts
+// the bytes instead of trying to hide them:
+//  * 8 waves, 512-pixel tile (8 x 64): one 43 KB weight block now feeds twice the MFMAs and the halo
+//    overhead drops from 1.55x to 1.29x;
+//  * the halo patch of (tile, q) is staged once and all NY output blocks are accumulated against it
+//    (NY*48 accumulator registers) instead of re-staging it per block;
+//  * the next weight block is prefetched into the other slot of a 2-slot ring while the current one is
+//    consumed (counted s_waitcnt vmcnt, raw s_barrier); two waves per SIMD hide the LDS latency.
+// LDS: 63,360 (patch) + 2 * 43,008 (weights) + scale/shift = 149.9 KiB, one workgroup per CU.
+// ------------------------------------------------------------------------------------------
+constexpr int kBigThreads = 512;
+template <int NY>
+struct ConvBig {
+    static constexpr int TW = 64, TH = 8, KC = 48, BN = 48, CG = 6, NG = 54, NS = 14, WGRP = 56;
+    static constexpr int PW = TW + 2, PH = TH + 2;
+    static constexpr int PGROUPS = PH * PW * CG;            // 3960
+    static constexpr int WGROUPS = BN * WGRP;               // 2688
+    static constexpr int PINST = (PGROUPS + 63) / 64;       // 62
+    static constexpr int WINST = WGROUPS / 64;              // 42: waves 0,1 issue 6, waves 2..7 issue 5
+    static constexpr size_t ring_bytes = 16 * (size_t)(PGROUPS + 2 * WGROUPS);
+    static constexpr size_t lds_bytes = ring_bytes + 2 * NY * BN * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "ConvBig: LDS budget");
+};
+
+template <int NY>
+__global__ void __launch_bounds__(kBigThreads, 2)
+conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
+                        const float* __restrict__ scale, const float* __restrict__ shift,
+                        const bf16_t* __restrict__ zero_page, int Th, int Fw, int Cin, int Cout, int tiles_t,
+                        int tiles_f, int ntiles) {
+    typedef ConvBig<NY> Cf;
+    bf16_t* patch = reinterpret_cast<bf16_t*>(alsep_smem);
+    bf16_t* wring = patch + (size_t)Cf::PGROUPS * 8;
+    float* ss = reinterpret_cast<float*>(alsep_smem + Cf::ring_bytes);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int nq = Cin / Cf::KC;
+    const int wswz = l15 >> 1;
+    for (int i = tid; i < NY * Cf::BN; i += kBigThreads) {
+        ss[i] = scale[i];
+        ss[NY * Cf::BN + i] = shift[i];
+    }
+    __syncthreads();
+
+    int pbase[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) pbase[ni] = (wave * Cf::PW + ni * 16 + l15) * Cf::KC;
+    auto koff_of = [&](int s) {
+        const int grp = 4 * s + lq;
+        const int gc = grp < Cf::NG ? grp : Cf::NG - 1;
+        const int tap = gc / Cf::CG, cg = gc % Cf::CG;
+        return ((tap / 3) * Cf::PW + (tap % 3)) * Cf::KC + cg * 8;
+    };
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nstage = my_tiles * NY * nq;
+
+    auto tile_coords = [&](int k, int& t0, int& f0, int64_t& b) {
+        int tile = (int)blockIdx.x + k * (int)gridDim.x;
+        const int tf = tile % tiles_f;  tile /= tiles_f;
+        const int tt = tile % tiles_t;
+        b = tile / tiles_t;
+        t0 = tt * Cf::TH;
+        f0 = tf * Cf::TW;
+    };
+    auto issue_patch = [&](int ps) {                         // (tile ps / nq, chunk ps % nq); waited with vmcnt(0)
+        int t0, f0; int64_t b;
+        tile_coords(ps / nq, t0, f0, b);
+        const bf16_t* xb = X + b * (int64_t)Th * Fw * Cin + (ps % nq) * Cf::KC;
+#pragma unroll
+        for (int j = 0; j < (Cf::PINST + 7) / 8; ++j) {
+            const int i = wave + 8 * j;
+            if (i < Cf::PINST) {
+                const int gidx = i * 64 + lane;
+                if (gidx < Cf::PGROUPS) {
+                    const int pix = gidx / Cf::CG, g = gidx % Cf::CG;
+                    const int t = t0 - 1 + pix / Cf::PW, f = f0 - 1 + pix % Cf::PW;
+                    const bool inb = t >= 0 && t < Th && f >= 0 && f < Fw;
+                    const bf16_t* src = inb ? xb + ((int64_t)t * Fw + f) * Cin + g * 8 : zero_page;
+                    glds16(src, patch + (size_t)i * 64 * 8);
+                }
+            }
+        }
+    };
+    auto issue_weights = [&](int s) {                        // stage s -> slot s & 1
+        const int ny = s % NY, q = (s / NY) % nq;
+        const bf16_t* wsrc = Wp + ((int64_t)ny * nq + q) * (Cf::WGROUPS * 8);
+        bf16_t* dst = wring + (size_t)(s & 1) * Cf::WGROUPS * 8;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int i = wave + 8 * j;
+            if (i < Cf::WINST) glds16(wsrc + ((size_t)i * 64 + lane) * 8, dst + (size_t)i * 64 * 8);
+        }
+    };
+
+    f32x4 acc[NY][3][4];
+    for (int s = 0; s < nstage; ++s) {
+        const int ny = s % NY, ps = s / NY, q = ps % nq;
+        const bool last = s + 1 >= nstage;
+        if (ny == 0) {                                       // new patch: every older DMA / store is drained here
+            issue_patch(ps);
+            if (s == 0) issue_weights(0);
+            wait_vmcnt<0>();
+            barrier_nodrain();
+        }
+        if (!last) issue_weights(s + 1);
+        if (ny > 0) {                                        // weights(s) were prefetched one stage ago; only the
+            if (last) wait_vmcnt<0>();                       // prefetch just issued is younger (6 / 5 per wave)
+            else if (wave < 2) wait_vmcnt<6>();
+            else wait_vmcnt<5>();
+            barrier_nodrain();
+        }
+        {
+            const bf16_t* wts = wring + (size_t)(s & 1) * Cf::WGROUPS * 8;
+#pragma unroll
+            for (int yy = 0; yy < NY; ++yy) {
+                if (yy == ny) {
+                    if (q == 0) {
+#pragma unroll
+                        for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni) acc[yy][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll 2
+                    for (int st = 0; st < Cf::NS; ++st) {
+                        const int ko = koff_of(st);
+                        bf16x8 xf[4], wf[3];
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) xf[ni] = lds_frag<bf16_t>(patch + pbase[ni] + ko);
+#pragma unroll
+                        for (int mi = 0; mi < 3; ++mi) wf[mi] = lds_frag<bf16_t>(wts + ((mi * 16 + l15) * Cf::WGRP + ((4 * st + lq) ^ wswz)) * 8);
+#pragma unroll
+                        for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni) mma_step(acc[yy][mi][ni], wf[mi], xf[ni]);
+                    }
+                }
+            }
+        }
+        barrier_nodrain();                                   // slot s&1 (and the patch, when ny == NY-1) may be refilled
+        if (ny == NY - 1 && q == nq - 1) {
+            int t0, f0; int64_t b;
+            tile_coords(ps / nq, t0, f0, b);
+            bf16_t* yb = Y + ((b * Th + t0 + wave) * (int64_t)Fw + f0) * Cout;
+#pragma unroll
+            for (int yy = 0; yy < NY; ++yy)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 3; ++mi) {
+                        const int co = yy * Cf::BN + mi * 16 + 4 * lq;
+                        const f32x4 scv = *reinterpret_cast<const f32x4*>(ss + co);      // ext-vector load: see regw kernel
+                        const f32x4 shv = *reinterpret_cast<const f32x4*>(ss + NY * Cf::BN + co);
+                        float y[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[yy][mi][ni][r], scv[r], shv[r]), 0.f);
+                        store4(yb + (int64_t)(ni * 16 + l15) * Cout + co, y);
+                    }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // generic tile GEMM: 64 weight rows x 128 activation columns per workgroup, BK = 8 k-groups.
 // ------------------------------------------------------------------------------------------
 template <typename T>
@@ -1618,6 +1782,29 @@ int launch_conv_pipe(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t
     return ALSEP_OK;
 }
 
+template <int NY>
+int launch_conv_big(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zero_page, int64_t B,
+                    int Th, int Fw) {
+    typedef ConvBig<NY> Cf;
+    const int tiles_t = Th / Cf::TH, tiles_f = Fw / Cf::TW;
+    const int64_t ntiles = B * tiles_t * tiles_f;
+    if (ntiles > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "conv3x3: too many tiles");
+    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_big_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)Cf::lds_bytes));
+    const int gx = ntiles < 256 ? (int)ntiles : 256;
+    ProfScope prof(ctx, ALSEP_PROF_CONV3X3_PIPE);
+    hipLaunchKernelGGL((conv3x3_bf16_big_kernel<NY>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                       (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
+                       L.cout, tiles_t, tiles_f, (int)ntiles);
+    ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_big_kernel");
+    return ALSEP_OK;
+}
+
+int conv_big_enabled() {
+    static const int v = [] { const char* e = getenv("ALSEP_CONV_BIG"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 int conv_pipe_enabled() {
     // opt-in: bit-identical to the plain kernel but not faster on MI355X (profiles/r01_conv_variants.txt):
     // the per-CU LDS-DMA intake, not the missing overlap, bounds these levels
@@ -1634,6 +1821,13 @@ int run_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y,
     if (conv_regw_enabled() && Th % 4 == 0 && Fw % 64 == 0 && L.cin == L.cout) {
         if (L.cin == 48) return launch_conv_regw<1>(ctx, L, X, Y, zp, B, Th, Fw);
         if (L.cin == 96 && conv_regw_enabled() >= 2) return launch_conv_regw<2>(ctx, L, X, Y, zp, B, Th, Fw);
+    }
+    if (conv_big_enabled() && Th % 8 == 0 && Fw % 64 == 0 && L.cin == L.cout &&
+        (conv_big_enabled() >= 2 || B * (Th / 8) * (Fw / 64) >= 96)) {       // =2: no minimum tile count (tests)
+        switch (L.cout / 48) {
+            case 2: return launch_conv_big<2>(ctx, L, X, Y, zp, B, Th, Fw);
+            default: break;                                  // NY = 3, 4 spill at 2 waves/SIMD with ROCm 7.2
+        }
     }
     if (conv_pipe_enabled() && Th % 4 == 0 && Fw % 64 == 0 && L.cin == L.cout &&
         (conv_pipe_enabled() >= 2 || B * (Th / 4) * (Fw / 64) >= 128)) {   // =2: no minimum tile count (tests)

@@ -1,0 +1,9 @@
+#!/bin/bash
+# TEST-ONLY: AddressSanitizer pass over the emulated kernels (about 10 minutes on 8 cores).
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+CXX="${ALSEP_HOST_CXX:-/opt/rocm/lib/llvm/bin/clang++}"
+"$HERE/build_emul.sh" asan > /dev/null
+RT="$($CXX -print-file-name=libclang_rt.asan-x86_64.so)"
+cd /tmp
+ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 LD_PRELOAD="$RT" python "$HERE/asan_cases.py"

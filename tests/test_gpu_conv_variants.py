@@ -31,16 +31,16 @@ np.save(sys.argv[1], np.stack(outs))
 
 
 def run_mode(mode, path):
-    regw, pipe = mode
-    env = dict(os.environ, ALSEP_CONV_REGW=str(regw), ALSEP_CONV_PIPE=str(pipe))
+    regw, pipe, big = mode
+    env = dict(os.environ, ALSEP_CONV_REGW=str(regw), ALSEP_CONV_PIPE=str(pipe), ALSEP_CONV_BIG=str(big))
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}, path], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     return np.load(path)
 
 
 def test_persistent_conv_bit_identical(tmp_path):
-    base = run_mode((0, 0), str(tmp_path / "m0.npy"))        # plain LDS-DMA kernel everywhere
+    base = run_mode((0, 0, 0), str(tmp_path / "m0.npy"))     # plain LDS-DMA kernel everywhere
     assert np.isfinite(base).all() and np.abs(base).max() > 1e-3
-    for mode in ((1, 0), (2, 0), (0, 1), (1, 1)):            # persistent register-weight / pipelined variants
-        got = run_mode(mode, str(tmp_path / f"m{mode[0]}{mode[1]}.npy"))
-        assert np.array_equal(base, got), f"REGW,PIPE={mode}: max diff {np.abs(base - got).max()}"
+    for mode in ((1, 0, 0), (2, 0, 0), (0, 1, 0), (1, 1, 0), (1, 0, 1), (0, 0, 2)):   # register-weight / pipelined / big-tile
+        got = run_mode(mode, str(tmp_path / ("m%d%d%d.npy" % mode)))
+        assert np.array_equal(base, got), f"REGW,PIPE,BIG={mode}: max diff {np.abs(base - got).max()}"
