@@ -17,9 +17,58 @@ __device__ __forceinline__ bf16x4 lds_read_tr16_b64(const bf16_t* lds_ptr) {
     return v;
 }
 
+// Same read at lds_ptr + OFF bytes, OFF in the instruction's 16-bit immediate: one address VGPR serves a whole
+// tile (as a separate "v" operand every constant offset becomes its own loop-invariant register).
+template <int OFF>
+__device__ __forceinline__ bf16x4 lds_read_tr16_b64_off(const bf16_t* lds_ptr) {
+    static_assert(OFF >= 0 && OFF < 65536 && OFF % 8 == 0, "ds offset field");
+    bf16x4 v;
+    const unsigned addr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)lds_ptr;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
 // Wait for every outstanding LDS read of this wave (the asm reads above are invisible to hipcc's own
 // lgkmcnt bookkeeping) and pin the instruction order around the wait.
 __device__ __forceinline__ void lds_read_tr16_wait() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+}
+
+// Counted form: wait until at most N of this wave's LDS reads are outstanding (they complete in order).
+template <int N>
+__device__ __forceinline__ void lds_read_tr16_wait_n() {
+    static_assert(N >= 0 && N < 16, "lgkmcnt is a 4-bit counter");
+    __builtin_amdgcn_s_waitcnt((63 & 15) | ((63 >> 4) << 14) | (7 << 4) | (N << 8));
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// A wave-uniform pointer the optimiser must treat as a fresh scalar (SGPR pair) here: keeps loop strength
+// reduction from turning "scalar base + 32-bit lane offset" addresses of an unrolled loop into one 64-bit VGPR
+// induction pointer per access (which then spill).
+template <typename T>
+__device__ __forceinline__ const T* opaque_uniform_ptr(const T* p) {
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("" : "+s"(v));
+    return (const T*)v;
+}
+
+// Asynchronous 16-byte global load into a register fragment, invisible to hipcc's waitcnt bookkeeping:
+//   dst <- *(sbase + voff + OFF)      (sbase wave-uniform SGPR pair, voff a 32-bit lane offset, 0 <= OFF < 4096)
+// A compiler-tracked load issued between LDS-DMAs inside a software-pipelined loop is waited for with
+// s_waitcnt vmcnt(0) at its first use (ROCm 7.2's SIInsertWaitcnts loses the count across the loop's merges),
+// which drains the whole prefetch ring every tile.  As asm the wait is ours: dst must not be read before a
+// counted s_waitcnt vmcnt that covers it (wait_vmcnt<N>() in mma.h).  The compiler does not know dst is in
+// flight, so it must have no reason to touch it in between (copy, spill): scripts/check_async_regs.py checks the
+// generated code for exactly that.
+template <int OFF>
+__device__ __forceinline__ void global_load_async_bf16x8(bf16x8& dst, const void* sbase, unsigned voff) {
+    static_assert(OFF >= 0 && OFF < 4096, "13-bit signed global offset field");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+
+// Extends the live range of a register value to this point (no code).
+template <typename T>
+__device__ __forceinline__ void keep_vgprs_live(const T& v) {
+    asm volatile("" ::"v"(v));
 }

@@ -1257,6 +1257,217 @@ tdf_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 TDF linear, wide-tile path (C multiple of 48, M multiple of 192): same math and k order as
+// tdf_bf16_kernel, different traffic.  Workgroup tile: 48*WM weight rows x 4 column units; wave w owns
+// weight rows [48w, 48w+48) of the tile and ALL four units (acc 4 x 3 x 3 fragments = 144 VGPRs).
+//   * the weight tile never goes through LDS: every wave needs a different 48-row slice, so it loads its
+//     fragments straight from the fragment-order image (make_tdf_frag_weights: 3 KiB contiguous per
+//     wave and 32-wide k-step) into registers one K tile ahead -- LDS-DMA traffic per flop drops 2.5x
+//     against the 128-row kernel and the L2 -> CU traffic by a third;
+//   * only activations are staged: [4 units][64 f][48 c] = 24 KiB per K tile, three-stage ring, the
+//     LDS-DMA of tile it+2 issued while tile it is consumed (one raw barrier per tile, counted vmcnt;
+//     issue order W(it+1), X(it+2) so that waiting for W(it) never waits for the youngest X tile);
+//   * WM = 4: 256 threads, 72 KiB -> 2 workgroups per CU, one in its epilogue while the other computes
+//     (second linear: output + residual traffic dominates); WM = 8: 512 threads, 384 rows -- the whole
+//     first linear of level 0 in one row block, so X is read from HBM exactly once.
+// ------------------------------------------------------------------------------------------
+template <int WM>
+struct TdfWide {
+    static constexpr int TR = 48, BM = TR * WM, UN = 4, UC = 48, BK = 64, NST = 3;
+    static constexpr int THREADS = 64 * WM;
+    static constexpr int UNIT_ELEMS = BK * UC;                       // 3072 bf16 = 6 KiB
+    static constexpr int STAGE_ELEMS = UN * UNIT_ELEMS;              // 24 KiB
+    static constexpr int PIECES = STAGE_ELEMS / 8 / 64;              // 24 wave-instructions of 1 KiB per stage
+    static constexpr int GLDS = PIECES / WM;                         // per wave and tile: 6 (WM = 4) / 3 (WM = 8)
+    static constexpr int WLOADS = 6;                                 // weight fragments per wave and tile
+    static constexpr size_t ring_bytes = (size_t)NST * STAGE_ELEMS * sizeof(bf16_t);
+    static constexpr size_t stage_bytes = (size_t)WM * TR * UC * sizeof(float);    // epilogue: one unit per wave, fp32
+    static constexpr size_t lds_bytes = ring_bytes > stage_bytes ? ring_bytes : stage_bytes;
+    static_assert(PIECES % WM == 0 && 6 % GLDS == 0, "a wave's LDS-DMA pieces stay inside one unit");
+};
+
+// A-operand fragments of one unit and k-step: byte offset OFF from the lane's base inside the stage
+template <int OFF>
+__device__ __forceinline__ bf16x8 tdfw_read_frag(const bf16_t* base) {
+    const bf16x4 lo = lds_read_tr16_b64_off<OFF>(base);
+    const bf16x4 hi = lds_read_tr16_b64_off<OFF + 16 * 48 * 2>(base);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <int KS, int U>
+__device__ __forceinline__ void tdfw_read_x(bf16x8 (&xf)[3], const bf16_t* base) {
+    constexpr int OFF = (U * 64 * 48 + KS * 32 * 48) * 2;
+    xf[0] = tdfw_read_frag<OFF>(base);
+    xf[1] = tdfw_read_frag<OFF + 32>(base);
+    xf[2] = tdfw_read_frag<OFF + 64>(base);
+}
+
+template <int WM, bool RESIDUAL>
+__global__ void __launch_bounds__(64 * WM, 2)
+tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wf,
+                     const float* __restrict__ bias, const float* __restrict__ scale, const float* __restrict__ shift,
+                     const bf16_t* __restrict__ R, int M, int K, int64_t nunits, int C) {
+    typedef TdfWide<WM> Tc;
+    bf16_t* ring = reinterpret_cast<bf16_t*>(alsep_smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: row block, DMA duty and their bases live in SGPRs
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int rowblk = blockIdx.y * WM + wave;                       // 48-row block of the weight matrix
+    const int upc = C / Tc::UC;
+    const int64_t u0 = (int64_t)blockIdx.x * Tc::UN;
+    const int ntile = K / Tc::BK;
+    if (ntile <= 0) return;                                          // (the launcher never does this; removes the zero-trip path)
+
+    // LDS-DMA duty of this wave: GLDS consecutive 1-KiB pieces of one unit's [64 f][48 c] tile.  The launcher
+    // guarantees K % 64 == 0 and nunits % 4 == 0, so there is no padding select.  Three pieces are exactly 32
+    // rows of 96 bytes: piece p reads (p / 3) * 32 rows below piece p % 3, so three 32-bit lane offsets and a
+    // scalar base (SGPR pair, advanced per tile) address everything -- nothing here is worth a 64-bit VGPR.
+    const int du = (wave * Tc::GLDS) / 6, dp0 = (wave * Tc::GLDS) % 6;
+    const int64_t dU = u0 + du;
+    const char* xu = reinterpret_cast<const char*>(X + ((dU / upc) * K) * (int64_t)C + (int)(dU % upc) * Tc::UC) +
+                     (size_t)(dp0 / 3) * 32 * C * sizeof(bf16_t);
+    unsigned xoff[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int within = j * 64 + lane;
+        xoff[j] = (unsigned)(((within / 6) * C + (within % 6) * 8) * (int)sizeof(bf16_t));
+    }
+    auto issue_x = [&](int it, int stage) {
+        bf16_t* dst = ring + (size_t)stage * Tc::STAGE_ELEMS + (size_t)du * Tc::UNIT_ELEMS + (size_t)dp0 * 64 * 8;
+        const char* xk = opaque_uniform_ptr(xu + (size_t)it * (Tc::BK * sizeof(bf16_t)) * C);
+#pragma unroll
+        for (int j = 0; j < Tc::GLDS; ++j)
+            glds16(xk + (size_t)(j / 3) * 32 * C * sizeof(bf16_t) + xoff[j % 3], dst + (size_t)j * 64 * 8);
+    };
+    const char* wrow = reinterpret_cast<const char*>(Wf) + (size_t)rowblk * ntile * (Tc::WLOADS * 1024);
+    const unsigned woff = (unsigned)lane * 16u;
+    bf16x8 wf[2][2][3];                                              // [tile parity][k-step][m-tile]
+    auto issue_w = [&](int it, int par) {
+        const char* wp = opaque_uniform_ptr(wrow + (size_t)it * (Tc::WLOADS * 1024));
+        const char* wq = wp + 4096;
+        global_load_async_bf16x8<0>(wf[par][0][0], wp, woff);
+        global_load_async_bf16x8<1024>(wf[par][0][1], wp, woff);
+        global_load_async_bf16x8<2048>(wf[par][0][2], wp, woff);
+        global_load_async_bf16x8<3072>(wf[par][1][0], wp, woff);
+        global_load_async_bf16x8<0>(wf[par][1][1], wq, woff);
+        global_load_async_bf16x8<1024>(wf[par][1][2], wq, woff);
+    };
+
+    f32x4 acc[Tc::UN][3][3];
+#pragma unroll
+    for (int u = 0; u < Tc::UN; ++u)
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 3; ++mi) acc[u][ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int trow = l15 >> 2, tcol = (l15 & 3) * 4;
+    const bf16_t* xlane = ring + (4 * lq + trow) * Tc::UC + tcol;
+    auto mma_unit = [&](int u, const bf16x8 (&xf)[3], int par, int ks) {
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 3; ++mi) mma_step(acc[u][ni][mi], xf[ni], wf[par][ks][mi]);
+    };
+    // tile it sits in stage S_ (= it % 3), its weights in wf[P_] (P_ = it % 2); all indices compile-time
+#define ALSEP_TDFW_STEP(it_, S_, P_)                                                              \
+    do {                                                                                          \
+        wait_vmcnt<Tc::GLDS>();            /* all but X(it+1): W(it) and X(it) have landed */     \
+        if ((it_) + 1 >= ntile) wait_vmcnt<0>();         /* last tile: nothing was issued behind */ \
+        barrier_nodrain();                 /* every wave's part of X(it); compute(it-1) finished */ \
+        if ((it_) + 1 < ntile) issue_w((it_) + 1, 1 - (P_));                                      \
+        if ((it_) + 2 < ntile) issue_x((it_) + 2, ((S_) + 2) % 3);                                \
+        const bf16_t* xs_ = xlane + (size_t)(S_) * Tc::STAGE_ELEMS;                               \
+        bf16x8 xa[3], xb[3];                                                                      \
+        tdfw_read_x<0, 0>(xa, xs_);                                                               \
+        tdfw_read_x<0, 1>(xb, xs_);                                                               \
+        lds_read_tr16_wait_n<6>();  mma_unit(0, xa, P_, 0);                                       \
+        tdfw_read_x<0, 2>(xa, xs_);                                                               \
+        lds_read_tr16_wait_n<6>();  mma_unit(1, xb, P_, 0);                                       \
+        tdfw_read_x<0, 3>(xb, xs_);                                                               \
+        lds_read_tr16_wait_n<6>();  mma_unit(2, xa, P_, 0);                                       \
+        tdfw_read_x<1, 0>(xa, xs_);                                                               \
+        lds_read_tr16_wait_n<6>();  mma_unit(3, xb, P_, 0);                                       \
+        tdfw_read_x<1, 1>(xb, xs_);                                                               \
+        lds_read_tr16_wait_n<6>();  mma_unit(0, xa, P_, 1);                                       \
+        tdfw_read_x<1, 2>(xa, xs_);                                                               \
+        lds_read_tr16_wait_n<6>();  mma_unit(1, xb, P_, 1);                                       \
+        tdfw_read_x<1, 3>(xb, xs_);                                                               \
+        lds_read_tr16_wait_n<6>();  mma_unit(2, xa, P_, 1);                                       \
+        lds_read_tr16_wait_n<0>();  mma_unit(3, xb, P_, 1);                                       \
+    } while (0)
+    issue_x(0, 0);
+    issue_w(0, 0);
+    if (1 < ntile) issue_x(1, 1);
+    for (int it = 0; it < ntile; it += 6) {
+        ALSEP_TDFW_STEP(it, 0, 0);
+        if (it + 1 < ntile) ALSEP_TDFW_STEP(it + 1, 1, 1);
+        if (it + 2 < ntile) ALSEP_TDFW_STEP(it + 2, 2, 0);
+        if (it + 3 < ntile) ALSEP_TDFW_STEP(it + 3, 0, 1);
+        if (it + 4 < ntile) ALSEP_TDFW_STEP(it + 4, 1, 0);
+        if (it + 5 < ntile) ALSEP_TDFW_STEP(it + 5, 2, 1);
+    }
+#undef ALSEP_TDFW_STEP
+    wait_vmcnt<0>();                                     // already true; states it on every path for check_async_regs.py
+    // keep the fragment registers live up to here: the epilogue's first values must not be allocated to (and
+    // scheduled above the wait into) registers that, as far as the control-flow graph can tell, may be in flight
+#pragma unroll
+    for (int i = 0; i < 12; ++i) keep_vgprs_live(wf[i / 6][(i / 3) % 2][i % 3]);
+    barrier_nodrain();                                   // the ring is free: every wave is past its last read
+
+    // Epilogue, one unit at a time through this wave's private 9 KiB of LDS (fp32 [48 f'][48 c]): the
+    // accumulator fragment of a lane is 4 channels of one f' row; re-laid out it leaves as whole
+    // 96-byte rows (16-byte residual loads and stores).  Arithmetic as in tdf_bf16_kernel: bias, BN,
+    // ReLU and the residual add in fp32, one rounding to bf16.
+    float* stg = reinterpret_cast<float*>(alsep_smem) + (size_t)wave * (Tc::TR * Tc::UC);
+    float bvv[3];
+#pragma unroll
+    for (int mi = 0; mi < 3; ++mi) bvv[mi] = bias ? bias[rowblk * Tc::TR + mi * 16 + l15] : 0.f;
+#pragma unroll
+    for (int u = 0; u < Tc::UN; ++u) {
+        const int64_t U = u0 + u;
+        const int64_t bt = U / upc;
+        const int cb = (int)(U % upc) * Tc::UC;
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + cb + ni * 16 + 4 * lq);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + cb + ni * 16 + 4 * lq);
+#pragma unroll
+            for (int mi = 0; mi < 3; ++mi) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(acc[u][ni][mi][r] + bvv[mi], sc[r], sh[r]), 0.f);
+                *reinterpret_cast<f32x4*>(stg + (mi * 16 + l15) * Tc::UC + ni * 16 + 4 * lq) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // 48 rows x 6 groups of 8 channels = 288 16-byte output groups
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int gidx = it * 64 + lane;
+            const int fr = gidx / 6, cg = gidx % 6;
+            if (gidx < Tc::TR * 6) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + fr * Tc::UC + cg * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + fr * Tc::UC + cg * 8 + 4);
+                {
+                    const int64_t o = (bt * M + rowblk * Tc::TR + fr) * (int64_t)C + cb + cg * 8;
+                    float y[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (RESIDUAL) {
+                        const bf16x8 xr = *reinterpret_cast<const bf16x8*>(R + o);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) y[e] += (float)xr[e];
+                    }
+                    bf16x8 q;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) q[e] = (bf16_t)y[e];
+                    *reinterpret_cast<bf16x8*>(Y + o) = q;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // bf16 ds (2x2/2 conv, 48 -> 96) and us (2x2 transposed conv, 96 -> 48, * skip) between levels 0 and 1,
 // the two largest resampling layers.  Every input element feeds exactly one output pixel (no halo,
 // no reuse), so nothing is staged: a wave keeps its weight fragments in registers for its whole
@@ -1415,6 +1626,7 @@ struct GemmLayer {       // ds / us / tdf
     bool has_bias = false;
     bool dma_path = false;   // packed for tdf_bf16_kernel
     DevBuf wfrag;            // [m-tile][k-step][lane][8] for the streaming ds/us kernels (bf16, level 0 <-> 1 only)
+    DevBuf wwide;            // fragment-order image for tdf_bf16_wide_kernel (bf16, M % 192 == 0)
 };
 struct Block {
     std::vector<ConvLayer> tfc;
@@ -1577,6 +1789,27 @@ int make_tdf_dma_weights(alsep_net* net, const std::vector<float>& wmk, int M, i
     return upload(net, pk.data(), pk.size() * sizeof(bf16_t), &L->w);
 }
 
+// fragment-order image for tdf_bf16_wide_kernel: [M/48][Kp/64][k-step 2][m-tile 3][lane 64][8]; lane (l15, lq) of
+// (m-tile mi, k-step ks) holds W[48 rb + 16 mi + l15][64 kt + 32 ks + {4lq..4lq+3, 16+4lq..16+4lq+3}] -- the same
+// k order as the LDS image above, so both kernels sum in the same order.
+int make_tdf_wide_weights(alsep_net* net, const std::vector<float>& wmk, int M, int K, GemmLayer* L) {
+    const int KT = (int)ceil_div64(K, 64);
+    std::vector<bf16_t> pk((size_t)(M / 48) * KT * 6 * 512, host_cast<bf16_t>(0.f));
+    for (int rb = 0; rb < M / 48; ++rb)
+        for (int kt = 0; kt < KT; ++kt)
+            for (int ks = 0; ks < 2; ++ks)
+                for (int mi = 0; mi < 3; ++mi)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 8; ++e) {
+                            const int lq = l >> 4, m = rb * 48 + mi * 16 + (l & 15);
+                            const int k = kt * 64 + ks * 32 + (e < 4 ? 4 * lq + e : 16 + 4 * lq + (e - 4));
+                            if (k < K)
+                                pk[((((size_t)rb * KT + kt) * 2 + ks) * 3 + mi) * 512 + l * 8 + e] =
+                                    host_cast<bf16_t>(wmk[(size_t)m * K + k]);
+                        }
+    return upload(net, pk.data(), pk.size() * sizeof(bf16_t), &L->wwide);
+}
+
 // fragment-order image of a [M][K] matrix for register-resident A operands: lane l of (m-tile, k-step) holds
 // W[16*mt + (l & 15)][32*ks + 8*(l >> 4) + e], e < 8 (zero beyond M / K)
 int make_frag_weights(alsep_net* net, const std::vector<float>& wmk, int M, int K, DevBuf* out) {
@@ -1614,6 +1847,7 @@ int make_block(alsep_net* net, const TensorMap& tm, const std::string& p, int c,
         int rc = (is_bf16<T>() && c % 48 == 0) ? make_tdf_dma_weights(net, *w, fo, fi, L)
                                                : make_gemm_weights<T>(net, *w, fo, fi, L);
         if (rc) return rc;
+        if (L->dma_path && fo % 192 == 0 && (rc = make_tdf_wide_weights(net, *w, fo, fi, L))) return rc;
         if ((rc = upload(net, sc->data(), c * sizeof(float), &L->scale))) return rc;
         if ((rc = upload(net, sh->data(), c * sizeof(float), &L->shift))) return rc;
         auto bi = find(tm, q + ".bias", fo, net->ctx, false);
@@ -1792,7 +2026,7 @@ int launch_conv_big(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_big_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)Cf::lds_bytes));
     const int gx = ntiles < 256 ? (int)ntiles : 256;
-    ProfScope prof(ctx, ALSEP_PROF_CONV3X3_PIPE);
+    ProfScope prof(ctx, ALSEP_PROF_CONV3X3_BIG);
     hipLaunchKernelGGL((conv3x3_bf16_big_kernel<NY>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
                        (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
                        L.cout, tiles_t, tiles_f, (int)ntiles);
@@ -1892,10 +2126,47 @@ int run_pix(alsep_ctx* ctx, const GemmLayer& L, const T* X, T* Y, const T* skip,
     return ALSEP_OK;
 }
 
+// ALSEP_TDF_WIDE: 0 = 128-row kernel only; 1 (default) = wide kernel where M % 192 == 0, 384 rows per workgroup for a
+// first linear whose whole M is 384; 4 / 8 = force 192 / 384 rows wherever M allows (experiments, tests)
+int tdf_wide_mode() {
+    static const int v = [] { const char* e = getenv("ALSEP_TDF_WIDE"); return e ? atoi(e) : 1; }();
+    return v;
+}
+template <int WM>
+int launch_tdf_wide(alsep_ctx* ctx, const GemmLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* R, int64_t nunits, int C) {
+    typedef TdfWide<WM> Tc;
+    const int64_t gx = ceil_div64(nunits, Tc::UN);
+    if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "tdf: too many column tiles");
+    const float* bias = L.has_bias ? (const float*)L.bias.p : nullptr;
+    const dim3 grid((unsigned)gx, L.M / Tc::BM);
+    ProfScope prof(ctx, ALSEP_PROF_TDF);
+    if (R) {
+        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)tdf_bf16_wide_kernel<WM, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Tc::lds_bytes));
+        hipLaunchKernelGGL((tdf_bf16_wide_kernel<WM, true>), grid, dim3(Tc::THREADS), Tc::lds_bytes, ctx->stream, X, Y,
+                           (const bf16_t*)L.wwide.p, bias, (const float*)L.scale.p, (const float*)L.shift.p, R, L.M, L.K,
+                           nunits, C);
+    } else {
+        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)tdf_bf16_wide_kernel<WM, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Tc::lds_bytes));
+        hipLaunchKernelGGL((tdf_bf16_wide_kernel<WM, false>), grid, dim3(Tc::THREADS), Tc::lds_bytes, ctx->stream, X, Y,
+                           (const bf16_t*)L.wwide.p, bias, (const float*)L.scale.p, (const float*)L.shift.p, R, L.M, L.K,
+                           nunits, C);
+    }
+    ALSEP_LAUNCH_CHECK(ctx, "tdf_bf16_wide_kernel");
+    return ALSEP_OK;
+}
+
 int run_tdf_dma(alsep_ctx* ctx, const GemmLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* R, const bf16_t* zp,
                 int64_t BT, int C) {
     typedef TdfB16 Tc;
     const int64_t nunits = BT * (C / Tc::UC);
+    if (L.wwide.p && tdf_wide_mode() && L.K % 64 == 0 && nunits % 4 == 0) {
+        const int mode = tdf_wide_mode();
+        const bool can8 = L.M % 384 == 0;
+        const bool use8 = mode == 8 ? can8 : (mode == 4 ? false : (can8 && L.M == 384 && !R));
+        return use8 ? launch_tdf_wide<8>(ctx, L, X, Y, R, nunits, C) : launch_tdf_wide<4>(ctx, L, X, Y, R, nunits, C);
+    }
     const int64_t gx = ceil_div64(nunits, Tc::UN);
     if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "tdf: too many column tiles");
     const float* bias = L.has_bias ? (const float*)L.bias.p : nullptr;

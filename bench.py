@@ -44,13 +44,24 @@ def conv_flops_per_chunk(cfg, levels) -> float:
     return total
 
 
-def conv_kernel_levels(cfg, bf16: bool):
-    """Which levels run which 3x3 kernel (tdfnet.hip run_conv_dma): level 0 (c = 48) -> persistent
-    register-weight kernel; deeper levels with F % 64 == 0 -> conv3x3_bf16_kernel<64>."""
+def conv_kernel_levels(cfg, bf16: bool, batch: int):
+    """Which U-Net levels run which 3x3 kernel -- mirrors run_conv_dma() in tdfnet.hip:
+    level 0 (c = 48) -> persistent register-weight kernel; c = 96 with T % 8 == 0 and >= 96 8x64 tiles -> the
+    8-wave big-tile kernel; the other levels with F % 64 == 0 -> conv3x3_bf16_kernel<64>.
+    Returns {class: [levels]} with classes "regw", "big", "plain"."""
     lv = cfg.levels()
-    regw = [0] if (bf16 and lv[0][0] == 48 and lv[0][2] % 64 == 0) else []
-    main = [i for i, (c, t, f) in enumerate(lv) if f % 64 == 0 and i not in regw]
-    return main, regw
+    out = {"regw": [], "big": [], "plain": []}
+    for i, (c, t, f) in enumerate(lv):
+        if f % 64:
+            continue                                          # TW < 64 tiles: ALSEP_PROF_CONV3X3_SMALL, not reported
+        if bf16 and c == 48 and t % 4 == 0 and os.environ.get("ALSEP_CONV_REGW", "1") != "0":
+            out["regw"].append(i)
+        elif (bf16 and c == 96 and t % 8 == 0 and batch * (t // 8) * (f // 64) >= 96
+              and os.environ.get("ALSEP_CONV_BIG", "1") != "0"):
+            out["big"].append(i)
+        else:
+            out["plain"].append(i)
+    return out
 
 
 def pmc_traffic(kernel_prefix: str):
@@ -148,7 +159,13 @@ def main() -> None:
     for _ in range(args.warmup):
         stems = step()
     fence()
-    ctx.profile_begin(_lib.PROF_CONV3X3)
+    klevels = conv_kernel_levels(cfg, dtype == torch.bfloat16, args.batch)
+    KCLASS = {"big": ("conv3x3_bf16_big_kernel<2>", _lib.PROF_CONV3X3_BIG),
+              "regw": ("conv3x3_bf16_regw_kernel<1>", _lib.PROF_CONV3X3_REGW),
+              "plain": ("conv3x3_bf16_kernel<64>" if dtype == torch.bfloat16 else "conv3x3_kernel<f32,16,48,64>",
+                        _lib.PROF_CONV3X3)}
+    primary = "big" if klevels["big"] else "plain"          # the single kernel with the largest share of the step
+    ctx.profile_begin(KCLASS[primary][1])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stems = step()
@@ -166,26 +183,42 @@ def main() -> None:
     n_win = n_samples // gen + 1
     from audiolab_amd.dist import window_range
     w_lo, w_hi = window_range(n_win, world, rank)
-    local_windows = (w_hi - w_lo) * N_STEMS * args.steps
-    main_levels, regw_levels = conv_kernel_levels(cfg, dtype == torch.bfloat16)
-    conv_flops = conv_flops_per_chunk(cfg, main_levels) * local_windows
-    achieved_tflops = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    es = 2 if dtype == torch.bfloat16 else 4
     peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
-    # the other 3x3 kernel class (level 0), one extra untimed pass
+
+    def conv_entry(cls, ms, launches, passes):
+        """Roofline object of one 3x3-conv kernel class from its HIP-event time over `passes` steps."""
+        levels = klevels[cls]
+        fl = conv_flops_per_chunk(cfg, levels) * (w_hi - w_lo) * N_STEMS * passes
+        byts = sum(2.0 * c * t * f * es * (1 if i == cfg.n else 2) * cfg.l for i, (c, t, f) in enumerate(cfg.levels())
+                   if i in levels) * (w_hi - w_lo) * N_STEMS * passes        # each conv reads X and writes Y once
+        tfl = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        gbs = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        e = {"kernel": KCLASS[cls][0]}
+        if cls == "regw":                                   # c = 48: 216 flop/B < the 312 flop/B ridge -> HBM side
+            e.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                      "frac": round(gbs / PEAK_HBM_GBS, 4), "tflops": round(tfl, 1)})
+        else:
+            e.update({"bound": "mfma", "achieved": round(tfl, 2), "peak": peak, "unit": "TFLOP/s",
+                      "frac": round(tfl / peak, 4), "gbs": round(gbs, 1)})
+        e.update({"traffic": pmc_traffic(KCLASS[cls][0]) if dtype == torch.bfloat16 else None,
+                  "launches": launches, "avg_us": round(ms * 1e3 / max(launches, 1), 2),
+                  "flops_per_launch": fl / max(launches, 1), "bytes_per_launch": byts / max(launches, 1),
+                  "levels": levels})
+        return e
+
+    roofline = conv_entry(primary, conv_ms, conv_launches, args.steps)
+    # the other 3x3 kernel classes, one extra untimed pass each
     other = {}
-    if regw_levels:
-        ctx.profile_begin(_lib.PROF_CONV3X3_REGW)
+    for cls in ("regw", "big", "plain"):
+        if cls == primary or not klevels[cls]:
+            continue
+        ctx.profile_begin(KCLASS[cls][1])
         step()
         fence()
         ms, launches = ctx.profile_end()
-        fl = conv_flops_per_chunk(cfg, regw_levels) * (w_hi - w_lo) * N_STEMS
-        lv0 = cfg.levels()[0]
-        byts = 2.0 * lv0[0] * lv0[1] * lv0[2] * (2 if dtype == torch.bfloat16 else 4) * 2 * cfg.l * (w_hi - w_lo) * N_STEMS
-        other["conv3x3_bf16_regw_kernel<1>"] = {
-            "bound": "hbm", "achieved": round(byts / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 1),
-            "launches": launches, "avg_us": round(ms * 1e3 / max(launches, 1), 2),
-            "traffic": pmc_traffic("conv3x3_bf16_regw_kernel<1>")}
+        e = conv_entry(cls, ms, launches, 1)
+        other[e.pop("kernel")] = e
 
     # per-stage HBM rooflines (outside the timed region): STFT and iSTFT over this rank's windows
     stages = {}
@@ -194,7 +227,6 @@ def main() -> None:
     pad_len = plan.trim * 2 + nb * gen + plan.chunk_size
     buf = torch.zeros((2, pad_len), device=device)
     buf[:, plan.trim:plan.trim + min(n_samples, pad_len - 2 * plan.trim)] = mix[:, :min(n_samples, pad_len - 2 * plan.trim)]
-    es = 2 if dtype == torch.bfloat16 else 4
     spec = plan.stft_strided(buf, pad_len, gen, nb, dtype, _lib.LAYOUT_NHWC)
     outb = torch.empty((2, nb * gen), device=device)
     torch.cuda.synchronize()
@@ -241,12 +273,7 @@ def main() -> None:
                                    f"{args.seconds} s 44.1 kHz stereo per GPU, margin chunker, windows/launch={args.batch}",
                        "stems": N_STEMS, "audio_seconds": audio_seconds, "sharding": f"windows/{world} + all_gather"},
             "realtime_factor_4stem": round(audio_seconds * args.steps / dt, 2),
-            "roofline": {"kernel": "conv3x3_bf16_kernel<64>" if dtype == torch.bfloat16 else "conv3x3_kernel<f32,16,48,64>",
-                         "bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved_tflops / peak, 4),
-                         "traffic": pmc_traffic("conv3x3_bf16_kernel<64>") if dtype == torch.bfloat16 else None,
-                         "launches": conv_launches, "avg_us": round(conv_ms * 1e3 / max(conv_launches, 1), 2),
-                         "flops_per_chunk": conv_flops_per_chunk(cfg, main_levels), "levels": main_levels},
+            "roofline": roofline,
             "kernels": other,
             "stages": stages,
             "cpu_baseline": cpu,

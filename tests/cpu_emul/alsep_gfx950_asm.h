@@ -18,4 +18,23 @@ static inline bf16x4 lds_read_tr16_b64(const bf16_t* lds_ptr) {
     return out;
 }
 
+template <int OFF>
+static inline bf16x4 lds_read_tr16_b64_off(const bf16_t* lds_ptr) {
+    return lds_read_tr16_b64(reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(lds_ptr) + OFF));
+}
+
 static inline void lds_read_tr16_wait() {}
+
+template <int N>
+static inline void lds_read_tr16_wait_n() {}
+
+template <typename T>
+static inline const T* opaque_uniform_ptr(const T* p) { return p; }
+
+template <int OFF>
+static inline void global_load_async_bf16x8(bf16x8& dst, const void* sbase, unsigned voff) {
+    dst = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sbase) + voff + OFF);
+}
+
+template <typename T>
+static inline void keep_vgprs_live(const T&) {}

@@ -91,6 +91,36 @@ def test_net_bf16_persistent_conv_two_chunks(emul, monkeypatch):
         assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_net_bf16_wide_tdf_matches_narrow(emul, tmp_path):
+    """Wide-tile TDF kernel (register-resident weight fragments, 3-stage activation ring) against the
+    128-row kernel: same k order, so the outputs must be bit-identical; and against the oracle.
+    dim_f=768, bn=4: first linear 768 -> 192 (M = 192: 4 waves), second 192 -> 768 (M = 768: 4 or, forced, 8 waves)."""
+    import subprocess, sys, os
+    code = (
+        "import os, sys, torch; sys.path.insert(0, %r); os.environ['ALSEP_TDF_WIDE']=sys.argv[1]\n"
+        "from audiolab_amd import _lib\n"
+        "_lib._LIB=_lib.bind(%r); _lib.DEVICE_TYPE='cpu'\n"
+        "from audiolab_amd.synth import synthetic_state_dict\n"
+        "from audiolab_amd.tdfnet import TDFNet, TDFNetConfig\n"
+        "from oracle import tdfnet_oracle\n"
+        "cfg=TDFNetConfig(dim_f=768, dim_t=8, n_fft=2048, hop=64, num_blocks=1, g=48, bn=4)\n"
+        "sd=synthetic_state_dict(cfg, calib_frames=8)\n"
+        "net=TDFNet(cfg, sd, ctx=_lib.Context('cpu'), dtype=torch.bfloat16, max_batch=1)\n"
+        "x=(torch.randn((1,4,768,8), generator=torch.Generator().manual_seed(3))*4).to(torch.bfloat16)\n"
+        "want=tdfnet_oracle.forward(sd, x.float(), 1, 3, 4)\n"
+        "got=net.forward_nhwc(x.permute(0,3,2,1).contiguous()).float().permute(0,3,2,1)\n"
+        "rel=float((got-want).norm()/want.norm()); print('rel', rel); assert rel < 3e-2\n"
+        "torch.save(got, sys.argv[2])\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpu_emul", "libalsep_emul.so"))
+    outs = {}
+    for mode in ("0", "1", "8"):
+        path = str(tmp_path / f"out{mode}.pt")
+        r = subprocess.run([sys.executable, "-c", code, mode, path], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[mode] = torch.load(path)
+    assert torch.equal(outs["0"], outs["1"]) and torch.equal(outs["0"], outs["8"])
+
+
 def test_net_rejects_bad_inputs(emul):
     from audiolab_amd._lib import AlsepError
     from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
