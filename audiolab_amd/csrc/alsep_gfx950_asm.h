@@ -72,3 +72,62 @@ template <typename T>
 __device__ __forceinline__ void keep_vgprs_live(const T& v) {
     asm volatile("" ::"v"(v));
 }
+
+// ------------------------------------------------------------------------------------------------
+// Packed-f32 complex arithmetic on (re, im) register pairs.  hipcc (ROCm 7.2) does not fold the half swap /
+// negation of a multiply by +-i or of a complex product into the op_sel / neg modifiers of v_pk_*_f32 (it emits
+// v_xor + v_mov per operand), which doubles the instruction count of an FFT butterfly; these helpers spell the
+// modifiers out.  op_sel[i] / op_sel_hi[i] pick the half of source i used for the low / high result.
+// ------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ v2f cx_add_mi(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + (+i) b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ v2f cx_add_pi(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a * w = (a.x w.x - a.y w.y, a.x w.y + a.y w.x)
+__device__ __forceinline__ v2f cx_mul(v2f a, v2f w) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// a * conj(w) = (a.x w.x + a.y w.y, a.y w.x - a.x w.y)
+__device__ __forceinline__ v2f cx_mul_conj(v2f a, v2f w) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// c + (-i) s d = (c.x + s.x d.y, c.y - s.y d.x)   (s: a real scale in both halves)
+__device__ __forceinline__ v2f cx_fma_mi(v2f d, v2f s, v2f c) {
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(d), "v"(s), "v"(c));
+    return r;
+}
+// c + (+i) s d = (c.x - s.x d.y, c.y + s.y d.x)
+__device__ __forceinline__ v2f cx_fma_pi(v2f d, v2f s, v2f c) {
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(d), "v"(s), "v"(c));
+    return r;
+}
+// a + conj(b) = (a.x + b.x, a.y - b.y)
+__device__ __forceinline__ v2f cx_add_conj(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (a - conj(b)) / i = (a.y + b.y, b.x - a.x)
+__device__ __forceinline__ v2f cx_sub_conj_divi(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}

@@ -1,0 +1,303 @@
+// Three-pass STFT for n_fft = 256 * R2 (4096 = 16*16*16, 6144 = 16*16*24): the production front end.
+//
+// Semantics: ConvTDFNetTrim.stft, reference modules/rvc/infer/modules/uvr5/mdxnet.py:41-56 (same as
+// stft_kernel in fft.hip, which stays as the generic-size kernel).
+//
+// Why three passes: the generic kernel is bound by instruction issue (~96 instructions per point) and by
+// LDS stores (the slowest LDS operation on gfx950, MI355X_MICROARCH.md section LDS); with radices 16, 16, R2
+//   * pass A takes its inputs straight from global memory (PCM x window) and pass C leaves its outputs in
+//     registers, so the frame crosses LDS twice instead of six times;
+//   * pass C gives thread j the butterflies k = j and k = 256 - j, i.e. both Z[k] and Z[N-k] of the
+//     two-for-one split XL[k] = (Z[k] + conj Z[N-k]) / 2, XR[k] = (Z[k] - conj Z[N-k]) / 2i, so the split needs
+//     no further exchange (thread 0 holds the two self-paired butterflies 0 and 128);
+//   * all complex arithmetic is packed (v_pk_*_f32 on (re, im) pairs, modifiers spelled out in
+//     alsep_gfx950_asm.h), the 1/2 of the split is folded into the window table.
+// One workgroup = one frame of both channels = 128 threads (2 waves), LDS = n_fft * 8 bytes.
+#pragma once
+
+namespace r16 {
+
+constexpr int kThreads = 128;
+
+__device__ __forceinline__ v2f mk(float x, float y) { v2f r = {x, y}; return r; }
+
+// forward DFT-4 in place: (a, b, c, d) -> (X0, X1, X2, X3)
+__device__ __forceinline__ void dft4(v2f& a, v2f& b, v2f& c, v2f& d) {
+    const v2f t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+    a = t0 + t2;
+    c = t0 - t2;
+    b = cx_add_mi(t1, t3);
+    d = cx_add_pi(t1, t3);
+}
+// the same with input c already owed a factor -i (c' = -i c)
+__device__ __forceinline__ void dft4_c_negi(v2f& a, v2f& b, v2f& c, v2f& d) {
+    const v2f t0 = cx_add_mi(a, c), t1 = cx_add_pi(a, c), t2 = b + d, t3 = b - d;
+    a = t0 + t2;
+    c = t0 - t2;
+    b = cx_add_mi(t1, t3);
+    d = cx_add_pi(t1, t3);
+}
+
+// W_16^m = exp(-2 pi i m / 16)
+#define R16_C1 0.92387953251128675613f
+#define R16_S1 0.38268343236508977173f
+#define R16_H 0.70710678118654752440f
+
+// Forward DFT-16 in place, 4 x 4 Cooley-Tukey; output X[q] ends up in u[(q & 3) * 4 + (q >> 2)].
+__device__ __forceinline__ void dft16(v2f (&u)[16]) {
+#pragma unroll
+    for (int r2 = 0; r2 < 4; ++r2) dft4(u[r2], u[4 + r2], u[8 + r2], u[12 + r2]);   // -> A[r2][q1] at u[4 q1 + r2]
+    const v2f w1 = mk(R16_C1, -R16_S1), w2 = mk(R16_H, -R16_H), w3 = mk(R16_S1, -R16_C1);
+    const v2f w6 = mk(-R16_H, -R16_H), w9 = mk(-R16_C1, R16_S1);
+    u[5] = cx_mul(u[5], w1);    // q1 = 1: r2 = 1, 2, 3 -> W^1, W^2, W^3
+    u[6] = cx_mul(u[6], w2);
+    u[7] = cx_mul(u[7], w3);
+    u[9] = cx_mul(u[9], w2);    // q1 = 2: W^2, W^4 (= -i, folded below), W^6
+    u[11] = cx_mul(u[11], w6);
+    u[13] = cx_mul(u[13], w3);  // q1 = 3: W^3, W^6, W^9
+    u[14] = cx_mul(u[14], w6);
+    u[15] = cx_mul(u[15], w9);
+    dft4(u[0], u[1], u[2], u[3]);
+    dft4(u[4], u[5], u[6], u[7]);
+    dft4_c_negi(u[8], u[9], u[10], u[11]);
+    dft4(u[12], u[13], u[14], u[15]);
+}
+__device__ __forceinline__ constexpr int dft16_slot(int q) { return (q & 3) * 4 + (q >> 2); }
+
+// forward DFT-8 in place, natural order
+__device__ __forceinline__ void dft8(v2f& u0, v2f& u1, v2f& u2, v2f& u3, v2f& u4, v2f& u5, v2f& u6, v2f& u7) {
+    dft4(u0, u2, u4, u6);                  // e0..e3 in u0, u2, u4, u6
+    dft4(u1, u3, u5, u7);                  // o0..o3 in u1, u3, u5, u7
+    const v2f o1 = cx_mul(u3, mk(R16_H, -R16_H));
+    const v2f o3 = cx_mul(u7, mk(-R16_H, -R16_H));
+    const v2f e0 = u0, e1 = u2, e2 = u4, e3 = u6, o0 = u1, o2 = u5;
+    u0 = e0 + o0;  u4 = e0 - o0;
+    u1 = e1 + o1;  u5 = e1 - o1;
+    u2 = cx_add_mi(e2, o2);  u6 = cx_add_pi(e2, o2);
+    u3 = e3 + o3;  u7 = e3 - o3;
+}
+// forward DFT-3 in place
+__device__ __forceinline__ void dft3(v2f& u0, v2f& u1, v2f& u2) {
+    const v2f s = mk(0.86602540378443864676f, 0.86602540378443864676f);
+    const v2f t1 = u1 + u2, d = u1 - u2;
+    const v2f t2 = u0 - 0.5f * t1;
+    u0 = u0 + t1;
+    u1 = cx_fma_mi(d, s, t2);
+    u2 = cx_fma_pi(d, s, t2);
+}
+
+// Last-pass DFT of size R2 in place; output X[q] ends up in u[LastDft<R2>::slot(q)].
+template <int R2> struct LastDft;
+template <> struct LastDft<16> {
+    static __device__ __forceinline__ void run(v2f (&u)[16]) { dft16(u); }
+    static __device__ __forceinline__ constexpr int slot(int q) { return dft16_slot(q); }
+};
+// 24 = 3 x 8 by the prime-factor map (no inner twiddles): input r = (8 n1 + 3 n2) mod 24, output
+// q = (16 k1 + 9 k2) mod 24; DFT-8 over n2 then DFT-3 over n1, both in place.
+template <> struct LastDft<24> {
+    static __device__ __forceinline__ constexpr int in_idx(int n1, int n2) { return (8 * n1 + 3 * n2) % 24; }
+    static __device__ __forceinline__ void run(v2f (&u)[24]) {
+#pragma unroll
+        for (int n1 = 0; n1 < 3; ++n1)
+            dft8(u[in_idx(n1, 0)], u[in_idx(n1, 1)], u[in_idx(n1, 2)], u[in_idx(n1, 3)], u[in_idx(n1, 4)],
+                 u[in_idx(n1, 5)], u[in_idx(n1, 6)], u[in_idx(n1, 7)]);
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) dft3(u[in_idx(0, k2)], u[in_idx(1, k2)], u[in_idx(2, k2)]);
+    }
+    // X[(16 k1 + 9 k2) % 24] sits where input (n1 = k1, n2 = k2) sat; k1 = q mod 3, k2 = q mod 8 (CRT)
+    static __device__ __forceinline__ constexpr int slot(int q) { return in_idx(q % 3, q % 8); }
+};
+
+// w[r] = w1^r for r = 1..R-1, product tree of depth <= log2(R)
+template <int R> __device__ __forceinline__ void twiddle_powers(v2f w1, v2f (&w)[R]) {
+    w[1] = w1;
+#pragma unroll
+    for (int r = 2; r < R; ++r) w[r] = (r & 1) ? cx_mul(w[r - 1], w1) : cx_mul(w[r >> 1], w[r >> 1]);
+}
+
+template <typename OutT> __device__ __forceinline__ void store_bin(OutT* spec, int64_t frame_off, int64_t b, int k,
+                                                                     int T, int t, int dim_f, int layout, v2f L, v2f R);
+template <> __device__ __forceinline__ void store_bin<float>(float* spec, int64_t frame_off, int64_t b, int k, int T,
+                                                             int t, int dim_f, int layout, v2f L, v2f R) {
+    if (layout == ALSEP_LAYOUT_NHWC) {
+        f32x4 v = {L.x, L.y, R.x, R.y};
+        *reinterpret_cast<f32x4*>(spec + (frame_off + k) * 4) = v;
+    } else {
+        const int64_t plane = (int64_t)dim_f * T;
+        float* o = spec + b * 4 * plane + (int64_t)k * T + t;
+        o[0] = L.x; o[plane] = L.y; o[2 * plane] = R.x; o[3 * plane] = R.y;
+    }
+}
+template <> __device__ __forceinline__ void store_bin<bf16_t>(bf16_t* spec, int64_t frame_off, int64_t b, int k, int T,
+                                                              int t, int dim_f, int layout, v2f L, v2f R) {
+    if (layout == ALSEP_LAYOUT_NHWC) {
+        bf16x4 v;
+        v[0] = (bf16_t)L.x; v[1] = (bf16_t)L.y; v[2] = (bf16_t)R.x; v[3] = (bf16_t)R.y;
+        *reinterpret_cast<bf16x4*>(spec + (frame_off + k) * 4) = v;
+    } else {
+        const int64_t plane = (int64_t)dim_f * T;
+        bf16_t* o = spec + b * 4 * plane + (int64_t)k * T + t;
+        o[0] = (bf16_t)L.x; o[plane] = (bf16_t)L.y; o[2 * plane] = (bf16_t)R.x; o[3 * plane] = (bf16_t)R.y;
+    }
+}
+
+// grid (T, n_chunks), 128 threads.  winh = 0.5 * periodic Hann (the 1/2 of the two-for-one split).
+// ABL != 0: timing-only ablations (wrong results): 1 no global loads, 2 no stores, 3 no LDS exchange / barriers,
+// 4 no arithmetic.
+template <int R2, typename OutT, int LAYOUT, int ABL = 0>
+__global__ void __launch_bounds__(kThreads)
+stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_stride, int chunk, int hop, int dim_f,
+                int T, const float2* __restrict__ tw_, const float* __restrict__ winh, OutT* __restrict__ spec) {
+    constexpr int N = 256 * R2, NT = kThreads;
+    constexpr int M = N / 16;                 // butterflies of passes A and B
+    constexpr int NB = M / NT;                // per thread (2 or 3)
+    static_assert(M % NT == 0 && (M / 16) % 8 == 0, "geometry");
+    const v2f* __restrict__ tw = reinterpret_cast<const v2f*>(tw_);
+    v2f* buf = reinterpret_cast<v2f*>(alsep_smem);
+    const int tid = threadIdx.x;
+    // consecutive workgroup ids are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of frames so
+    // that the 6-fold re-read of every PCM sample (hop = n_fft / 6) is served by ONE L2 instead of all eight
+    const int wg = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int t = wg % T;
+    const int64_t b = wg / T;
+    const int p0 = t * hop - N / 2;
+    const float* xl = pcm + b * chunk_stride;
+    const float* xr = xl + ch_stride;
+    // first-order twiddles of passes B and C, fetched now: behind a barrier each would expose one memory latency
+    const int ka = tid, kb = tid ? 256 - tid : 128;
+    const v2f wB1 = tw[(tid & 15) * (N / 256)], wa1 = tw[ka], wb1 = tw[kb];
+
+    // ---- pass A: radix 16, P = 1.  Butterfly i takes x[i + M r] * w[i + M r]; writes row i (16 values).
+    // LDS image after pass A: row i at i*16, its 16-byte granule g (values 2g, 2g+1) at position g ^ (i & 7):
+    // conflict-free ds_write_b128 here, conflict-free ds_read_b64 in pass B.
+    {
+        v2f u[NB][16];
+        if (ABL == 1) {
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u[bb][r] = mk((float)(tid + r), (float)(tid * bb));
+        } else if (p0 >= 0 && p0 + N <= chunk) {                 // interior frame (wave-uniform)
+            // uniform base (SGPR pair) + 32-bit lane offset + immediate: no per-load 64-bit address arithmetic
+            const unsigned voff = (unsigned)tid * 4u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const char* sl = reinterpret_cast<const char*>(xl + p0 + M * r);
+                const char* sr = reinterpret_cast<const char*>(xr + p0 + M * r);
+                const char* sw = reinterpret_cast<const char*>(winh + M * r);
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) {
+                    const float w = *reinterpret_cast<const float*>(sw + voff + NT * bb * 4);
+                    u[bb][r] = mk(*reinterpret_cast<const float*>(sl + voff + NT * bb * 4) * w,
+                                  *reinterpret_cast<const float*>(sr + voff + NT * bb * 4) * w);
+                }
+            }
+        } else {                                                 // reflect padding (center=True)
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = tid + NT * bb + M * r;
+                    int p = p0 + n;
+                    if (p < 0) p = -p;
+                    if (p >= chunk) p = 2 * (chunk - 1) - p;
+                    const float w = winh[n];
+                    u[bb][r] = mk(xl[p] * w, xr[p] * w);
+                }
+        }
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+            if (ABL != 4) dft16(u[bb]);
+            const int i = tid + NT * bb;
+            f32x4* row = reinterpret_cast<f32x4*>(buf + i * 16);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const v2f lo = u[bb][dft16_slot(2 * g)], hi = u[bb][dft16_slot(2 * g + 1)];
+                f32x4 v = {lo.x, lo.y, hi.x, hi.y};
+                if (ABL != 3) row[g ^ (i & 7)] = v;
+                else if (v[0] == 123.f) row[g] = v;
+            }
+        }
+    }
+    if (ABL != 3) __syncthreads();
+
+    // ---- pass B: radix 16, P = 16.  Butterfly i (k = i & 15) takes logical buf[i + M r] * W_256^(k r) and
+    // writes logical (i >> 4) * 256 + 16 q + k (plain layout from here on).
+    {
+        v2f u[NB][16];
+        const int k = tid & 15;
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+            const int i = tid + NT * bb;
+            const int row = i >> 4;                              // (row + (M/16) r) & 7 == row & 7
+            const v2f* src = buf + row * 16 + ((((k >> 1) ^ (row & 7)) << 1) | (k & 1));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[bb][r] = ABL == 3 ? mk((float)(tid * r), (float)bb) : src[M * r];
+        }
+        v2f w[16];
+        twiddle_powers<16>(wB1, w);
+        if (ABL != 3) __syncthreads();                           // every read of the pass-A image is done
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+            if (ABL != 4) {
+#pragma unroll
+                for (int r = 1; r < 16; ++r) u[bb][r] = cx_mul(u[bb][r], w[r]);
+                dft16(u[bb]);
+            }
+            const int i = tid + NT * bb;
+            v2f* dst = buf + (i >> 4) * 256 + k;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (ABL != 3 || u[bb][q].x == 123.f) dst[16 * q] = u[bb][dft16_slot(q)];
+        }
+    }
+    if (ABL != 3) __syncthreads();
+
+    // ---- pass C: radix R2, P = 256.  Thread j: butterflies ka = j and kb = 256 - j (thread 0: 0 and 128).
+    {
+        v2f za[R2], zb[R2];
+#pragma unroll
+        for (int r = 0; r < R2; ++r) za[r] = ABL == 3 ? mk((float)(tid + r), 1.f) : buf[ka + 256 * r];
+#pragma unroll
+        for (int r = 0; r < R2; ++r) zb[r] = ABL == 3 ? mk((float)(tid * r), 2.f) : buf[kb + 256 * r];
+        if (ABL != 4) {
+            v2f w[R2];
+            twiddle_powers<R2>(wa1, w);
+#pragma unroll
+            for (int r = 1; r < R2; ++r) za[r] = cx_mul(za[r], w[r]);
+            LastDft<R2>::run(za);
+        }
+        if (ABL != 4) {
+            v2f w[R2];
+            twiddle_powers<R2>(wb1, w);
+#pragma unroll
+            for (int r = 1; r < R2; ++r) zb[r] = cx_mul(zb[r], w[r]);
+            LastDft<R2>::run(zb);
+        } else {
+            za[0] += wa1 + wB1; zb[0] += wb1;
+        }
+        // Two-for-one split.  Bin k1 = ka + 256 q pairs with N - k1 = kb + 256 (R2-1-q)  [thread 0: 256 (R2-q)],
+        // bin k2 = kb + 256 q with N - k2 = ka + 256 (R2-1-q)                                [thread 0: kb + ...].
+        const bool t0 = tid == 0;
+        const int64_t frame_off = (b * T + t) * (int64_t)dim_f;
+#pragma unroll
+        for (int q = 0; q < R2 / 2; ++q) {
+            const v2f a_q = za[LastDft<R2>::slot(q)], b_q = zb[LastDft<R2>::slot(q)];
+            const v2f a_m = za[LastDft<R2>::slot(R2 - 1 - q)], b_m = zb[LastDft<R2>::slot(R2 - 1 - q)];
+            const v2f a_w = za[LastDft<R2>::slot((R2 - q) % R2)];
+            const v2f n1 = t0 ? a_w : b_m;
+            const v2f n2 = t0 ? b_m : a_m;
+            const int k1 = ka + 256 * q, k2 = kb + 256 * q;
+            if (k1 < dim_f && (ABL != 2 || a_q.x == 123.f))
+                store_bin<OutT>(spec, frame_off, b, k1, T, t, dim_f, LAYOUT, cx_add_conj(a_q, n1), cx_sub_conj_divi(a_q, n1));
+            if (k2 < dim_f && (ABL != 2 || b_q.x == 123.f))
+                store_bin<OutT>(spec, frame_off, b, k2, T, t, dim_f, LAYOUT, cx_add_conj(b_q, n2), cx_sub_conj_divi(b_q, n2));
+        }
+        if (t0 && dim_f > N / 2) {                               // Nyquist bin, self-paired
+            const v2f z = za[LastDft<R2>::slot(R2 / 2)];
+            store_bin<OutT>(spec, frame_off, b, N / 2, T, t, dim_f, LAYOUT, cx_add_conj(z, z), cx_sub_conj_divi(z, z));
+        }
+    }
+}
+
+}  // namespace r16

@@ -38,3 +38,13 @@ static inline void global_load_async_bf16x8(bf16x8& dst, const void* sbase, unsi
 
 template <typename T>
 static inline void keep_vgprs_live(const T&) {}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+static inline v2f cx_add_mi(v2f a, v2f b) { return v2f{a.x + b.y, a.y - b.x}; }
+static inline v2f cx_add_pi(v2f a, v2f b) { return v2f{a.x - b.y, a.y + b.x}; }
+static inline v2f cx_mul(v2f a, v2f w) { return v2f{fmaf(a.x, w.x, -(a.y * w.y)), fmaf(a.x, w.y, a.y * w.x)}; }
+static inline v2f cx_mul_conj(v2f a, v2f w) { return v2f{fmaf(a.x, w.x, a.y * w.y), fmaf(-a.x, w.y, a.y * w.x)}; }
+static inline v2f cx_fma_mi(v2f d, v2f s, v2f c) { return v2f{fmaf(s.x, d.y, c.x), fmaf(-s.y, d.x, c.y)}; }
+static inline v2f cx_fma_pi(v2f d, v2f s, v2f c) { return v2f{fmaf(-s.x, d.y, c.x), fmaf(s.y, d.x, c.y)}; }
+static inline v2f cx_add_conj(v2f a, v2f b) { return v2f{a.x + b.x, a.y - b.y}; }
+static inline v2f cx_sub_conj_divi(v2f a, v2f b) { return v2f{a.y + b.y, b.x - a.x}; }
