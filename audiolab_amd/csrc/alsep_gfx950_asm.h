@@ -131,3 +131,19 @@ __device__ __forceinline__ v2f cx_sub_conj_divi(v2f a, v2f b) {
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// conj(a + i b) = (a.x - b.y, -a.y - b.x)
+__device__ __forceinline__ v2f cx_conj_add_pi(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// register budget of a kernel: exactly n waves per SIMD (512 / n VGPRs + AGPRs per lane)
+#define ALSEP_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+
+// A literal the optimiser must materialise HERE, in an SGPR (s_mov, scalar unit): loop-invariant literals of an
+// unrolled body are otherwise hoisted into one VGPR each and spill.
+__device__ __forceinline__ float sgpr_literal(float c) {
+    asm volatile("" : "+s"(c));
+    return c;
+}

@@ -30,6 +30,7 @@ struct alsep_plan {
     float2* tw = nullptr;     // W_N^j = exp(-2*pi*i*j/N), j in [0,N)
     float* win = nullptr;     // periodic Hann window, N floats
     float* winh = nullptr;    // 0.5 * win (three-pass STFT: the 1/2 of the two-for-one split, exact)
+    float* wini = nullptr;    // win / N (three-pass iSTFT)
     float* env = nullptr;     // sum_t w^2 over the padded chunk timeline, N + hop*(T-1)
     int64_t env_len = 0;
 };
@@ -490,7 +491,7 @@ extern "C" int alsep_plan_create(alsep_ctx* ctx, int n_fft, int hop, int dim_f, 
     alsep_plan* p = new alsep_plan();
     p->ctx = ctx; p->n_fft = n_fft; p->hop = hop; p->dim_f = dim_f; p->dim_t = dim_t; p->chunk = (int)chunk;
     std::vector<float2> tw(n_fft);
-    std::vector<float> win(n_fft), winh(n_fft);
+    std::vector<float> win(n_fft), winh(n_fft), wini(n_fft);
     std::vector<double> w2(n_fft);
     for (int j = 0; j < n_fft; ++j) {
         const double a = -2.0 * M_PI * (double)j / (double)n_fft;
@@ -498,6 +499,7 @@ extern "C" int alsep_plan_create(alsep_ctx* ctx, int n_fft, int hop, int dim_f, 
         const double w = 0.5 - 0.5 * cos(2.0 * M_PI * (double)j / (double)n_fft);
         win[j] = (float)w;
         winh[j] = 0.5f * win[j];
+        wini[j] = win[j] * (1.0f / (float)n_fft);
         w2[j] = (double)win[j] * (double)win[j];
     }
     p->env_len = (int64_t)n_fft + (int64_t)hop * (dim_t - 1);
@@ -509,6 +511,7 @@ extern "C" int alsep_plan_create(alsep_ctx* ctx, int n_fft, int hop, int dim_f, 
     if (hipMalloc((void**)&p->tw, sizeof(float2) * n_fft) != hipSuccess ||
         hipMalloc((void**)&p->win, sizeof(float) * n_fft) != hipSuccess ||
         hipMalloc((void**)&p->winh, sizeof(float) * n_fft) != hipSuccess ||
+        hipMalloc((void**)&p->wini, sizeof(float) * n_fft) != hipSuccess ||
         hipMalloc((void**)&p->env, sizeof(float) * p->env_len) != hipSuccess) {
         alsep_plan_destroy(p);
         return alsep_fail(ctx, ALSEP_ERR_NOMEM, "plan tables: hipMalloc failed");
@@ -517,6 +520,7 @@ extern "C" int alsep_plan_create(alsep_ctx* ctx, int n_fft, int hop, int dim_f, 
     ALSEP_HIP(ctx, hipMemcpy(p->tw, tw.data(), sizeof(float2) * n_fft, hipMemcpyHostToDevice));
     ALSEP_HIP(ctx, hipMemcpy(p->win, win.data(), sizeof(float) * n_fft, hipMemcpyHostToDevice));
     ALSEP_HIP(ctx, hipMemcpy(p->winh, winh.data(), sizeof(float) * n_fft, hipMemcpyHostToDevice));
+    ALSEP_HIP(ctx, hipMemcpy(p->wini, wini.data(), sizeof(float) * n_fft, hipMemcpyHostToDevice));
     ALSEP_HIP(ctx, hipMemcpy(p->env, env.data(), sizeof(float) * p->env_len, hipMemcpyHostToDevice));
     *out = p;
     return ALSEP_OK;
@@ -527,6 +531,7 @@ extern "C" int alsep_plan_destroy(alsep_plan* plan) {
     if (plan->tw) (void)hipFree(plan->tw);
     if (plan->win) (void)hipFree(plan->win);
     if (plan->winh) (void)hipFree(plan->winh);
+    if (plan->wini) (void)hipFree(plan->wini);
     if (plan->env) (void)hipFree(plan->env);
     delete plan;
     return ALSEP_OK;
@@ -611,6 +616,35 @@ extern "C" int alsep_stft(alsep_ctx* ctx, const alsep_plan* plan, const float* p
     return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_stft: unsupported n_fft %d", plan->n_fft);
 }
 
+// Hop-blocks per workgroup of the persistent iSTFT kernels.  A workgroup spends run + Q - 1 frames on `run` blocks
+// (Q - 1 warm-up frames re-done by every workgroup), and the grid runs in ceil(workgroups / slots) rounds: pick the
+// run with the smallest rounds x frames (one nearly full round beats two half-empty ones).
+static int istft_pick_run(int n_blocks, int Q, int64_t n_chunks, int slots) {
+    int best = 16;
+    double best_cost = 1e30;
+    for (int run = 4; run <= 64; ++run) {
+        const int64_t wgs = n_chunks * ((n_blocks + run - 1) / run);
+        const int64_t rounds = (wgs + slots - 1) / slots;
+        const double cost = (double)rounds * (run + Q - 1);
+        if (cost < best_cost) { best_cost = cost; best = run; }
+    }
+    return best;
+}
+
+static int device_cu_count(alsep_ctx* ctx) {
+#ifdef ALSEP_CPU_EMUL
+    (void)ctx;
+    return 256;
+#else
+    static const int n = [ctx] {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+#endif
+}
+
 constexpr int kIstftRun = 32;   // hop-blocks finished per workgroup (warm-up = ceil(N/hop)-1 frames)
 
 template <int N, typename InT, int LAYOUT>
@@ -621,12 +655,36 @@ static int launch_istft(alsep_ctx* ctx, const alsep_plan* p, const void* spec, i
     const int j_lo = (int)((keep_lo + N / 2) / p->hop);
     const int j_hi = (int)((keep_hi - 1 + N / 2) / p->hop) + 1;
     ProfScope prof(ctx, ALSEP_PROF_ISTFT);
+    if constexpr (N == 4096 || N == 6144) {
+        static const int r16_on = [] { const char* e = getenv("ALSEP_ISTFT_R16"); return e ? atoi(e) : 1; }();
+        if (p->hop == 1024 && r16_on) {                      // production geometry: three-pass kernel
+            constexpr int R2 = N / 256;
+            const size_t lds_r = r16::istft_lds_bytes<R2>();
+            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)r16::istft_r16_kernel<R2, 8, InT, LAYOUT>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+            static const int run_env = [] { const char* e = getenv("ALSEP_ISTFT_RUN"); return e ? atoi(e) : 0; }();
+            const int run = run_env > 0 ? run_env : istft_pick_run(j_hi - j_lo, Q, n_chunks, 3 * device_cu_count(ctx));
+            const int groups_r = (j_hi - j_lo + run - 1) / run;
+            for (int64_t b0 = 0; b0 < n_chunks; b0 += 32768) {
+                const int64_t nb = std::min<int64_t>(32768, n_chunks - b0);
+                const int64_t spec_off = b0 * 4 * (int64_t)p->dim_f * p->dim_t;
+                hipLaunchKernelGGL((r16::istft_r16_kernel<R2, 8, InT, LAYOUT>), dim3(groups_r, (unsigned)nb),
+                                   dim3(r16::kThreads), lds_r, ctx->stream, (const InT*)spec + spec_off, p->dim_f, p->dim_t,
+                                   (const float2*)p->tw, (const float*)p->wini, (const float*)p->env, j_lo, j_hi, run,
+                                   out + b0 * out_chunk_stride, out_ch_stride, out_chunk_stride, keep_lo, keep_hi,
+                                   out_limit - b0 * out_chunk_stride);
+            }
+            ALSEP_LAUNCH_CHECK(ctx, "istft_r16_kernel");
+            return ALSEP_OK;
+        }
+    }
     if constexpr (N % 1024 == 0 || N == 7680) {
         if (p->hop == 1024) {                                // production geometry: register ring, 3 workgroups per CU
             const size_t lds_r = sizeof(float2) * (size_t)N;
             ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)istft_regring_kernel<N, 1024, InT, LAYOUT>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
-            const int run = 16;
+            static const int run_env = [] { const char* e = getenv("ALSEP_ISTFT_RUN"); return e ? atoi(e) : 0; }();
+            const int run = run_env > 0 ? run_env : istft_pick_run(j_hi - j_lo, Q, n_chunks, 3 * device_cu_count(ctx));
             const int groups_r = (j_hi - j_lo + run - 1) / run;
             for (int64_t b0 = 0; b0 < n_chunks; b0 += 32768) {
                 const int64_t nb = std::min<int64_t>(32768, n_chunks - b0);

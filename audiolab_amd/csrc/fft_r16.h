@@ -300,4 +300,218 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// iSTFT + overlap-add for n_fft = 256 * R2, hop = 128 * NBH (production: 6144 / 1024).
+//
+// Semantics: ConvTDFNetTrim.istft, mdxnet.py:58-75 (same contract as istft_regring_kernel in fft.hip).
+// y = conj(FFT(conj Z)) / N with the passes in the order R2, 16, 16:
+//   * pass A (radix R2, no twiddles) builds its inputs straight from the spectrogram: thread j owns the
+//     butterflies j and 256 - j, whose inputs are exactly conj Z[k] and conj Z[N-k] of the bins k = j + 256 r and
+//     (256 - j) + 256 r (r < R2/2) that it loads -- the Hermitian extension needs no exchange;
+//   * pass C leaves sample n = tid + 128 (bb + NB q) in thread tid, so the overlap-add accumulator lives in
+//     registers: 1/N * window, add, emit the NBH finished entries per frame, slide by NBH.
+// LDS: rows of R2 values padded to R2 + 1 (conflict-free ds_write_b64 of the pass-A rows).
+// ------------------------------------------------------------------------------------------------
+template <typename InT> __device__ __forceinline__ void load_bin(const InT* p, v2f& L, v2f& R);
+template <> __device__ __forceinline__ void load_bin<float>(const float* p, v2f& L, v2f& R) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(p);
+    L = mk(q[0], q[1]); R = mk(q[2], q[3]);
+}
+template <> __device__ __forceinline__ void load_bin<bf16_t>(const bf16_t* p, v2f& L, v2f& R) {
+    const bf16x4 q = *reinterpret_cast<const bf16x4*>(p);
+    L = mk((float)q[0], (float)q[1]); R = mk((float)q[2], (float)q[3]);
+}
+
+template <int R2> constexpr int istft_lds_bytes() { return 256 * (R2 + 1) * 8; }
+
+// grid (n_groups, n_chunks); each workgroup finishes `run` consecutive hop-blocks (as istft_regring_kernel).
+// wini = window / N.
+template <int R2, int NBH, typename InT, int LAYOUT>
+__global__ void __launch_bounds__(kThreads) ALSEP_WAVES_PER_EU(2)
+istft_r16_kernel(const InT* __restrict__ spec, int dim_f, int T, const float2* __restrict__ tw_,
+                 const float* __restrict__ wini, const float* __restrict__ env, int j_lo, int j_hi, int run,
+                 float* __restrict__ out, int64_t out_ch_stride, int64_t out_chunk_stride, int64_t keep_lo,
+                 int64_t keep_hi, int64_t out_limit) {
+    constexpr int N = 256 * R2, NT = kThreads, HOP = 128 * NBH;
+    constexpr int M = 16 * R2;                // butterflies of passes B and C
+    constexpr int NB = M / NT;                // per thread
+    constexpr int NA = N / NT;                // accumulator entries per thread
+    constexpr int RS = R2 + 1;                // padded row stride of the pass-A image
+    constexpr int H = R2 / 2;
+    constexpr int Q = (N + HOP - 1) / HOP;
+    static_assert(M % NT == 0 && NA % NBH == 0, "geometry");
+    const v2f* __restrict__ tw = reinterpret_cast<const v2f*>(tw_);
+    v2f* buf = reinterpret_cast<v2f*>(alsep_smem);
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.y;
+    const int j0 = j_lo + blockIdx.x * run;
+    const int j1 = min(j0 + run, j_hi);
+    if (j0 >= j1) return;
+    const bool t0 = tid == 0;
+    const int ka = tid, kb = tid ? 256 - tid : 128;
+
+    // per-butterfly constants of passes B and C (kept across frames)
+    int rowB[NB];                             // pass-A image offset of butterfly i's first input
+    int dstB[NB];                             // pass-B output offset
+    v2f wB1[NB], wC1[NB];
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+        const int i = tid + NT * bb;
+        const int a = i / R2, k = i - a * R2;
+        rowB[bb] = a * RS + k;
+        dstB[bb] = a * M + k;
+        wB1[bb] = tw[k * 16];                 // W_{16 R2}^k
+        wC1[bb] = tw[i];                      // W_N^i
+    }
+
+    v2f acc[NA];
+#pragma unroll
+    for (int m = 0; m < NA; ++m) acc[m] = mk(0.f, 0.f);
+    // global addresses as uniform base (SGPR pair) + 32-bit lane offset: 64-bit per-load pointers would be hoisted
+    // out of the frame loop by the compiler and spill
+    const v2f wt = tw[tid];                   // (cos, -sin)(2 pi tid / N)
+    const unsigned voffA = (unsigned)ka * (4u * (unsigned)sizeof(InT)), voffB = (unsigned)kb * (4u * (unsigned)sizeof(InT));
+
+    const int t_start = max(0, j0 - Q + 1);
+    for (int t = t_start; t < j1; ++t) {
+        if (t < T) {
+            // ---- pass A
+            {
+                const InT* frame = spec + (b * T + t) * (int64_t)dim_f * 4;   // NHWC row of this frame (uniform)
+                v2f za[R2], zb[R2];
+                v2f mA[H], mB[H];
+#pragma unroll
+                for (int r = 0; r < H; ++r) {
+                    v2f L = mk(0.f, 0.f), R = mk(0.f, 0.f);
+                    const int k = ka + 256 * r;
+                    if (k < dim_f) {
+                        if (LAYOUT == ALSEP_LAYOUT_NHWC) {
+                            load_bin<InT>(reinterpret_cast<const InT*>(opaque_uniform_ptr(reinterpret_cast<const char*>(frame + 256 * r * 4)) + voffA), L, R);
+                        } else {
+                            const int64_t plane = (int64_t)dim_f * T;
+                            const InT* s = spec + b * 4 * plane + (int64_t)k * T + t;
+                            L = mk(to_f32(s[0]), to_f32(s[plane]));
+                            R = mk(to_f32(s[2 * plane]), to_f32(s[3 * plane]));
+                        }
+                    }
+                    if (r == 0 && t0) { L.y = 0.f; R.y = 0.f; }          // c2r ignores Im of DC
+                    za[r] = cx_conj_add_pi(L, R);                          // conj Z[k]
+                    mA[r] = cx_add_mi(L, R);                               // conj Z[N-k]
+                }
+#pragma unroll
+                for (int r = 0; r < H; ++r) {
+                    v2f L = mk(0.f, 0.f), R = mk(0.f, 0.f);
+                    const int k = kb + 256 * r;
+                    if (k < dim_f) {
+                        if (LAYOUT == ALSEP_LAYOUT_NHWC) {
+                            load_bin<InT>(reinterpret_cast<const InT*>(opaque_uniform_ptr(reinterpret_cast<const char*>(frame + 256 * r * 4)) + voffB), L, R);
+                        } else {
+                            const int64_t plane = (int64_t)dim_f * T;
+                            const InT* s = spec + b * 4 * plane + (int64_t)k * T + t;
+                            L = mk(to_f32(s[0]), to_f32(s[plane]));
+                            R = mk(to_f32(s[2 * plane]), to_f32(s[3 * plane]));
+                        }
+                    }
+                    zb[r] = cx_conj_add_pi(L, R);
+                    mB[r] = cx_add_mi(L, R);
+                }
+                v2f nyq = mk(0.f, 0.f);
+                if (t0 && dim_f > N / 2) {                               // Nyquist bin: Im ignored
+                    v2f L, R;
+                    if (LAYOUT == ALSEP_LAYOUT_NHWC) {
+                        load_bin<InT>(spec + ((b * T + t) * (int64_t)dim_f + N / 2) * 4, L, R);
+                    } else {
+                        const int64_t plane = (int64_t)dim_f * T;
+                        const InT* s = spec + b * 4 * plane + (int64_t)(N / 2) * T + t;
+                        L = mk(to_f32(s[0]), 0.f);
+                        R = mk(to_f32(s[2 * plane]), 0.f);
+                    }
+                    nyq = mk(L.x, -R.x);
+                }
+                // upper halves: index s = R2-1-r of butterfly a is N - (kb + 256 r), of b is N - (ka + 256 r);
+                // thread 0 (a = 0, b = 128): a[R2 - r] = N - 256 r, a[R2/2] = Nyquist, b[R2-1-r] = N - (128 + 256 r)
+#pragma unroll
+                for (int s = H; s < R2; ++s) {
+                    const v2f a0 = s == H ? nyq : mA[(R2 - s) % H];
+                    za[s] = t0 ? a0 : mB[R2 - 1 - s];
+                    zb[s] = t0 ? mB[R2 - 1 - s] : mA[R2 - 1 - s];
+                }
+                LastDft<R2>::run(za);
+                LastDft<R2>::run(zb);
+                v2f* ra = buf + ka * RS;
+                v2f* rb = buf + kb * RS;
+#pragma unroll
+                for (int q = 0; q < R2; ++q) ra[q] = za[LastDft<R2>::slot(q)];
+#pragma unroll
+                for (int q = 0; q < R2; ++q) rb[q] = zb[LastDft<R2>::slot(q)];
+            }
+            __syncthreads();
+            // ---- pass B: radix 16, P = R2
+            {
+                v2f u[NB][16];
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) u[bb][r] = buf[rowB[bb] + 16 * RS * r];
+                __syncthreads();                                         // every read of the pass-A image is done
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) {
+                    v2f w[16];
+                    twiddle_powers<16>(wB1[bb], w);
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) u[bb][r] = cx_mul(u[bb][r], w[r]);
+                    dft16(u[bb]);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) buf[dstB[bb] + R2 * q] = u[bb][dft16_slot(q)];
+                }
+            }
+            __syncthreads();
+            // ---- pass C: radix 16, P = 16 R2; output sample n = tid + 128 (bb + NB q).  Nothing is written to LDS
+            // here, so the butterflies go one at a time (32 live registers instead of 32 NB beside the accumulator).
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                v2f u[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u[r] = buf[tid + NT * bb + M * r];
+                v2f w[16];
+                twiddle_powers<16>(wC1[bb], w);
+#pragma unroll
+                for (int r = 1; r < 16; ++r) u[r] = cx_mul(u[r], w[r]);
+                dft16(u);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int m = bb + NB * q;
+                    // window / N at n = tid + 128 m, from W_N^tid (a register) and the constant W_N^(128 m):
+                    // cos(2 pi n / N) = Re(W_N^tid W_N^(128 m)); two FMAs instead of a table load per sample
+                    constexpr double kA = 6.283185307179586476925286766559 * (double)NT / (double)N;
+                    const float cm = (float)(-0.5 / N * __builtin_cos(kA * m)), sm = (float)(-0.5 / N * __builtin_sin(kA * m));
+                    const float wv = fmaf(wt.x, sgpr_literal(cm), fmaf(wt.y, sgpr_literal(sm), (float)(0.5 / N)));
+                    acc[m] += u[dft16_slot(q)] * wv;                     // conj applied at the store
+                }
+            }
+            __syncthreads();                                             // buf is rewritten by the next frame
+        }
+        // hop-block j = t is complete
+        if (t >= j0) {
+#pragma unroll
+            for (int j = 0; j < NBH; ++j) {
+                const int64_t p = (int64_t)t * HOP + j * NT + tid;
+                const int64_t s = p - N / 2;
+                if (s >= keep_lo && s < keep_hi) {
+                    const int64_t o = b * out_chunk_stride + (s - keep_lo);
+                    if (o < out_limit) {
+                        const float e = 1.0f / env[p];
+                        out[o] = acc[j].x * e;
+                        out[out_ch_stride + o] = -acc[j].y * e;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NA - NBH; ++m) acc[m] = acc[m + NBH];
+#pragma unroll
+        for (int m = NA - NBH; m < NA; ++m) acc[m] = mk(0.f, 0.f);
+    }
+}
+
 }  // namespace r16

@@ -48,3 +48,6 @@ static inline v2f cx_fma_mi(v2f d, v2f s, v2f c) { return v2f{fmaf(s.x, d.y, c.x
 static inline v2f cx_fma_pi(v2f d, v2f s, v2f c) { return v2f{fmaf(-s.x, d.y, c.x), fmaf(s.y, d.x, c.y)}; }
 static inline v2f cx_add_conj(v2f a, v2f b) { return v2f{a.x + b.x, a.y - b.y}; }
 static inline v2f cx_sub_conj_divi(v2f a, v2f b) { return v2f{a.y + b.y, b.x - a.x}; }
+static inline v2f cx_conj_add_pi(v2f a, v2f b) { return v2f{a.x - b.y, -a.y - b.x}; }
+#define ALSEP_WAVES_PER_EU(n)
+static inline float sgpr_literal(float c) { return c; }
