@@ -11,9 +11,11 @@
 //     two-for-one split XL[k] = (Z[k] + conj Z[N-k]) / 2, XR[k] = (Z[k] - conj Z[N-k]) / 2i, so the split needs
 //     no further exchange (thread 0 holds the two self-paired butterflies 0 and 128);
 //   * all complex arithmetic is packed (v_pk_*_f32 on (re, im) pairs, modifiers spelled out in
-//     alsep_gfx950_asm.h), the 1/2 of the split is folded into the window table.
+//     alsep_gfx950_asm.h), the 1/2 of the split is folded into the window.
 // One workgroup = one frame of both channels = 128 threads (2 waves), LDS = n_fft * 8 bytes.
 #pragma once
+
+#include <type_traits>
 
 namespace r16 {
 
@@ -141,7 +143,7 @@ template <> __device__ __forceinline__ void store_bin<bf16_t>(bf16_t* spec, int6
     }
 }
 
-// grid (T, n_chunks), 128 threads.  winh = 0.5 * periodic Hann (the 1/2 of the two-for-one split).
+// grid (T, n_chunks), 128 threads.
 // ABL != 0: timing-only ablations (wrong results): 1 no global loads, 2 no stores, 3 no LDS exchange / barriers,
 // 4 no arithmetic.
 template <int R2, typename OutT, int LAYOUT, int ABL = 0>
@@ -168,47 +170,58 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
     const v2f wB1 = tw[(tid & 15) * (N / 256)], wa1 = tw[ka], wb1 = tw[kb];
 
     // ---- pass A: radix 16, P = 1.  Butterfly i takes x[i + M r] * w[i + M r]; writes row i (16 values).
+    // Thread tid owns the NB consecutive butterflies i = NB tid + bb: its inputs for one r are NB consecutive samples
+    // (one 8- / 12-byte load per channel; 32 loads in flight per thread instead of 96, all under the 63-deep vmcnt).
+    // The window is not loaded: 0.5 w[n] = 1/4 - 1/4 cos(2 pi n / N) and cos(2 pi (i + M r) / N) = Re(W_N^i W_16^r),
+    // W_N^i from the twiddle table (NB loads), W_16^r literals: two FMAs per sample.
     // LDS image after pass A: row i at i*16, its 16-byte granule g (values 2g, 2g+1) at position g ^ (i & 7):
     // conflict-free ds_write_b128 here, conflict-free ds_read_b64 in pass B.
     {
+        typedef float fvec __attribute__((ext_vector_type(NB == 3 ? 3 : 2), aligned(4)));
         v2f u[NB][16];
+        v2f wi[NB];
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) wi[bb] = tw[NB * tid + bb];
         if (ABL == 1) {
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) u[bb][r] = mk((float)(tid + r), (float)(tid * bb));
         } else if (p0 >= 0 && p0 + N <= chunk) {                 // interior frame (wave-uniform)
-            // uniform base (SGPR pair) + 32-bit lane offset + immediate: no per-load 64-bit address arithmetic
-            const unsigned voff = (unsigned)tid * 4u;
+            // uniform base (SGPR pair) + 32-bit lane offset: no per-load 64-bit address arithmetic
+            const unsigned voff = (unsigned)tid * (4u * NB);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const char* sl = reinterpret_cast<const char*>(xl + p0 + M * r);
-                const char* sr = reinterpret_cast<const char*>(xr + p0 + M * r);
-                const char* sw = reinterpret_cast<const char*>(winh + M * r);
+                const fvec l = *reinterpret_cast<const fvec*>(reinterpret_cast<const char*>(xl + p0 + M * r) + voff);
+                const fvec rr = *reinterpret_cast<const fvec*>(reinterpret_cast<const char*>(xr + p0 + M * r) + voff);
 #pragma unroll
-                for (int bb = 0; bb < NB; ++bb) {
-                    const float w = *reinterpret_cast<const float*>(sw + voff + NT * bb * 4);
-                    u[bb][r] = mk(*reinterpret_cast<const float*>(sl + voff + NT * bb * 4) * w,
-                                  *reinterpret_cast<const float*>(sr + voff + NT * bb * 4) * w);
-                }
+                for (int bb = 0; bb < NB; ++bb) u[bb][r] = mk(l[bb], rr[bb]);
             }
         } else {                                                 // reflect padding (center=True)
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int n = tid + NT * bb + M * r;
-                    int p = p0 + n;
+                    int p = p0 + NB * tid + bb + M * r;
                     if (p < 0) p = -p;
                     if (p >= chunk) p = 2 * (chunk - 1) - p;
-                    const float w = winh[n];
-                    u[bb][r] = mk(xl[p] * w, xr[p] * w);
+                    u[bb][r] = mk(xl[p], xr[p]);
                 }
         }
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
+            if (ABL != 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    constexpr double kA = 6.283185307179586476925286766559 / 16.0;
+                    const float cr = (float)(-0.25 * __builtin_cos(kA * r)), sr = (float)(-0.25 * __builtin_sin(kA * r));
+                    // cos(a + b) = cos a cos b - sin a sin b, wi = (cos a, -sin a)
+                    const float w = fmaf(wi[bb].x, cr, fmaf(wi[bb].y, sr, 0.25f));
+                    u[bb][r] *= w;
+                }
+            }
             if (ABL != 4) dft16(u[bb]);
-            const int i = tid + NT * bb;
+            const int i = NB * tid + bb;
             f32x4* row = reinterpret_cast<f32x4*>(buf + i * 16);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
@@ -280,19 +293,23 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
         // bin k2 = kb + 256 q with N - k2 = ka + 256 (R2-1-q)                                [thread 0: kb + ...].
         const bool t0 = tid == 0;
         const int64_t frame_off = (b * T + t) * (int64_t)dim_f;
+        auto emit = [&](auto full) {
 #pragma unroll
-        for (int q = 0; q < R2 / 2; ++q) {
-            const v2f a_q = za[LastDft<R2>::slot(q)], b_q = zb[LastDft<R2>::slot(q)];
-            const v2f a_m = za[LastDft<R2>::slot(R2 - 1 - q)], b_m = zb[LastDft<R2>::slot(R2 - 1 - q)];
-            const v2f a_w = za[LastDft<R2>::slot((R2 - q) % R2)];
-            const v2f n1 = t0 ? a_w : b_m;
-            const v2f n2 = t0 ? b_m : a_m;
-            const int k1 = ka + 256 * q, k2 = kb + 256 * q;
-            if (k1 < dim_f && (ABL != 2 || a_q.x == 123.f))
-                store_bin<OutT>(spec, frame_off, b, k1, T, t, dim_f, LAYOUT, cx_add_conj(a_q, n1), cx_sub_conj_divi(a_q, n1));
-            if (k2 < dim_f && (ABL != 2 || b_q.x == 123.f))
-                store_bin<OutT>(spec, frame_off, b, k2, T, t, dim_f, LAYOUT, cx_add_conj(b_q, n2), cx_sub_conj_divi(b_q, n2));
-        }
+            for (int q = 0; q < R2 / 2; ++q) {
+                const v2f a_q = za[LastDft<R2>::slot(q)], b_q = zb[LastDft<R2>::slot(q)];
+                const v2f a_m = za[LastDft<R2>::slot(R2 - 1 - q)], b_m = zb[LastDft<R2>::slot(R2 - 1 - q)];
+                const v2f a_w = za[LastDft<R2>::slot((R2 - q) % R2)];
+                const v2f n1 = t0 ? a_w : b_m;
+                const v2f n2 = t0 ? b_m : a_m;
+                const int k1 = ka + 256 * q, k2 = kb + 256 * q;
+                if ((decltype(full)::value || k1 < dim_f) && (ABL != 2 || a_q.x == 123.f))
+                    store_bin<OutT>(spec, frame_off, b, k1, T, t, dim_f, LAYOUT, cx_add_conj(a_q, n1), cx_sub_conj_divi(a_q, n1));
+                if ((decltype(full)::value || k2 < dim_f) && (ABL != 2 || b_q.x == 123.f))
+                    store_bin<OutT>(spec, frame_off, b, k2, T, t, dim_f, LAYOUT, cx_add_conj(b_q, n2), cx_sub_conj_divi(b_q, n2));
+            }
+        };
+        if (dim_f >= N / 2) emit(std::true_type());              // every bin below N/2 is kept: no per-bin predicate
+        else emit(std::false_type());
         if (t0 && dim_f > N / 2) {                               // Nyquist bin, self-paired
             const v2f z = za[LastDft<R2>::slot(R2 / 2)];
             store_bin<OutT>(spec, frame_off, b, N / 2, T, t, dim_f, LAYOUT, cx_add_conj(z, z), cx_sub_conj_divi(z, z));
