@@ -537,7 +537,37 @@ extern "C" int alsep_plan_destroy(alsep_plan* plan) {
     return ALSEP_OK;
 }
 
-// ALSEP_STFT_R16=0 falls back to the generic multi-pass kernel for 4096 / 6144 (A/B timing, bit-level cross-check)
+// Hop-blocks per workgroup of the persistent iSTFT kernels.  A workgroup spends run + Q - 1 frames on `run` blocks
+// (Q - 1 warm-up frames re-done by every workgroup), and the grid runs in ceil(workgroups / slots) rounds: pick the
+// run with the smallest rounds x frames (one nearly full round beats two half-empty ones).
+static int istft_pick_run(int n_blocks, int Q, int64_t n_chunks, int slots) {
+    int best = 16;
+    double best_cost = 1e30;
+    for (int run = 4; run <= 64; ++run) {
+        const int64_t wgs = n_chunks * ((n_blocks + run - 1) / run);
+        const int64_t rounds = (wgs + slots - 1) / slots;
+        const double cost = (double)rounds * (run + Q - 1);
+        if (cost < best_cost) { best_cost = cost; best = run; }
+    }
+    return best;
+}
+
+static int device_cu_count(alsep_ctx* ctx) {
+#ifdef ALSEP_CPU_EMUL
+    (void)ctx;
+    return 256;
+#else
+    static const int n = [ctx] {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+#endif
+}
+
+// ALSEP_STFT_R16: 1 (default) three-pass kernel, one frame per workgroup; 3 sliding-window variant (hop 1024);
+// 0 generic multi-pass kernel (A/B timing, cross-check)
 static int stft_r16_enabled() {
     static const int v = [] { const char* e = getenv("ALSEP_STFT_R16"); return e ? atoi(e) : 1; }();
     return v;
@@ -546,9 +576,32 @@ static int stft_r16_enabled() {
 template <int N, typename OutT, int LAYOUT>
 static int launch_stft(alsep_ctx* ctx, const alsep_plan* p, const float* pcm, int64_t ch_stride,
                        int64_t chunk_stride, int64_t n_chunks, void* spec) {
-    const size_t lds = sizeof(float2) * N;
+    size_t lds = sizeof(float2) * N;
     if constexpr (N == 4096 || N == 6144) {
-        if (stft_r16_enabled()) {
+        static const int lds_pad = [] { const char* e = getenv("ALSEP_STFT_LDS_PAD"); return e ? atoi(e) : 0; }();
+        lds += (size_t)lds_pad;                              // occupancy experiment: fewer workgroups per CU
+        if (stft_r16_enabled() == 3 && p->hop == 1024) {     // opt-in: sliding-window kernel (measured slower)
+            constexpr int R2 = N / 256;
+            const size_t lds_s = r16::stft_slide_lds_bytes<R2>();
+            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)r16::stft_slide_kernel<R2, OutT, LAYOUT>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+            ProfScope prof(ctx, ALSEP_PROF_STFT);
+            static const int run_env = [] { const char* e = getenv("ALSEP_STFT_RUN"); return e ? atoi(e) : 0; }();
+            // frames per workgroup: the first frame of a run costs a whole window of loads (weight ~ 1 extra frame)
+            const int run = run_env > 0 ? run_env : istft_pick_run(p->dim_t, 2, n_chunks, 3 * device_cu_count(ctx));
+            const int groups = (p->dim_t + run - 1) / run;
+            for (int64_t b0 = 0; b0 < n_chunks; b0 += 32768) {
+                const int64_t nb = std::min<int64_t>(32768, n_chunks - b0);
+                const int64_t spec_off = b0 * 4 * (int64_t)p->dim_f * p->dim_t;
+                hipLaunchKernelGGL((r16::stft_slide_kernel<R2, OutT, LAYOUT>), dim3(groups, (unsigned)nb),
+                                   dim3(r16::kThreadsSlide), lds_s, ctx->stream, pcm + b0 * chunk_stride, ch_stride,
+                                   chunk_stride, p->chunk, p->dim_f, p->dim_t, run, (const float2*)p->tw,
+                                   (OutT*)spec + spec_off);
+            }
+            ALSEP_LAUNCH_CHECK(ctx, "stft_slide_kernel");
+            return ALSEP_OK;
+        }
+        if (stft_r16_enabled()) {                            // default: one frame per two-wave workgroup
             ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)r16::stft_r16_kernel<N / 256, OutT, LAYOUT>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ProfScope prof(ctx, ALSEP_PROF_STFT);
@@ -614,35 +667,6 @@ extern "C" int alsep_stft(alsep_ctx* ctx, const alsep_plan* plan, const float* p
     ALSEP_FOR_EACH_NFFT(X)
 #undef X
     return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_stft: unsupported n_fft %d", plan->n_fft);
-}
-
-// Hop-blocks per workgroup of the persistent iSTFT kernels.  A workgroup spends run + Q - 1 frames on `run` blocks
-// (Q - 1 warm-up frames re-done by every workgroup), and the grid runs in ceil(workgroups / slots) rounds: pick the
-// run with the smallest rounds x frames (one nearly full round beats two half-empty ones).
-static int istft_pick_run(int n_blocks, int Q, int64_t n_chunks, int slots) {
-    int best = 16;
-    double best_cost = 1e30;
-    for (int run = 4; run <= 64; ++run) {
-        const int64_t wgs = n_chunks * ((n_blocks + run - 1) / run);
-        const int64_t rounds = (wgs + slots - 1) / slots;
-        const double cost = (double)rounds * (run + Q - 1);
-        if (cost < best_cost) { best_cost = cost; best = run; }
-    }
-    return best;
-}
-
-static int device_cu_count(alsep_ctx* ctx) {
-#ifdef ALSEP_CPU_EMUL
-    (void)ctx;
-    return 256;
-#else
-    static const int n = [ctx] {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
-    return n;
-#endif
 }
 
 constexpr int kIstftRun = 32;   // hop-blocks finished per workgroup (warm-up = ceil(N/hop)-1 frames)

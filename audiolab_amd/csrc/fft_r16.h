@@ -318,6 +318,178 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sliding-window STFT for hop = 1024 = 4 * 256 (opt-in, ALSEP_STFT_R16=3: parity-green, measured 15 % slower than the
+// per-frame kernel above -- the hypothesis below did not hold; kept as the record of the experiment).
+//
+// Measured on the per-frame kernel above (profiles/r01_stft_*): with the arithmetic removed it still takes 78 % of
+// its time -- every PCM sample is fetched n_fft / hop = 6 times from L2 (a frame's 48 KiB do not survive in the 32 KiB
+// L1 until the next frame), and a CU takes in only ~11 B/clk of L2 data.  Here a workgroup walks a run of consecutive
+// frames and keeps the raw samples in registers: thread tid (of 256) owns positions n = tid + 256 j (j < R2) of the
+// frame, which are also exactly the inputs of the radix-R2 butterfly i = tid when the passes run in the order
+// R2, 16, 16; the next frame is the same window slid by 4 rows, so each thread fetches 4 new stereo samples per frame
+// (one frame ahead, their latency hidden) instead of R2.  The PCM then crosses L2 -> L1 about once.
+//   pass A  radix R2, P = 1     registers (window from the twiddle register) -> LDS rows of R2 (+1 pad)
+//   pass B  radix 16, P = R2    16 R2 butterflies over 256 threads (threads 0..127 take two when R2 = 24)
+//   pass C  radix 16, P = 16 R2 outputs Z[i + 16 R2 q]; Z[N - k] of the two-for-one split belongs to butterfly
+//                               16 R2 - i, so the upper half of the outputs crosses LDS once more (9 rows)
+// ------------------------------------------------------------------------------------------------
+constexpr int kThreadsSlide = 256;
+template <int R2> constexpr int stft_slide_lds_bytes() { return 256 * (R2 + 1) * 8; }
+
+template <int R2, typename OutT, int LAYOUT>
+__global__ void __launch_bounds__(kThreadsSlide) ALSEP_WAVES_PER_EU(3)
+stft_slide_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_stride, int chunk, int dim_f, int T,
+                  int run, const float2* __restrict__ tw_, OutT* __restrict__ spec) {
+    constexpr int N = 256 * R2, NT = kThreadsSlide, HOP = 1024, HS = HOP / 256;
+    constexpr int M = 16 * R2;                // butterflies of passes B and C (256 or 384)
+    constexpr int NBX = M > NT ? 2 : 1;       // butterflies of the heavy threads
+    constexpr int RS = R2 + 1;
+    static_assert(M == NT || M == NT + 128, "geometry");
+    const v2f* __restrict__ tw = reinterpret_cast<const v2f*>(tw_);
+    v2f* buf = reinterpret_cast<v2f*>(alsep_smem);
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.y;
+    const int t_lo = blockIdx.x * run, t_hi = min(t_lo + run, T);
+    if (t_lo >= t_hi) return;
+    const float* xl = pcm + b * chunk_stride;
+    const float* xr = xl + ch_stride;
+    const bool heavy = NBX == 2 && tid < M - NT;                 // wave-uniform: waves 0 and 1
+    const v2f wt = tw[tid];                                      // W_N^tid: window and pass C of butterfly tid
+
+    // per-butterfly constants of passes B and C
+    int rowB[NBX], dstB[NBX];
+    v2f wB1[NBX], wC1[NBX];
+#pragma unroll
+    for (int bb = 0; bb < NBX; ++bb) {
+        const int i = tid + NT * bb;
+        const int a = i / R2, k = i - a * R2;
+        rowB[bb] = a * RS + k;
+        dstB[bb] = a * M + k;
+        wB1[bb] = tw[k * 16];                                    // W_{16 R2}^k
+        wC1[bb] = bb == 0 ? wt : tw[min(i, N - 1)];              // W_N^i
+    }
+
+    auto sample = [&](int p) -> v2f {                            // reflect padding (center=True)
+        if (p < 0) p = -p;
+        if (p >= chunk) p = 2 * (chunk - 1) - p;
+        return mk(xl[p], xr[p]);
+    };
+    v2f xs[R2];
+    {
+        const int p0 = t_lo * HOP - N / 2 + tid;
+#pragma unroll
+        for (int j = 0; j < R2; ++j) xs[j] = sample(p0 + 256 * j);
+    }
+    for (int t = t_lo; t < t_hi; ++t) {
+        // the HS rows the next frame adds (fetched now, used after this frame's last pass)
+        v2f nx[HS];
+        if (t + 1 < t_hi) {
+            const int p1 = (t + 1) * HOP - N / 2 + tid + 256 * (R2 - HS);
+#pragma unroll
+            for (int j = 0; j < HS; ++j) nx[j] = sample(p1 + 256 * j);
+        }
+        // ---- pass A: butterfly tid
+        {
+            v2f u[R2];
+#pragma unroll
+            for (int j = 0; j < R2; ++j) {
+                constexpr double kA = 6.283185307179586476925286766559 / (double)R2;
+                const float cj = (float)(-0.25 * __builtin_cos(kA * j)), sj = (float)(-0.25 * __builtin_sin(kA * j));
+                // 0.5 Hann(n) = 1/4 - 1/4 cos(2 pi n / N), n = tid + 256 j: cos(a + b) = wt.x cos b + wt.y sin b
+                u[j] = xs[j] * fmaf(wt.x, sgpr_literal(cj), fmaf(wt.y, sgpr_literal(sj), 0.25f));
+            }
+            LastDft<R2>::run(u);
+            v2f* row = buf + tid * RS;
+#pragma unroll
+            for (int q = 0; q < R2; ++q) row[q] = u[LastDft<R2>::slot(q)];
+        }
+        __syncthreads();
+        // ---- pass B
+        {
+            v2f u[NBX][16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[0][r] = buf[rowB[0] + 16 * RS * r];
+            if (heavy) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u[NBX - 1][r] = buf[rowB[NBX - 1] + 16 * RS * r];
+            }
+            __syncthreads();                                     // every read of the pass-A image is done
+            auto bfly = [&](int bb) {
+                v2f w[16];
+                twiddle_powers<16>(wB1[bb], w);
+#pragma unroll
+                for (int r = 1; r < 16; ++r) u[bb][r] = cx_mul(u[bb][r], w[r]);
+                dft16(u[bb]);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) buf[dstB[bb] + R2 * q] = u[bb][dft16_slot(q)];
+            };
+            bfly(0);
+            if (heavy) bfly(NBX - 1);
+        }
+        __syncthreads();
+        // ---- pass C + two-for-one split
+        {
+            v2f z[NBX][16];
+            auto bfly = [&](int bb) {
+                const int i = tid + NT * bb;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[bb][r] = buf[i + M * r];
+                v2f w[16];
+                twiddle_powers<16>(wC1[bb], w);
+#pragma unroll
+                for (int r = 1; r < 16; ++r) z[bb][r] = cx_mul(z[bb][r], w[r]);
+                dft16(z[bb]);
+            };
+            bfly(0);
+            if (heavy) bfly(NBX - 1);
+            __syncthreads();                                     // every read of the pass-B image is done
+            // exchange rows: row j < 8 holds Z[i + M (8 + j)], row 8 holds Z[i] (butterfly 0 pairs M q with M (16 - q))
+            auto put = [&](int bb) {
+                const int i = tid + NT * bb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) buf[j * M + i] = z[bb][dft16_slot(8 + j)];
+                buf[8 * M + i] = z[bb][dft16_slot(0)];
+            };
+            put(0);
+            if (heavy) put(NBX - 1);
+            __syncthreads();
+            const int64_t frame_off = (b * T + t) * (int64_t)dim_f;
+            auto emit = [&](int bb, auto full) {
+                // bin k = i + M q (q < 8) pairs with N - k = (M - i) + M (15 - q): row 7 - q, column M - i;
+                // butterfly 0: N - M q = M (16 - q): row 8 - q, column 0
+                const int i = tid + NT * bb;
+                const v2f* src = buf + (i == 0 ? M : M - i);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const v2f zk = z[bb][dft16_slot(q)];
+                    const v2f zn = src[(7 - q) * M];
+                    const int k = i + M * q;
+                    if (decltype(full)::value || k < dim_f)
+                        store_bin<OutT>(spec, frame_off, b, k, T, t, dim_f, LAYOUT, cx_add_conj(zk, zn), cx_sub_conj_divi(zk, zn));
+                }
+            };
+            if (dim_f >= N / 2) {
+                emit(0, std::true_type());
+                if (heavy) emit(NBX - 1, std::true_type());
+            } else {
+                emit(0, std::false_type());
+                if (heavy) emit(NBX - 1, std::false_type());
+            }
+            if (tid == 0 && dim_f > N / 2) {                     // Nyquist bin N/2 = M * 8, self-paired
+                const v2f zq = z[0][dft16_slot(8)];
+                store_bin<OutT>(spec, frame_off, b, N / 2, T, t, dim_f, LAYOUT, cx_add_conj(zq, zq), cx_sub_conj_divi(zq, zq));
+            }
+        }
+        __syncthreads();                                         // exchange rows are read before the next pass A
+        // slide the window by one hop
+#pragma unroll
+        for (int j = 0; j < R2 - HS; ++j) xs[j] = xs[j + HS];
+#pragma unroll
+        for (int j = 0; j < HS; ++j) xs[R2 - HS + j] = nx[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // iSTFT + overlap-add for n_fft = 256 * R2, hop = 128 * NBH (production: 6144 / 1024).
 //
 // Semantics: ConvTDFNetTrim.istft, mdxnet.py:58-75 (same contract as istft_regring_kernel in fft.hip).
