@@ -100,6 +100,19 @@ __device__ __forceinline__ v2f cx_mul(v2f a, v2f w) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
     return r;
 }
+// The two halves of cx_mul as separate steps.  gfx950 needs one wait state between an op_sel-writing VALU and a dependent
+// VALU, and hipcc pads every asm-to-dependent-asm pair with s_nop; batching the first halves of several products
+// before their second halves (cx_mul_n) leaves no adjacent dependent pair.
+__device__ __forceinline__ v2f cx_mul_p1(v2f a, v2f w) {
+    v2f t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    return t;
+}
+__device__ __forceinline__ v2f cx_mul_p2(v2f a, v2f w, v2f t) {
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
 // a * conj(w) = (a.x w.x + a.y w.y, a.y w.x - a.x w.y)
 __device__ __forceinline__ v2f cx_mul_conj(v2f a, v2f w) {
     v2f t, r;

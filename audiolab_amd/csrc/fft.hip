@@ -29,8 +29,6 @@ struct alsep_plan {
     int chunk = 0;
     float2* tw = nullptr;     // W_N^j = exp(-2*pi*i*j/N), j in [0,N)
     float* win = nullptr;     // periodic Hann window, N floats
-    float* winh = nullptr;    // 0.5 * win (three-pass STFT: the 1/2 of the two-for-one split, exact)
-    float* wini = nullptr;    // win / N (three-pass iSTFT)
     float* env = nullptr;     // sum_t w^2 over the padded chunk timeline, N + hop*(T-1)
     int64_t env_len = 0;
 };
@@ -491,15 +489,13 @@ extern "C" int alsep_plan_create(alsep_ctx* ctx, int n_fft, int hop, int dim_f, 
     alsep_plan* p = new alsep_plan();
     p->ctx = ctx; p->n_fft = n_fft; p->hop = hop; p->dim_f = dim_f; p->dim_t = dim_t; p->chunk = (int)chunk;
     std::vector<float2> tw(n_fft);
-    std::vector<float> win(n_fft), winh(n_fft), wini(n_fft);
+    std::vector<float> win(n_fft);
     std::vector<double> w2(n_fft);
     for (int j = 0; j < n_fft; ++j) {
         const double a = -2.0 * M_PI * (double)j / (double)n_fft;
         tw[j] = make_float2((float)cos(a), (float)sin(a));
         const double w = 0.5 - 0.5 * cos(2.0 * M_PI * (double)j / (double)n_fft);
         win[j] = (float)w;
-        winh[j] = 0.5f * win[j];
-        wini[j] = win[j] * (1.0f / (float)n_fft);
         w2[j] = (double)win[j] * (double)win[j];
     }
     p->env_len = (int64_t)n_fft + (int64_t)hop * (dim_t - 1);
@@ -510,8 +506,6 @@ extern "C" int alsep_plan_create(alsep_ctx* ctx, int n_fft, int hop, int dim_f, 
     for (int64_t i = 0; i < p->env_len; ++i) env[i] = (float)envd[i];
     if (hipMalloc((void**)&p->tw, sizeof(float2) * n_fft) != hipSuccess ||
         hipMalloc((void**)&p->win, sizeof(float) * n_fft) != hipSuccess ||
-        hipMalloc((void**)&p->winh, sizeof(float) * n_fft) != hipSuccess ||
-        hipMalloc((void**)&p->wini, sizeof(float) * n_fft) != hipSuccess ||
         hipMalloc((void**)&p->env, sizeof(float) * p->env_len) != hipSuccess) {
         alsep_plan_destroy(p);
         return alsep_fail(ctx, ALSEP_ERR_NOMEM, "plan tables: hipMalloc failed");
@@ -519,8 +513,6 @@ extern "C" int alsep_plan_create(alsep_ctx* ctx, int n_fft, int hop, int dim_f, 
     // blocking copies on purpose: the host vectors die at return
     ALSEP_HIP(ctx, hipMemcpy(p->tw, tw.data(), sizeof(float2) * n_fft, hipMemcpyHostToDevice));
     ALSEP_HIP(ctx, hipMemcpy(p->win, win.data(), sizeof(float) * n_fft, hipMemcpyHostToDevice));
-    ALSEP_HIP(ctx, hipMemcpy(p->winh, winh.data(), sizeof(float) * n_fft, hipMemcpyHostToDevice));
-    ALSEP_HIP(ctx, hipMemcpy(p->wini, wini.data(), sizeof(float) * n_fft, hipMemcpyHostToDevice));
     ALSEP_HIP(ctx, hipMemcpy(p->env, env.data(), sizeof(float) * p->env_len, hipMemcpyHostToDevice));
     *out = p;
     return ALSEP_OK;
@@ -530,8 +522,6 @@ extern "C" int alsep_plan_destroy(alsep_plan* plan) {
     if (!plan) return ALSEP_OK;
     if (plan->tw) (void)hipFree(plan->tw);
     if (plan->win) (void)hipFree(plan->win);
-    if (plan->winh) (void)hipFree(plan->winh);
-    if (plan->wini) (void)hipFree(plan->wini);
     if (plan->env) (void)hipFree(plan->env);
     delete plan;
     return ALSEP_OK;
@@ -566,8 +556,7 @@ static int device_cu_count(alsep_ctx* ctx) {
 #endif
 }
 
-// ALSEP_STFT_R16: 1 (default) three-pass kernel, one frame per workgroup; 3 sliding-window variant (hop 1024);
-// 0 generic multi-pass kernel (A/B timing, cross-check)
+// ALSEP_STFT_R16=0 falls back to the generic multi-pass kernel for 4096 / 6144 (A/B timing, cross-check)
 static int stft_r16_enabled() {
     static const int v = [] { const char* e = getenv("ALSEP_STFT_R16"); return e ? atoi(e) : 1; }();
     return v;
@@ -576,31 +565,8 @@ static int stft_r16_enabled() {
 template <int N, typename OutT, int LAYOUT>
 static int launch_stft(alsep_ctx* ctx, const alsep_plan* p, const float* pcm, int64_t ch_stride,
                        int64_t chunk_stride, int64_t n_chunks, void* spec) {
-    size_t lds = sizeof(float2) * N;
+    const size_t lds = sizeof(float2) * N;
     if constexpr (N == 4096 || N == 6144) {
-        static const int lds_pad = [] { const char* e = getenv("ALSEP_STFT_LDS_PAD"); return e ? atoi(e) : 0; }();
-        lds += (size_t)lds_pad;                              // occupancy experiment: fewer workgroups per CU
-        if (stft_r16_enabled() == 3 && p->hop == 1024) {     // opt-in: sliding-window kernel (measured slower)
-            constexpr int R2 = N / 256;
-            const size_t lds_s = r16::stft_slide_lds_bytes<R2>();
-            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)r16::stft_slide_kernel<R2, OutT, LAYOUT>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-            ProfScope prof(ctx, ALSEP_PROF_STFT);
-            static const int run_env = [] { const char* e = getenv("ALSEP_STFT_RUN"); return e ? atoi(e) : 0; }();
-            // frames per workgroup: the first frame of a run costs a whole window of loads (weight ~ 1 extra frame)
-            const int run = run_env > 0 ? run_env : istft_pick_run(p->dim_t, 2, n_chunks, 3 * device_cu_count(ctx));
-            const int groups = (p->dim_t + run - 1) / run;
-            for (int64_t b0 = 0; b0 < n_chunks; b0 += 32768) {
-                const int64_t nb = std::min<int64_t>(32768, n_chunks - b0);
-                const int64_t spec_off = b0 * 4 * (int64_t)p->dim_f * p->dim_t;
-                hipLaunchKernelGGL((r16::stft_slide_kernel<R2, OutT, LAYOUT>), dim3(groups, (unsigned)nb),
-                                   dim3(r16::kThreadsSlide), lds_s, ctx->stream, pcm + b0 * chunk_stride, ch_stride,
-                                   chunk_stride, p->chunk, p->dim_f, p->dim_t, run, (const float2*)p->tw,
-                                   (OutT*)spec + spec_off);
-            }
-            ALSEP_LAUNCH_CHECK(ctx, "stft_slide_kernel");
-            return ALSEP_OK;
-        }
         if (stft_r16_enabled()) {                            // default: one frame per two-wave workgroup
             ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)r16::stft_r16_kernel<N / 256, OutT, LAYOUT>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -608,25 +574,9 @@ static int launch_stft(alsep_ctx* ctx, const alsep_plan* p, const float* pcm, in
             for (int64_t b0 = 0; b0 < n_chunks; b0 += 32768) {
                 const int64_t nb = std::min<int64_t>(32768, n_chunks - b0);
                 const int64_t spec_off = b0 * 4 * (int64_t)p->dim_f * p->dim_t;
-                if constexpr (N == 6144 && LAYOUT == ALSEP_LAYOUT_NHWC && sizeof(OutT) == 2) {
-                    static const int abl = [] { const char* e = getenv("ALSEP_STFT_ABLATE"); return e ? atoi(e) : 0; }();
-#define ALSEP_ABL(A_)                                                                                                   \
-    if (abl == A_) {                                                                                                    \
-        hipFuncSetAttribute((const void*)r16::stft_r16_kernel<24, OutT, LAYOUT, A_>,                                    \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
-        hipLaunchKernelGGL((r16::stft_r16_kernel<24, OutT, LAYOUT, A_>), dim3(p->dim_t, (unsigned)nb),                  \
-                           dim3(r16::kThreads), lds, ctx->stream, pcm + b0 * chunk_stride, ch_stride, chunk_stride,     \
-                           p->chunk, p->hop, p->dim_f, p->dim_t, (const float2*)p->tw, (const float*)p->winh,           \
-                           (OutT*)spec + spec_off);                                                                     \
-        continue;                                                                                                       \
-    }
-                    ALSEP_ABL(1) ALSEP_ABL(2) ALSEP_ABL(3) ALSEP_ABL(4)
-#undef ALSEP_ABL
-                }
                 hipLaunchKernelGGL((r16::stft_r16_kernel<N / 256, OutT, LAYOUT>), dim3(p->dim_t, (unsigned)nb),
                                    dim3(r16::kThreads), lds, ctx->stream, pcm + b0 * chunk_stride, ch_stride, chunk_stride,
-                                   p->chunk, p->hop, p->dim_f, p->dim_t, (const float2*)p->tw, (const float*)p->winh,
-                                   (OutT*)spec + spec_off);
+                                   p->chunk, p->hop, p->dim_f, p->dim_t, (const float2*)p->tw, (OutT*)spec + spec_off);
             }
             ALSEP_LAUNCH_CHECK(ctx, "stft_r16_kernel");
             return ALSEP_OK;
@@ -694,7 +644,7 @@ static int launch_istft(alsep_ctx* ctx, const alsep_plan* p, const void* spec, i
                 const int64_t spec_off = b0 * 4 * (int64_t)p->dim_f * p->dim_t;
                 hipLaunchKernelGGL((r16::istft_r16_kernel<R2, 8, InT, LAYOUT>), dim3(groups_r, (unsigned)nb),
                                    dim3(r16::kThreads), lds_r, ctx->stream, (const InT*)spec + spec_off, p->dim_f, p->dim_t,
-                                   (const float2*)p->tw, (const float*)p->wini, (const float*)p->env, j_lo, j_hi, run,
+                                   (const float2*)p->tw, (const float*)p->env, j_lo, j_hi, run,
                                    out + b0 * out_chunk_stride, out_ch_stride, out_chunk_stride, keep_lo, keep_hi,
                                    out_limit - b0 * out_chunk_stride);
             }

@@ -23,6 +23,15 @@ constexpr int kThreads = 128;
 
 __device__ __forceinline__ v2f mk(float x, float y) { v2f r = {x, y}; return r; }
 
+// u[r] *= w[r] for r = FIRST..R-1, first halves of all products before the second halves (see cx_mul_p1)
+template <int R, int FIRST = 1> __device__ __forceinline__ void cx_mul_n(v2f (&u)[R], const v2f (&w)[R]) {
+    v2f t[R];
+#pragma unroll
+    for (int r = FIRST; r < R; ++r) t[r] = cx_mul_p1(u[r], w[r]);
+#pragma unroll
+    for (int r = FIRST; r < R; ++r) u[r] = cx_mul_p2(u[r], w[r], t[r]);
+}
+
 // forward DFT-4 in place: (a, b, c, d) -> (X0, X1, X2, X3)
 __device__ __forceinline__ void dft4(v2f& a, v2f& b, v2f& c, v2f& d) {
     const v2f t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
@@ -51,14 +60,17 @@ __device__ __forceinline__ void dft16(v2f (&u)[16]) {
     for (int r2 = 0; r2 < 4; ++r2) dft4(u[r2], u[4 + r2], u[8 + r2], u[12 + r2]);   // -> A[r2][q1] at u[4 q1 + r2]
     const v2f w1 = mk(R16_C1, -R16_S1), w2 = mk(R16_H, -R16_H), w3 = mk(R16_S1, -R16_C1);
     const v2f w6 = mk(-R16_H, -R16_H), w9 = mk(-R16_C1, R16_S1);
-    u[5] = cx_mul(u[5], w1);    // q1 = 1: r2 = 1, 2, 3 -> W^1, W^2, W^3
-    u[6] = cx_mul(u[6], w2);
-    u[7] = cx_mul(u[7], w3);
-    u[9] = cx_mul(u[9], w2);    // q1 = 2: W^2, W^4 (= -i, folded below), W^6
-    u[11] = cx_mul(u[11], w6);
-    u[13] = cx_mul(u[13], w3);  // q1 = 3: W^3, W^6, W^9
-    u[14] = cx_mul(u[14], w6);
-    u[15] = cx_mul(u[15], w9);
+    // q1 = 1: r2 = 1, 2, 3 -> W^1, W^2, W^3;  q1 = 2: W^2, W^4 (= -i, folded below), W^6;  q1 = 3: W^3, W^6, W^9
+    const v2f t5 = cx_mul_p1(u[5], w1), t6 = cx_mul_p1(u[6], w2), t7 = cx_mul_p1(u[7], w3), t9 = cx_mul_p1(u[9], w2);
+    const v2f t11 = cx_mul_p1(u[11], w6), t13 = cx_mul_p1(u[13], w3), t14 = cx_mul_p1(u[14], w6), t15 = cx_mul_p1(u[15], w9);
+    u[5] = cx_mul_p2(u[5], w1, t5);
+    u[6] = cx_mul_p2(u[6], w2, t6);
+    u[7] = cx_mul_p2(u[7], w3, t7);
+    u[9] = cx_mul_p2(u[9], w2, t9);
+    u[11] = cx_mul_p2(u[11], w6, t11);
+    u[13] = cx_mul_p2(u[13], w3, t13);
+    u[14] = cx_mul_p2(u[14], w6, t14);
+    u[15] = cx_mul_p2(u[15], w9, t15);
     dft4(u[0], u[1], u[2], u[3]);
     dft4(u[4], u[5], u[6], u[7]);
     dft4_c_negi(u[8], u[9], u[10], u[11]);
@@ -70,8 +82,9 @@ __device__ __forceinline__ constexpr int dft16_slot(int q) { return (q & 3) * 4 
 __device__ __forceinline__ void dft8(v2f& u0, v2f& u1, v2f& u2, v2f& u3, v2f& u4, v2f& u5, v2f& u6, v2f& u7) {
     dft4(u0, u2, u4, u6);                  // e0..e3 in u0, u2, u4, u6
     dft4(u1, u3, u5, u7);                  // o0..o3 in u1, u3, u5, u7
-    const v2f o1 = cx_mul(u3, mk(R16_H, -R16_H));
-    const v2f o3 = cx_mul(u7, mk(-R16_H, -R16_H));
+    const v2f c1 = mk(R16_H, -R16_H), c3 = mk(-R16_H, -R16_H);
+    const v2f p1 = cx_mul_p1(u3, c1), p3 = cx_mul_p1(u7, c3);
+    const v2f o1 = cx_mul_p2(u3, c1, p1), o3 = cx_mul_p2(u7, c3, p3);
     const v2f e0 = u0, e1 = u2, e2 = u4, e3 = u6, o0 = u1, o2 = u5;
     u0 = e0 + o0;  u4 = e0 - o0;
     u1 = e1 + o1;  u5 = e1 - o1;
@@ -110,11 +123,21 @@ template <> struct LastDft<24> {
     static __device__ __forceinline__ constexpr int slot(int q) { return in_idx(q % 3, q % 8); }
 };
 
-// w[r] = w1^r for r = 1..R-1, product tree of depth <= log2(R)
+// w[r] = w1^r for r = 1..R-1 by doubling: level by level, w[p + j] = w[p] w[j] (j < p) and w[2p] = w[p]^2 for
+// p = 1, 2, 4, ...; the products of one level are independent (first halves batched before second halves) and every
+// power is at most ceil(log2 R) products away from w1.
 template <int R> __device__ __forceinline__ void twiddle_powers(v2f w1, v2f (&w)[R]) {
     w[1] = w1;
 #pragma unroll
-    for (int r = 2; r < R; ++r) w[r] = (r & 1) ? cx_mul(w[r - 1], w1) : cx_mul(w[r >> 1], w[r >> 1]);
+    for (int p = 1; p < R; p *= 2) {
+        v2f t[2 * 16];
+#pragma unroll
+        for (int j = 1; j <= p; ++j)
+            if (p + j < R) t[j] = cx_mul_p1(w[p], w[j]);
+#pragma unroll
+        for (int j = 1; j <= p; ++j)
+            if (p + j < R) w[p + j] = cx_mul_p2(w[p], w[j], t[j]);
+    }
 }
 
 template <typename OutT> __device__ __forceinline__ void store_bin(OutT* spec, int64_t frame_off, int64_t b, int k,
@@ -144,12 +167,10 @@ template <> __device__ __forceinline__ void store_bin<bf16_t>(bf16_t* spec, int6
 }
 
 // grid (T, n_chunks), 128 threads.
-// ABL != 0: timing-only ablations (wrong results): 1 no global loads, 2 no stores, 3 no LDS exchange / barriers,
-// 4 no arithmetic.
-template <int R2, typename OutT, int LAYOUT, int ABL = 0>
+template <int R2, typename OutT, int LAYOUT>
 __global__ void __launch_bounds__(kThreads)
 stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_stride, int chunk, int hop, int dim_f,
-                int T, const float2* __restrict__ tw_, const float* __restrict__ winh, OutT* __restrict__ spec) {
+                int T, const float2* __restrict__ tw_, OutT* __restrict__ spec) {
     constexpr int N = 256 * R2, NT = kThreads;
     constexpr int M = N / 16;                 // butterflies of passes A and B
     constexpr int NB = M / NT;                // per thread (2 or 3)
@@ -182,12 +203,7 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
         v2f wi[NB];
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) wi[bb] = tw[NB * tid + bb];
-        if (ABL == 1) {
-#pragma unroll
-            for (int bb = 0; bb < NB; ++bb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) u[bb][r] = mk((float)(tid + r), (float)(tid * bb));
-        } else if (p0 >= 0 && p0 + N <= chunk) {                 // interior frame (wave-uniform)
+        if (p0 >= 0 && p0 + N <= chunk) {                        // interior frame (wave-uniform)
             // uniform base (SGPR pair) + 32-bit lane offset: no per-load 64-bit address arithmetic
             const unsigned voff = (unsigned)tid * (4u * NB);
 #pragma unroll
@@ -210,7 +226,7 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
         }
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
-            if (ABL != 1) {
+            {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     constexpr double kA = 6.283185307179586476925286766559 / 16.0;
@@ -220,19 +236,18 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
                     u[bb][r] *= w;
                 }
             }
-            if (ABL != 4) dft16(u[bb]);
+            dft16(u[bb]);
             const int i = NB * tid + bb;
             f32x4* row = reinterpret_cast<f32x4*>(buf + i * 16);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const v2f lo = u[bb][dft16_slot(2 * g)], hi = u[bb][dft16_slot(2 * g + 1)];
                 f32x4 v = {lo.x, lo.y, hi.x, hi.y};
-                if (ABL != 3) row[g ^ (i & 7)] = v;
-                else if (v[0] == 123.f) row[g] = v;
+                row[g ^ (i & 7)] = v;
             }
         }
     }
-    if (ABL != 3) __syncthreads();
+    __syncthreads();
 
     // ---- pass B: radix 16, P = 16.  Butterfly i (k = i & 15) takes logical buf[i + M r] * W_256^(k r) and
     // writes logical (i >> 4) * 256 + 16 q + k (plain layout from here on).
@@ -245,49 +260,41 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
             const int row = i >> 4;                              // (row + (M/16) r) & 7 == row & 7
             const v2f* src = buf + row * 16 + ((((k >> 1) ^ (row & 7)) << 1) | (k & 1));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) u[bb][r] = ABL == 3 ? mk((float)(tid * r), (float)bb) : src[M * r];
+            for (int r = 0; r < 16; ++r) u[bb][r] = src[M * r];
         }
         v2f w[16];
         twiddle_powers<16>(wB1, w);
-        if (ABL != 3) __syncthreads();                           // every read of the pass-A image is done
+        __syncthreads();                           // every read of the pass-A image is done
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
-            if (ABL != 4) {
-#pragma unroll
-                for (int r = 1; r < 16; ++r) u[bb][r] = cx_mul(u[bb][r], w[r]);
-                dft16(u[bb]);
-            }
+            cx_mul_n<16>(u[bb], w);
+            dft16(u[bb]);
             const int i = tid + NT * bb;
             v2f* dst = buf + (i >> 4) * 256 + k;
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-                if (ABL != 3 || u[bb][q].x == 123.f) dst[16 * q] = u[bb][dft16_slot(q)];
+            for (int q = 0; q < 16; ++q) dst[16 * q] = u[bb][dft16_slot(q)];
         }
     }
-    if (ABL != 3) __syncthreads();
+    __syncthreads();
 
     // ---- pass C: radix R2, P = 256.  Thread j: butterflies ka = j and kb = 256 - j (thread 0: 0 and 128).
     {
         v2f za[R2], zb[R2];
 #pragma unroll
-        for (int r = 0; r < R2; ++r) za[r] = ABL == 3 ? mk((float)(tid + r), 1.f) : buf[ka + 256 * r];
+        for (int r = 0; r < R2; ++r) za[r] = buf[ka + 256 * r];
 #pragma unroll
-        for (int r = 0; r < R2; ++r) zb[r] = ABL == 3 ? mk((float)(tid * r), 2.f) : buf[kb + 256 * r];
-        if (ABL != 4) {
+        for (int r = 0; r < R2; ++r) zb[r] = buf[kb + 256 * r];
+        {
             v2f w[R2];
             twiddle_powers<R2>(wa1, w);
-#pragma unroll
-            for (int r = 1; r < R2; ++r) za[r] = cx_mul(za[r], w[r]);
+            cx_mul_n<R2>(za, w);
             LastDft<R2>::run(za);
         }
-        if (ABL != 4) {
+        {
             v2f w[R2];
             twiddle_powers<R2>(wb1, w);
-#pragma unroll
-            for (int r = 1; r < R2; ++r) zb[r] = cx_mul(zb[r], w[r]);
+            cx_mul_n<R2>(zb, w);
             LastDft<R2>::run(zb);
-        } else {
-            za[0] += wa1 + wB1; zb[0] += wb1;
         }
         // Two-for-one split.  Bin k1 = ka + 256 q pairs with N - k1 = kb + 256 (R2-1-q)  [thread 0: 256 (R2-q)],
         // bin k2 = kb + 256 q with N - k2 = ka + 256 (R2-1-q)                                [thread 0: kb + ...].
@@ -302,9 +309,9 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
                 const v2f n1 = t0 ? a_w : b_m;
                 const v2f n2 = t0 ? b_m : a_m;
                 const int k1 = ka + 256 * q, k2 = kb + 256 * q;
-                if ((decltype(full)::value || k1 < dim_f) && (ABL != 2 || a_q.x == 123.f))
+                if ((decltype(full)::value || k1 < dim_f))
                     store_bin<OutT>(spec, frame_off, b, k1, T, t, dim_f, LAYOUT, cx_add_conj(a_q, n1), cx_sub_conj_divi(a_q, n1));
-                if ((decltype(full)::value || k2 < dim_f) && (ABL != 2 || b_q.x == 123.f))
+                if ((decltype(full)::value || k2 < dim_f))
                     store_bin<OutT>(spec, frame_off, b, k2, T, t, dim_f, LAYOUT, cx_add_conj(b_q, n2), cx_sub_conj_divi(b_q, n2));
             }
         };
@@ -314,178 +321,6 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
             const v2f z = za[LastDft<R2>::slot(R2 / 2)];
             store_bin<OutT>(spec, frame_off, b, N / 2, T, t, dim_f, LAYOUT, cx_add_conj(z, z), cx_sub_conj_divi(z, z));
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Sliding-window STFT for hop = 1024 = 4 * 256 (opt-in, ALSEP_STFT_R16=3: parity-green, measured 15 % slower than the
-// per-frame kernel above -- the hypothesis below did not hold; kept as the record of the experiment).
-//
-// Measured on the per-frame kernel above (profiles/r01_stft_*): with the arithmetic removed it still takes 78 % of
-// its time -- every PCM sample is fetched n_fft / hop = 6 times from L2 (a frame's 48 KiB do not survive in the 32 KiB
-// L1 until the next frame), and a CU takes in only ~11 B/clk of L2 data.  Here a workgroup walks a run of consecutive
-// frames and keeps the raw samples in registers: thread tid (of 256) owns positions n = tid + 256 j (j < R2) of the
-// frame, which are also exactly the inputs of the radix-R2 butterfly i = tid when the passes run in the order
-// R2, 16, 16; the next frame is the same window slid by 4 rows, so each thread fetches 4 new stereo samples per frame
-// (one frame ahead, their latency hidden) instead of R2.  The PCM then crosses L2 -> L1 about once.
-//   pass A  radix R2, P = 1     registers (window from the twiddle register) -> LDS rows of R2 (+1 pad)
-//   pass B  radix 16, P = R2    16 R2 butterflies over 256 threads (threads 0..127 take two when R2 = 24)
-//   pass C  radix 16, P = 16 R2 outputs Z[i + 16 R2 q]; Z[N - k] of the two-for-one split belongs to butterfly
-//                               16 R2 - i, so the upper half of the outputs crosses LDS once more (9 rows)
-// ------------------------------------------------------------------------------------------------
-constexpr int kThreadsSlide = 256;
-template <int R2> constexpr int stft_slide_lds_bytes() { return 256 * (R2 + 1) * 8; }
-
-template <int R2, typename OutT, int LAYOUT>
-__global__ void __launch_bounds__(kThreadsSlide) ALSEP_WAVES_PER_EU(3)
-stft_slide_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_stride, int chunk, int dim_f, int T,
-                  int run, const float2* __restrict__ tw_, OutT* __restrict__ spec) {
-    constexpr int N = 256 * R2, NT = kThreadsSlide, HOP = 1024, HS = HOP / 256;
-    constexpr int M = 16 * R2;                // butterflies of passes B and C (256 or 384)
-    constexpr int NBX = M > NT ? 2 : 1;       // butterflies of the heavy threads
-    constexpr int RS = R2 + 1;
-    static_assert(M == NT || M == NT + 128, "geometry");
-    const v2f* __restrict__ tw = reinterpret_cast<const v2f*>(tw_);
-    v2f* buf = reinterpret_cast<v2f*>(alsep_smem);
-    const int tid = threadIdx.x;
-    const int64_t b = blockIdx.y;
-    const int t_lo = blockIdx.x * run, t_hi = min(t_lo + run, T);
-    if (t_lo >= t_hi) return;
-    const float* xl = pcm + b * chunk_stride;
-    const float* xr = xl + ch_stride;
-    const bool heavy = NBX == 2 && tid < M - NT;                 // wave-uniform: waves 0 and 1
-    const v2f wt = tw[tid];                                      // W_N^tid: window and pass C of butterfly tid
-
-    // per-butterfly constants of passes B and C
-    int rowB[NBX], dstB[NBX];
-    v2f wB1[NBX], wC1[NBX];
-#pragma unroll
-    for (int bb = 0; bb < NBX; ++bb) {
-        const int i = tid + NT * bb;
-        const int a = i / R2, k = i - a * R2;
-        rowB[bb] = a * RS + k;
-        dstB[bb] = a * M + k;
-        wB1[bb] = tw[k * 16];                                    // W_{16 R2}^k
-        wC1[bb] = bb == 0 ? wt : tw[min(i, N - 1)];              // W_N^i
-    }
-
-    auto sample = [&](int p) -> v2f {                            // reflect padding (center=True)
-        if (p < 0) p = -p;
-        if (p >= chunk) p = 2 * (chunk - 1) - p;
-        return mk(xl[p], xr[p]);
-    };
-    v2f xs[R2];
-    {
-        const int p0 = t_lo * HOP - N / 2 + tid;
-#pragma unroll
-        for (int j = 0; j < R2; ++j) xs[j] = sample(p0 + 256 * j);
-    }
-    for (int t = t_lo; t < t_hi; ++t) {
-        // the HS rows the next frame adds (fetched now, used after this frame's last pass)
-        v2f nx[HS];
-        if (t + 1 < t_hi) {
-            const int p1 = (t + 1) * HOP - N / 2 + tid + 256 * (R2 - HS);
-#pragma unroll
-            for (int j = 0; j < HS; ++j) nx[j] = sample(p1 + 256 * j);
-        }
-        // ---- pass A: butterfly tid
-        {
-            v2f u[R2];
-#pragma unroll
-            for (int j = 0; j < R2; ++j) {
-                constexpr double kA = 6.283185307179586476925286766559 / (double)R2;
-                const float cj = (float)(-0.25 * __builtin_cos(kA * j)), sj = (float)(-0.25 * __builtin_sin(kA * j));
-                // 0.5 Hann(n) = 1/4 - 1/4 cos(2 pi n / N), n = tid + 256 j: cos(a + b) = wt.x cos b + wt.y sin b
-                u[j] = xs[j] * fmaf(wt.x, sgpr_literal(cj), fmaf(wt.y, sgpr_literal(sj), 0.25f));
-            }
-            LastDft<R2>::run(u);
-            v2f* row = buf + tid * RS;
-#pragma unroll
-            for (int q = 0; q < R2; ++q) row[q] = u[LastDft<R2>::slot(q)];
-        }
-        __syncthreads();
-        // ---- pass B
-        {
-            v2f u[NBX][16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) u[0][r] = buf[rowB[0] + 16 * RS * r];
-            if (heavy) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) u[NBX - 1][r] = buf[rowB[NBX - 1] + 16 * RS * r];
-            }
-            __syncthreads();                                     // every read of the pass-A image is done
-            auto bfly = [&](int bb) {
-                v2f w[16];
-                twiddle_powers<16>(wB1[bb], w);
-#pragma unroll
-                for (int r = 1; r < 16; ++r) u[bb][r] = cx_mul(u[bb][r], w[r]);
-                dft16(u[bb]);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) buf[dstB[bb] + R2 * q] = u[bb][dft16_slot(q)];
-            };
-            bfly(0);
-            if (heavy) bfly(NBX - 1);
-        }
-        __syncthreads();
-        // ---- pass C + two-for-one split
-        {
-            v2f z[NBX][16];
-            auto bfly = [&](int bb) {
-                const int i = tid + NT * bb;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) z[bb][r] = buf[i + M * r];
-                v2f w[16];
-                twiddle_powers<16>(wC1[bb], w);
-#pragma unroll
-                for (int r = 1; r < 16; ++r) z[bb][r] = cx_mul(z[bb][r], w[r]);
-                dft16(z[bb]);
-            };
-            bfly(0);
-            if (heavy) bfly(NBX - 1);
-            __syncthreads();                                     // every read of the pass-B image is done
-            // exchange rows: row j < 8 holds Z[i + M (8 + j)], row 8 holds Z[i] (butterfly 0 pairs M q with M (16 - q))
-            auto put = [&](int bb) {
-                const int i = tid + NT * bb;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) buf[j * M + i] = z[bb][dft16_slot(8 + j)];
-                buf[8 * M + i] = z[bb][dft16_slot(0)];
-            };
-            put(0);
-            if (heavy) put(NBX - 1);
-            __syncthreads();
-            const int64_t frame_off = (b * T + t) * (int64_t)dim_f;
-            auto emit = [&](int bb, auto full) {
-                // bin k = i + M q (q < 8) pairs with N - k = (M - i) + M (15 - q): row 7 - q, column M - i;
-                // butterfly 0: N - M q = M (16 - q): row 8 - q, column 0
-                const int i = tid + NT * bb;
-                const v2f* src = buf + (i == 0 ? M : M - i);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const v2f zk = z[bb][dft16_slot(q)];
-                    const v2f zn = src[(7 - q) * M];
-                    const int k = i + M * q;
-                    if (decltype(full)::value || k < dim_f)
-                        store_bin<OutT>(spec, frame_off, b, k, T, t, dim_f, LAYOUT, cx_add_conj(zk, zn), cx_sub_conj_divi(zk, zn));
-                }
-            };
-            if (dim_f >= N / 2) {
-                emit(0, std::true_type());
-                if (heavy) emit(NBX - 1, std::true_type());
-            } else {
-                emit(0, std::false_type());
-                if (heavy) emit(NBX - 1, std::false_type());
-            }
-            if (tid == 0 && dim_f > N / 2) {                     // Nyquist bin N/2 = M * 8, self-paired
-                const v2f zq = z[0][dft16_slot(8)];
-                store_bin<OutT>(spec, frame_off, b, N / 2, T, t, dim_f, LAYOUT, cx_add_conj(zq, zq), cx_sub_conj_divi(zq, zq));
-            }
-        }
-        __syncthreads();                                         // exchange rows are read before the next pass A
-        // slide the window by one hop
-#pragma unroll
-        for (int j = 0; j < R2 - HS; ++j) xs[j] = xs[j + HS];
-#pragma unroll
-        for (int j = 0; j < HS; ++j) xs[R2 - HS + j] = nx[j];
     }
 }
 
@@ -514,11 +349,10 @@ template <> __device__ __forceinline__ void load_bin<bf16_t>(const bf16_t* p, v2
 template <int R2> constexpr int istft_lds_bytes() { return 256 * (R2 + 1) * 8; }
 
 // grid (n_groups, n_chunks); each workgroup finishes `run` consecutive hop-blocks (as istft_regring_kernel).
-// wini = window / N.
 template <int R2, int NBH, typename InT, int LAYOUT>
 __global__ void __launch_bounds__(kThreads) ALSEP_WAVES_PER_EU(2)
 istft_r16_kernel(const InT* __restrict__ spec, int dim_f, int T, const float2* __restrict__ tw_,
-                 const float* __restrict__ wini, const float* __restrict__ env, int j_lo, int j_hi, int run,
+                 const float* __restrict__ env, int j_lo, int j_hi, int run,
                  float* __restrict__ out, int64_t out_ch_stride, int64_t out_chunk_stride, int64_t keep_lo,
                  int64_t keep_hi, int64_t out_limit) {
     constexpr int N = 256 * R2, NT = kThreads, HOP = 128 * NBH;
@@ -647,8 +481,7 @@ istft_r16_kernel(const InT* __restrict__ spec, int dim_f, int T, const float2* _
                 for (int bb = 0; bb < NB; ++bb) {
                     v2f w[16];
                     twiddle_powers<16>(wB1[bb], w);
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) u[bb][r] = cx_mul(u[bb][r], w[r]);
+                    cx_mul_n<16>(u[bb], w);
                     dft16(u[bb]);
 #pragma unroll
                     for (int q = 0; q < 16; ++q) buf[dstB[bb] + R2 * q] = u[bb][dft16_slot(q)];
@@ -664,8 +497,7 @@ istft_r16_kernel(const InT* __restrict__ spec, int dim_f, int T, const float2* _
                 for (int r = 0; r < 16; ++r) u[r] = buf[tid + NT * bb + M * r];
                 v2f w[16];
                 twiddle_powers<16>(wC1[bb], w);
-#pragma unroll
-                for (int r = 1; r < 16; ++r) u[r] = cx_mul(u[r], w[r]);
+                cx_mul_n<16>(u, w);
                 dft16(u);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {

@@ -51,3 +51,5 @@ static inline v2f cx_sub_conj_divi(v2f a, v2f b) { return v2f{a.y + b.y, b.x - a
 static inline v2f cx_conj_add_pi(v2f a, v2f b) { return v2f{a.x - b.y, -a.y - b.x}; }
 #define ALSEP_WAVES_PER_EU(n)
 static inline float sgpr_literal(float c) { return c; }
+static inline v2f cx_mul_p1(v2f a, v2f w) { return v2f{-(a.y * w.y), a.y * w.x}; }
+static inline v2f cx_mul_p2(v2f a, v2f w, v2f t) { return v2f{fmaf(a.x, w.x, t.x), fmaf(a.x, w.y, t.y)}; }

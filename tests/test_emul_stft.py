@@ -84,3 +84,44 @@ def test_istft_register_ring_hop1024(emul):
     ref = want[:, :, trim:-trim].transpose(1, 0, 2).reshape(2, -1)
     assert np.max(np.abs(st.numpy()[:, :limit] - ref[:, :limit])) < 2e-5 * max(1.0, np.max(np.abs(want)))
     assert float(st[:, limit:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n_fft,dim_f,dim_t", [(6144, 3072, 8), (6144, 3073, 7), (6144, 1000, 8), (4096, 2049, 6), (4096, 2048, 9)])
+def test_three_pass_kernels_production_sizes(emul, n_fft, dim_f, dim_t):
+    """n_fft 4096 / 6144 with hop 1024 take the three-pass kernels of fft_r16.h (radix 16,16,R2 forward with the
+    in-thread two-for-one split; radix R2,16,16 inverse with the in-thread Hermitian extension and the register
+    overlap-add).  Small dim_t keeps both the reflect-padded edge frames and interior frames in play; dim_f covers
+    the full band (Nyquist bin), the production band (n_fft/2) and a narrow band (zero-filled bins)."""
+    from audiolab_amd import _lib
+    from audiolab_amd.mdx import StftPlan
+    plan = StftPlan(emul, n_fft, 1024, dim_f, dim_t)
+    g = mo.MDXGeometry(dim_f, dim_t, n_fft, 1024)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 2, plan.chunk_size)).astype(np.float32)
+    want = mo.stft(x, g)
+    ref = plan.stft_strided(torch.from_numpy(x), plan.chunk_size, 2 * plan.chunk_size, 2, torch.float32, _lib.LAYOUT_REF)
+    nhwc = plan.stft_strided(torch.from_numpy(x), plan.chunk_size, 2 * plan.chunk_size, 2, torch.float32, _lib.LAYOUT_NHWC)
+    assert np.max(np.abs(ref.numpy() - want)) < 3e-6 * np.max(np.abs(want))
+    assert torch.equal(nhwc.permute(0, 3, 2, 1).contiguous(), ref)
+    bf = plan.stft_strided(torch.from_numpy(x), plan.chunk_size, 2 * plan.chunk_size, 2, torch.bfloat16, _lib.LAYOUT_NHWC)
+    assert torch.equal(bf, nhwc.to(torch.bfloat16))
+    # inverse on an arbitrary (non-consistent) spectrogram, plain and stitched stores
+    spec = rng.standard_normal((2, 4, dim_f, dim_t)).astype(np.float32)
+    want_y = mo.istft(spec, g)
+    tol = 2e-5 * max(1.0, float(np.max(np.abs(want_y))))
+    for layout in (_lib.LAYOUT_REF, _lib.LAYOUT_NHWC):
+        sp = torch.from_numpy(spec)
+        if layout == _lib.LAYOUT_NHWC:
+            sp = plan.convert(sp, _lib.LAYOUT_REF)
+        out = emul.empty((2, 2, plan.chunk_size))
+        plan.istft_strided(sp, layout, out, plan.chunk_size, 2 * plan.chunk_size, 0, plan.chunk_size, 3 * plan.chunk_size)
+        assert np.max(np.abs(out.numpy() - want_y)) < tol
+    trim, gen = plan.trim, plan.gen_size
+    if gen > 0:
+        limit = gen + 777
+        st = emul.zeros((2, 2 * gen))
+        plan.istft_strided(plan.convert(torch.from_numpy(spec), _lib.LAYOUT_REF), _lib.LAYOUT_NHWC, st, 2 * gen, gen, trim,
+                           plan.chunk_size - trim, limit)
+        want_s = want_y[:, :, trim:-trim].transpose(1, 0, 2).reshape(2, -1)
+        assert np.max(np.abs(st.numpy()[:, :limit] - want_s[:, :limit])) < tol
+        assert float(st[:, limit:].abs().max()) == 0.0
