@@ -245,9 +245,13 @@ def main() -> None:
         else:
             alg = spec_bytes + 3 * 2 * plan.chunk_size * 4                 # spec read + acc/div read-modify-write
         gbs = alg * nb * reps / (ms * 1e-3) / 1e9
+        # PMC HBM bytes per launch of the stage's kernel, scaled to this launch's chunk count (the committed pass ran
+        # the same 52-chunk launches; traffic is linear in the chunk count)
+        tr = pmc_traffic("stft_r16_kernel" if name == "stft" else "istft_r16_kernel") if cfg.n_fft in (4096, 6144) else None
         stages[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(gbs / PEAK_HBM_GBS, 4), "bytes_per_chunk": alg, "chunks_per_launch": nb,
-                        "us_per_launch": round(ms * 1e3 / max(launches, 1), 2), "traffic": None}
+                        "us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
+                        "traffic": None if tr is None else tr * nb / 52.0, "algorithmic_bytes_per_launch": alg * nb}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
