@@ -126,16 +126,29 @@ class Separator:
 
     # -- inference --------------------------------------------------------------------------------
     def separate_array(self, mix) -> Dict[str, torch.Tensor]:
-        """mix [C,N] (numpy or tensor; mono is duplicated, >2 channels rejected) -> {stem label: [2,N] device tensor}."""
+        """mix [C,N] (numpy or tensor) -> {stem label: [C,N] device tensor}.  Mono is duplicated to stereo (and comes
+        back as [2,N], as the reference's loaders do); more than two channels are separated as consecutive stereo pairs
+        (BASELINE configs[4]: 8-channel long-form), an odd last channel as a duplicated pair."""
         if self.model_instance is None:
             raise AlsepError("load_model() first")
         m = torch.as_tensor(mix, dtype=torch.float32)
         if m.dim() == 1:
             m = torch.stack([m, m])
+        if m.dim() != 2:
+            raise AlsepError("separate_array expects [channels, samples]")
         if m.shape[0] == 1:
             m = torch.cat([m, m])
-        if m.shape[0] != 2:
-            raise AlsepError("MDX-Net models are stereo; split other layouts into stereo pairs")
+        if m.shape[0] > 2:
+            c = m.shape[0]
+            parts: Dict[str, List[torch.Tensor]] = {}
+            for c0 in range(0, c, 2):
+                pair = m[c0:c0 + 2] if c0 + 2 <= c else torch.cat([m[c0:c0 + 1], m[c0:c0 + 1]])
+                for label, t in self._separate_pair(pair).items():
+                    parts.setdefault(label, []).append(t if c0 + 2 <= c else t[:1])
+            return {label: torch.cat(ts) for label, ts in parts.items()}
+        return self._separate_pair(m)
+
+    def _separate_pair(self, m: torch.Tensor) -> Dict[str, torch.Tensor]:
         m = m.to(self.ctx.device).contiguous()
         inst = self.model_instance
         primary = inst.predictor.demix(m)

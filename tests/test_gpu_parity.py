@@ -195,3 +195,37 @@ def test_empty_and_tiny_inputs(ctx):
     assert out.shape == (1, 2, 1000) and float(out.abs().max()) == 0.0
     with pytest.raises(Exception):
         pred.demix(torch.zeros((3, 1000), device="cuda"))
+
+
+def test_long_form_8ch_ola_075(ctx):
+    """BASELINE configs[4] shape at reduced length: 8 channels (four stereo pairs), Hann overlap-add at overlap 0.75,
+    production STFT geometry (n_fft 6144, hop 1024, dim_t 256).  Parity vs the oracle with a linear stand-in network in
+    fp32; then the property the overlap-add offers at any length: with an identity network and compensate 1 the runner
+    returns the mix with bins 0-2 and >= dim_f removed, so two runs at different overlaps agree."""
+    from audiolab_amd.mdx import OlaRunner
+    from audiolab_amd.synth import synth_mix
+    from audiolab_amd.tdfnet import TDFNetConfig
+    from oracle import mdx_oracle as mo
+    from oracle import toy
+    cfg = TDFNetConfig(dim_f=3072, dim_t=256, n_fft=6144)
+    g = mo.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
+
+    class Lin:
+        def __init__(self, fn):
+            self.cfg, self.ctx, self.dtype, self.fn = cfg, ctx, torch.float32, fn
+
+        def forward_nhwc(self, spek, denoise=False):          # [B,T,F,4] -> same; the toy nets are written for [B,4,F,T]
+            return self.fn(spek.permute(0, 3, 2, 1)).permute(0, 3, 2, 1).contiguous()
+    n = 600000                                               # 13.6 s per channel
+    mix8 = np.concatenate([synth_mix(n, seed=80 + c) for c in range(4)])
+    runner = OlaRunner(Lin(toy_lin), ctx=ctx, overlap=0.75, compensate=1.0, max_batch=4)
+    for c0 in (0, 6):
+        pair = mix8[c0:c0 + 2]
+        got = runner.demix(torch.from_numpy(pair).cuda()).cpu().numpy()
+        want = mo.demix_ola(pair, g, toy.toy_net, overlap=0.75, denoise=False, zero_low_bins=3, compensate=1.0)
+        assert np.max(np.abs(got - want)) < 1e-4
+    ident = lambda s: s
+    a = OlaRunner(Lin(ident), ctx=ctx, overlap=0.75, compensate=1.0, max_batch=8).demix(torch.from_numpy(mix8[2:4]).cuda())
+    b = OlaRunner(Lin(ident), ctx=ctx, overlap=0.25, compensate=1.0, max_batch=8).demix(torch.from_numpy(mix8[2:4]).cuda())
+    lo, hi = 300000 - 100000, 300000 + 100000               # interior: every sample fully covered at both overlaps
+    assert float((a[:, lo:hi] - b[:, lo:hi]).abs().max()) < 1e-4
