@@ -1476,7 +1476,6 @@ tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const
 // Weights are packed in fragment order [m-tile][k-step][lane][8].
 // ------------------------------------------------------------------------------------------
 struct Ds48 { static constexpr int C = 48, M = 96, K = 192, MT = 6, KS = 6; };
-struct Us48 { static constexpr int C = 96, C2 = 48, K = 96, MT = 3, KS = 3; };
 
 __global__ void __launch_bounds__(kThreads, 1)
 ds48_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wf,
@@ -1538,11 +1537,96 @@ ds48_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const b
     }
 }
 
+// ds for the deeper levels (C -> C + 48, C = 96): the weight block no longer fits one wave's registers, so the four
+// waves of a workgroup share a tile of 64 output pixels and split the OUTPUT channels (m-tiles w, w + 4, w + 8): each
+// keeps its 16-row weight fragments in registers for its whole life and streams the same activation fragments from
+// global memory (the re-read by the other three waves is served by L1); the epilogue goes through one LDS image of the
+// tile so that it leaves as whole contiguous rows.
+template <int C_> struct DsSplitCfg {
+    static constexpr int C = C_, M = C_ + 48, K = 4 * C_, MT = M / 16, KS = K / 32, MTW = (MT + 3) / 4;
+    static_assert(M % 16 == 0 && K % 32 == 0, "ds stream geometry");
+};
+template <int C_>
 __global__ void __launch_bounds__(kThreads, 1)
-us48_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wf,
-                   const float* __restrict__ scale, const float* __restrict__ shift, const bf16_t* __restrict__ skip,
-                   int64_t npix, int Tp, int Fp) {
-    typedef Us48 U;
+ds_split_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wf,
+                       const float* __restrict__ scale, const float* __restrict__ shift, int64_t npix, int Tp, int Fp) {
+    typedef DsSplitCfg<C_> D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    bf16_t* stg = reinterpret_cast<bf16_t*>(alsep_smem);                                // [64 px][M ch]
+    bf16x8 wf[D::MTW][D::KS];
+    float sc[D::MTW][4], sh[D::MTW][4];
+#pragma unroll
+    for (int j = 0; j < D::MTW; ++j) {
+        const int mt = wave + 4 * j;
+#pragma unroll
+        for (int ks = 0; ks < D::KS; ++ks)
+            wf[j][ks] = mt < D::MT ? *reinterpret_cast<const bf16x8*>(Wf + ((size_t)(mt * D::KS + ks) * 64 + lane) * 8) : bf16x8{};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[j][r] = mt < D::MT ? scale[mt * 16 + 4 * lq + r] : 0.f;
+            sh[j][r] = mt < D::MT ? shift[mt * 16 + 4 * lq + r] : 0.f;
+        }
+    }
+    const int64_t ntile = npix / 64;                         // Fp % 64 == 0: a tile is 64 consecutive f' of one row
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int64_t p0 = tile * 64;
+        const int64_t fp0 = p0 % Fp, tp = (p0 / Fp) % Tp, bb = p0 / ((int64_t)Fp * Tp);
+        // input pixel (2tp + dy, 2(fp0 + j) + dx): k = (dy*2 + dx)*C + ci -> two runs of 2C per dy
+        const bf16_t* xrow = X + ((bb * 2 * Tp + 2 * tp) * (2 * (int64_t)Fp) + 2 * fp0) * D::C;
+        f32x4 acc[D::MTW][4];
+#pragma unroll
+        for (int j = 0; j < D::MTW; ++j)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[j][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < D::KS; ++ks) {
+            const int k = ks * 32 + lq * 8;
+            const int dy = k / (2 * D::C), rem = k % (2 * D::C);
+            bf16x8 xf[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                xf[ni] = *reinterpret_cast<const bf16x8*>(xrow + (int64_t)dy * (2 * (int64_t)Fp * D::C) + (int64_t)(ni * 16 + l15) * (2 * D::C) + rem);
+#pragma unroll
+            for (int j = 0; j < D::MTW; ++j)
+                if (wave + 4 * j < D::MT) {                  // wave-uniform
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) mma_step(acc[j][ni], wf[j][ks], xf[ni]);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < D::MTW; ++j) {
+            const int mt = wave + 4 * j;
+            if (mt < D::MT) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    float y[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[j][ni][r], sc[j][r], sh[j][r]), 0.f);
+                    store4(stg + (ni * 16 + l15) * D::M + mt * 16 + 4 * lq, y);
+                }
+            }
+        }
+        __syncthreads();
+        bf16_t* yrow = Y + p0 * D::M;                        // 64 pixels x M channels, contiguous
+        for (int it = tid; it < 64 * D::M / 8; it += kThreads)
+            *reinterpret_cast<vec16*>(yrow + (size_t)it * 8) = *reinterpret_cast<const vec16*>(stg + (size_t)it * 8);
+        __syncthreads();
+    }
+}
+
+// Us<CIN, C2>: CIN input channels -> C2 output channels per tap; K = CIN padded to a multiple of 32 (the fragment of
+// the padded k-groups is zero on both sides: weights packed with zeros, activations not loaded).
+template <int CIN, int C2_> struct UsCfg {
+    static constexpr int C = CIN, C2 = C2_, MT = C2_ / 16, KS = (CIN + 31) / 32;
+    static_assert(C2_ % 16 == 0 && CIN % 8 == 0, "us stream geometry");
+};
+template <int CIN, int C2_>
+__global__ void __launch_bounds__(kThreads, 1)
+us_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wf,
+                 const float* __restrict__ scale, const float* __restrict__ shift, const bf16_t* __restrict__ skip,
+                 int64_t npix, int Tp, int Fp) {
+    typedef UsCfg<CIN, C2_> U;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int dy = wave >> 1, dx = wave & 1;                 // this wave's tap of the 2x2 transposed kernel
@@ -1571,8 +1655,12 @@ us48_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const b
         for (int ks = 0; ks < U::KS; ++ks) {
             bf16x8 xf[4];
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                xf[ni] = *reinterpret_cast<const bf16x8*>(X + (p0 + ni * 16 + l15) * U::C + ks * 32 + lq * 8);
+            for (int ni = 0; ni < 4; ++ni) {
+                if (U::C % 32 == 0 || ks * 32 + lq * 8 < U::C)
+                    xf[ni] = *reinterpret_cast<const bf16x8*>(X + (p0 + ni * 16 + l15) * U::C + ks * 32 + lq * 8);
+                else
+                    xf[ni] = bf16x8{};                           // k-groups beyond CIN: zero weights, nothing to read
+            }
 #pragma unroll
             for (int mt = 0; mt < U::MT; ++mt)
 #pragma unroll
@@ -1589,11 +1677,12 @@ us48_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const b
                 *reinterpret_cast<f32x4*>(stg + ((size_t)dy * 128 + 2 * (ni * 16 + l15) + dx) * U::C2 + mt * 16 + 4 * lq) = y;
             }
         __syncthreads();
-        // 2 rows x 128 pixels x 6 groups of 8 channels; output rows are contiguous (128 x 96 B)
+        // 2 rows x 128 pixels x C2/8 groups of 8 channels; output rows are contiguous (128 x 2 C2 bytes)
+        constexpr int NG = U::C2 / 8;
 #pragma unroll
-        for (int it = 0; it < 2 * 128 * 6 / kThreads; ++it) {
+        for (int it = 0; it < 2 * 128 * NG / kThreads; ++it) {
             const int gidx = it * kThreads + tid;
-            const int row = gidx / (128 * 6), rem = gidx % (128 * 6);
+            const int row = gidx / (128 * NG), rem = gidx % (128 * NG);
             const int64_t o = ((bb * 2 * Tp + 2 * tp + row) * (2 * (int64_t)Fp) + 2 * fp0) * U::C2 + (int64_t)rem * 8;
             const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + (size_t)row * 128 * U::C2 + (size_t)rem * 8);
             const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + (size_t)row * 128 * U::C2 + (size_t)rem * 8 + 4);
@@ -1625,7 +1714,7 @@ struct GemmLayer {       // ds / us / tdf
     int M = 0, K = 0, Kp = 0, Mp = 0;
     bool has_bias = false;
     bool dma_path = false;   // packed for tdf_bf16_kernel
-    DevBuf wfrag;            // [m-tile][k-step][lane][8] for the streaming ds/us kernels (bf16, level 0 <-> 1 only)
+    DevBuf wfrag;            // [m-tile][k-step][lane][8] for the streaming ds/us kernels (bf16, levels 0 <-> 1 <-> 2)
     DevBuf wwide;            // fragment-order image for tdf_bf16_wide_kernel (bf16, M % 192 == 0)
 };
 struct Block {
@@ -1896,7 +1985,7 @@ int build_net(alsep_net* net, const TensorMap& tm) {
             for (int ci = 0; ci < c; ++ci)
                 for (int d = 0; d < 4; ++d) mk[(size_t)co * 4 * c + d * c + ci] = (*w)[((size_t)co * c + ci) * 4 + d];
         if ((rc = make_gemm_weights<T>(net, mk, c2, 4 * c, &net->ds[i]))) return rc;
-        if (is_bf16<T>() && c == 48 && c2 == 96 && (rc = make_frag_weights(net, mk, c2, 4 * c, &net->ds[i].wfrag))) return rc;
+        if (is_bf16<T>() && (c == 48 || c == 96) && (rc = make_frag_weights(net, mk, c2, 4 * c, &net->ds[i].wfrag))) return rc;
         if ((rc = upload(net, sc->data(), c2 * 4, &net->ds[i].scale))) return rc;
         if ((rc = upload(net, sh->data(), c2 * 4, &net->ds[i].shift))) return rc;
         c = c2; f /= 2;
@@ -1917,7 +2006,7 @@ int build_net(alsep_net* net, const TensorMap& tm) {
         for (int d = 0; d < 4; ++d)
             for (int co = 0; co < c2; ++co) { sc4[d * c2 + co] = (*sc)[co]; sh4[d * c2 + co] = (*sh)[co]; }
         if ((rc = make_gemm_weights<T>(net, mk, 4 * c2, c, &net->us[i]))) return rc;
-        if (is_bf16<T>() && c == 96 && c2 == 48 && (rc = make_frag_weights(net, mk, 4 * c2, c, &net->us[i].wfrag))) return rc;
+        if (is_bf16<T>() && (c == 96 || c == 144) && (rc = make_frag_weights(net, mk, 4 * c2, c, &net->us[i].wfrag))) return rc;
         if ((rc = upload(net, sc4.data(), sc4.size() * 4, &net->us[i].scale))) return rc;
         if ((rc = upload(net, sh4.data(), sh4.size() * 4, &net->us[i].shift))) return rc;
         c = c2; f *= 2;
@@ -2094,16 +2183,28 @@ int run_pix_stream(alsep_ctx* ctx, int mode, const GemmLayer& L, const bf16_t* X
                    int Tp, int Fp) {
     ProfScope prof(ctx, ALSEP_PROF_PIX);
     const int64_t ntile = ncols / 64;
-    if (mode == PIX_DS) {
+    if (mode == PIX_DS && L.M == Ds48::M) {
         const size_t lds = 4 * 64 * Ds48::M * sizeof(bf16_t);
         const int64_t gx = std::min<int64_t>(ceil_div64(ntile, 4), 256);
         hipLaunchKernelGGL(ds48_stream_kernel, dim3((unsigned)gx), dim3(kThreads), lds, ctx->stream, X, Y, (const bf16_t*)L.wfrag.p,
                            (const float*)L.scale.p, (const float*)L.shift.p, ncols, Tp, Fp);
-    } else {
-        const size_t lds = 2 * 128 * Us48::C2 * sizeof(float);
+    } else if (mode == PIX_DS) {                             // 96 -> 144
+        const size_t lds = 64 * DsSplitCfg<96>::M * sizeof(bf16_t);
         const int64_t gx = std::min<int64_t>(ntile, 512);
-        hipLaunchKernelGGL(us48_stream_kernel, dim3((unsigned)gx), dim3(kThreads), lds, ctx->stream, X, Y, (const bf16_t*)L.wfrag.p,
-                           (const float*)L.scale.p, (const float*)L.shift.p, skip, ncols, Tp, Fp);
+        hipLaunchKernelGGL(ds_split_stream_kernel<96>, dim3((unsigned)gx), dim3(kThreads), lds, ctx->stream, X, Y,
+                           (const bf16_t*)L.wfrag.p, (const float*)L.scale.p, (const float*)L.shift.p, ncols, Tp, Fp);
+    } else if (L.K == 96) {                                  // us 96 -> 48
+        const size_t lds = 2 * 128 * 48 * sizeof(float);
+        const int64_t gx = std::min<int64_t>(ntile, 512);
+        hipLaunchKernelGGL((us_stream_kernel<96, 48>), dim3((unsigned)gx), dim3(kThreads), lds, ctx->stream, X, Y,
+                           (const bf16_t*)L.wfrag.p, (const float*)L.scale.p, (const float*)L.shift.p, skip, ncols, Tp, Fp);
+    } else {                                                 // us 144 -> 96
+        const size_t lds = 2 * 128 * 96 * sizeof(float);
+        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)us_stream_kernel<144, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds));
+        const int64_t gx = std::min<int64_t>(ntile, 256);
+        hipLaunchKernelGGL((us_stream_kernel<144, 96>), dim3((unsigned)gx), dim3(kThreads), lds, ctx->stream, X, Y,
+                           (const bf16_t*)L.wfrag.p, (const float*)L.scale.p, (const float*)L.shift.p, skip, ncols, Tp, Fp);
     }
     ALSEP_LAUNCH_CHECK(ctx, "pix stream kernel");
     return ALSEP_OK;

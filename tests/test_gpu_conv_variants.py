@@ -30,9 +30,9 @@ np.save(sys.argv[1], np.stack(outs))
 """
 
 
-def run_mode(mode, path):
+def run_mode(mode, path, **extra):
     regw, pipe, big = mode
-    env = dict(os.environ, ALSEP_CONV_REGW=str(regw), ALSEP_CONV_PIPE=str(pipe), ALSEP_CONV_BIG=str(big))
+    env = dict(os.environ, ALSEP_CONV_REGW=str(regw), ALSEP_CONV_PIPE=str(pipe), ALSEP_CONV_BIG=str(big), **extra)
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}, path], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     return np.load(path)
@@ -44,3 +44,12 @@ def test_persistent_conv_bit_identical(tmp_path):
     for mode in ((1, 0, 0), (2, 0, 0), (0, 1, 0), (1, 1, 0), (1, 0, 1), (0, 0, 2)):   # register-weight / pipelined / big-tile
         got = run_mode(mode, str(tmp_path / ("m%d%d%d.npy" % mode)))
         assert np.array_equal(base, got), f"REGW,PIPE,BIG={mode}: max diff {np.abs(base - got).max()}"
+
+
+def test_streaming_ds_us_match_tile_gemm(tmp_path):
+    """The register-weight streaming ds / us kernels (48<->96 and 96<->144 channels) against the generic tile GEMM on the
+    same layers: same bf16 MFMA and the same k order, so the results must agree bit for bit."""
+    base = run_mode((1, 0, 1), str(tmp_path / "s0.npy"), ALSEP_PIX_STREAM="0")
+    got = run_mode((1, 0, 1), str(tmp_path / "s1.npy"), ALSEP_PIX_STREAM="1")
+    assert np.isfinite(base).all() and np.abs(base).max() > 1e-3
+    assert np.array_equal(base, got), f"max diff {np.abs(base - got).max()} (peak {np.abs(base).max()})"
