@@ -1546,8 +1546,8 @@ template <int C_> struct DsSplitCfg {
     static constexpr int C = C_, M = C_ + 48, K = 4 * C_, MT = M / 16, KS = K / 32, MTW = (MT + 3) / 4;
     static_assert(M % 16 == 0 && K % 32 == 0, "ds stream geometry");
 };
-template <int C_>
-__global__ void __launch_bounds__(kThreads, 1)
+template <int C_, int OCC>
+__global__ void __launch_bounds__(kThreads, OCC)
 ds_split_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wf,
                        const float* __restrict__ scale, const float* __restrict__ shift, int64_t npix, int Tp, int Fp) {
     typedef DsSplitCfg<C_> D;
@@ -1555,18 +1555,12 @@ ds_split_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, con
     const int l15 = lane & 15, lq = lane >> 4;
     bf16_t* stg = reinterpret_cast<bf16_t*>(alsep_smem);                                // [64 px][M ch]
     bf16x8 wf[D::MTW][D::KS];
-    float sc[D::MTW][4], sh[D::MTW][4];
 #pragma unroll
     for (int j = 0; j < D::MTW; ++j) {
         const int mt = wave + 4 * j;
 #pragma unroll
         for (int ks = 0; ks < D::KS; ++ks)
             wf[j][ks] = mt < D::MT ? *reinterpret_cast<const bf16x8*>(Wf + ((size_t)(mt * D::KS + ks) * 64 + lane) * 8) : bf16x8{};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sc[j][r] = mt < D::MT ? scale[mt * 16 + 4 * lq + r] : 0.f;
-            sh[j][r] = mt < D::MT ? shift[mt * 16 + 4 * lq + r] : 0.f;
-        }
     }
     const int64_t ntile = npix / 64;                         // Fp % 64 == 0: a tile is 64 consecutive f' of one row
     for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
@@ -1598,11 +1592,13 @@ ds_split_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, con
         for (int j = 0; j < D::MTW; ++j) {
             const int mt = wave + 4 * j;
             if (mt < D::MT) {
+                const f32x4 scv = *reinterpret_cast<const f32x4*>(scale + mt * 16 + 4 * lq);   // L1-resident, once per tile
+                const f32x4 shv = *reinterpret_cast<const f32x4*>(shift + mt * 16 + 4 * lq);
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     float y[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[j][ni][r], sc[j][r], sh[j][r]), 0.f);
+                    for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[j][ni][r], scv[r], shv[r]), 0.f);
                     store4(stg + (ni * 16 + l15) * D::M + mt * 16 + 4 * lq, y);
                 }
             }
@@ -1615,47 +1611,54 @@ ds_split_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, con
     }
 }
 
-// Us<CIN, C2>: CIN input channels -> C2 output channels per tap; K = CIN padded to a multiple of 32 (the fragment of
-// the padded k-groups is zero on both sides: weights packed with zeros, activations not loaded).
-template <int CIN, int C2_> struct UsCfg {
-    static constexpr int C = CIN, C2 = C2_, MT = C2_ / 16, KS = (CIN + 31) / 32;
-    static_assert(C2_ % 16 == 0 && CIN % 8 == 0, "us stream geometry");
+// Us<CIN, C2, NI>: CIN input channels -> C2 output channels per tap, tiles of 16 NI input pixels; K = CIN padded to a
+// multiple of 32 (the fragment of the padded k-groups is zero on both sides: weights packed with zeros, activations not
+// loaded).  Wave w owns tap (dy, dx) = (w >> 1, w & 1) of the 2x2 transposed kernel.
+template <int CIN, int C2_, int NI_> struct UsCfg {
+    static constexpr int C = CIN, C2 = C2_, NI = NI_, PX = 16 * NI_, MT = C2_ / 16, KS = (CIN + 31) / 32;
+    static constexpr size_t lds_bytes = 2 * (size_t)(2 * PX) * C2_ * sizeof(float);   // [dy][2 PX output pixels][C2] fp32
+    static_assert(C2_ % 16 == 0 && CIN % 8 == 0 && (2 * 2 * PX * (C2_ / 8)) % kThreads == 0, "us stream geometry");
 };
-template <int CIN, int C2_>
-__global__ void __launch_bounds__(kThreads, 1)
+template <int CIN, int C2_, int NI_, int OCC = 1>
+__global__ void __launch_bounds__(kThreads, OCC)
 us_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wf,
                  const float* __restrict__ scale, const float* __restrict__ shift, const bf16_t* __restrict__ skip,
                  int64_t npix, int Tp, int Fp) {
-    typedef UsCfg<CIN, C2_> U;
+    typedef UsCfg<CIN, C2_, NI_> U;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int dy = wave >> 1, dx = wave & 1;                 // this wave's tap of the 2x2 transposed kernel
-    float* stg = reinterpret_cast<float*>(alsep_smem);       // [dy][128 output pixels][48 ch] fp32 = 48 KiB
+    const int dy = wave >> 1, dx = wave & 1;
+    float* stg = reinterpret_cast<float*>(alsep_smem);
     bf16x8 wf[U::MT][U::KS];
 #pragma unroll
     for (int mt = 0; mt < U::MT; ++mt)
 #pragma unroll
         for (int ks = 0; ks < U::KS; ++ks)
             wf[mt][ks] = *reinterpret_cast<const bf16x8*>(Wf + ((size_t)((wave * U::MT + mt) * U::KS + ks) * 64 + lane) * 8);
-    float sc[U::MT][4], sh[U::MT][4];
+    // scale / shift of this lane's rows: registers while they fit beside the weight fragments, L1 otherwise
+    constexpr bool SS_REGS = U::MT <= 3;
+    constexpr int SSN = SS_REGS ? U::MT : 1;
+    float sc[SSN][4], sh[SSN][4];
+    if (SS_REGS) {
 #pragma unroll
-    for (int mt = 0; mt < U::MT; ++mt)
+        for (int mt = 0; mt < SSN; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { sc[mt][r] = scale[mt * 16 + 4 * lq + r]; sh[mt][r] = shift[mt * 16 + 4 * lq + r]; }
-    const int64_t ntile = npix / 64;
+            for (int r = 0; r < 4; ++r) { sc[mt][r] = scale[mt * 16 + 4 * lq + r]; sh[mt][r] = shift[mt * 16 + 4 * lq + r]; }
+    }
+    const int64_t ntile = npix / U::PX;                      // Fp % PX == 0: a tile is PX consecutive f' of one row
     for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        const int64_t p0 = tile * 64;
+        const int64_t p0 = tile * U::PX;
         const int64_t fp0 = p0 % Fp, tp = (p0 / Fp) % Tp, bb = p0 / ((int64_t)Fp * Tp);
-        f32x4 acc[U::MT][4];
+        f32x4 acc[U::MT][U::NI];
 #pragma unroll
         for (int mt = 0; mt < U::MT; ++mt)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mt][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ni = 0; ni < U::NI; ++ni) acc[mt][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < U::KS; ++ks) {
-            bf16x8 xf[4];
+            bf16x8 xf[U::NI];
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
+            for (int ni = 0; ni < U::NI; ++ni) {
                 if (U::C % 32 == 0 || ks * 32 + lq * 8 < U::C)
                     xf[ni] = *reinterpret_cast<const bf16x8*>(X + (p0 + ni * 16 + l15) * U::C + ks * 32 + lq * 8);
                 else
@@ -1664,28 +1667,35 @@ us_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf1
 #pragma unroll
             for (int mt = 0; mt < U::MT; ++mt)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) mma_step(acc[mt][ni], wf[mt][ks], xf[ni]);
+                for (int ni = 0; ni < U::NI; ++ni) mma_step(acc[mt][ni], wf[mt][ks], xf[ni]);
         }
         // relu(bn(.)) in fp32 to LDS at output pixel 2j + dx of row dy
 #pragma unroll
         for (int mt = 0; mt < U::MT; ++mt)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
+            for (int ni = 0; ni < U::NI; ++ni) {
                 f32x4 y;
+                if (SS_REGS) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[mt][ni][r], sc[mt][r], sh[mt][r]), 0.f);
-                *reinterpret_cast<f32x4*>(stg + ((size_t)dy * 128 + 2 * (ni * 16 + l15) + dx) * U::C2 + mt * 16 + 4 * lq) = y;
+                    for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[mt][ni][r], sc[SS_REGS ? mt : 0][r], sh[SS_REGS ? mt : 0][r]), 0.f);
+                } else {
+                    const f32x4 scv = *reinterpret_cast<const f32x4*>(scale + mt * 16 + 4 * lq);
+                    const f32x4 shv = *reinterpret_cast<const f32x4*>(shift + mt * 16 + 4 * lq);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[mt][ni][r], scv[r], shv[r]), 0.f);
+                }
+                *reinterpret_cast<f32x4*>(stg + ((size_t)dy * (2 * U::PX) + 2 * (ni * 16 + l15) + dx) * U::C2 + mt * 16 + 4 * lq) = y;
             }
         __syncthreads();
-        // 2 rows x 128 pixels x C2/8 groups of 8 channels; output rows are contiguous (128 x 2 C2 bytes)
-        constexpr int NG = U::C2 / 8;
+        // 2 rows x 2 PX pixels x C2/8 groups of 8 channels; each output row is contiguous (2 PX x 2 C2 bytes)
+        constexpr int NG = U::C2 / 8, ROWG = 2 * U::PX * NG;
 #pragma unroll
-        for (int it = 0; it < 2 * 128 * NG / kThreads; ++it) {
+        for (int it = 0; it < 2 * ROWG / kThreads; ++it) {
             const int gidx = it * kThreads + tid;
-            const int row = gidx / (128 * NG), rem = gidx % (128 * NG);
+            const int row = gidx / ROWG, rem = gidx % ROWG;
             const int64_t o = ((bb * 2 * Tp + 2 * tp + row) * (2 * (int64_t)Fp) + 2 * fp0) * U::C2 + (int64_t)rem * 8;
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + (size_t)row * 128 * U::C2 + (size_t)rem * 8);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + (size_t)row * 128 * U::C2 + (size_t)rem * 8 + 4);
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + (size_t)row * (2 * U::PX) * U::C2 + (size_t)rem * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + (size_t)row * (2 * U::PX) * U::C2 + (size_t)rem * 8 + 4);
             const bf16x8 sk = *reinterpret_cast<const bf16x8*>(skip + o);
             bf16x8 q;
 #pragma unroll
@@ -1985,7 +1995,7 @@ int build_net(alsep_net* net, const TensorMap& tm) {
             for (int ci = 0; ci < c; ++ci)
                 for (int d = 0; d < 4; ++d) mk[(size_t)co * 4 * c + d * c + ci] = (*w)[((size_t)co * c + ci) * 4 + d];
         if ((rc = make_gemm_weights<T>(net, mk, c2, 4 * c, &net->ds[i]))) return rc;
-        if (is_bf16<T>() && (c == 48 || c == 96) && (rc = make_frag_weights(net, mk, c2, 4 * c, &net->ds[i].wfrag))) return rc;
+        if (is_bf16<T>() && (c == 48 || c == 96 || c == 144) && (rc = make_frag_weights(net, mk, c2, 4 * c, &net->ds[i].wfrag))) return rc;
         if ((rc = upload(net, sc->data(), c2 * 4, &net->ds[i].scale))) return rc;
         if ((rc = upload(net, sh->data(), c2 * 4, &net->ds[i].shift))) return rc;
         c = c2; f /= 2;
@@ -2006,7 +2016,7 @@ int build_net(alsep_net* net, const TensorMap& tm) {
         for (int d = 0; d < 4; ++d)
             for (int co = 0; co < c2; ++co) { sc4[d * c2 + co] = (*sc)[co]; sh4[d * c2 + co] = (*sh)[co]; }
         if ((rc = make_gemm_weights<T>(net, mk, 4 * c2, c, &net->us[i]))) return rc;
-        if (is_bf16<T>() && (c == 96 || c == 144) && (rc = make_frag_weights(net, mk, 4 * c2, c, &net->us[i].wfrag))) return rc;
+        if (is_bf16<T>() && (c == 96 || c == 144 || c == 192) && (rc = make_frag_weights(net, mk, 4 * c2, c, &net->us[i].wfrag))) return rc;
         if ((rc = upload(net, sc4.data(), sc4.size() * 4, &net->us[i].scale))) return rc;
         if ((rc = upload(net, sh4.data(), sh4.size() * 4, &net->us[i].shift))) return rc;
         c = c2; f *= 2;
@@ -2188,23 +2198,31 @@ int run_pix_stream(alsep_ctx* ctx, int mode, const GemmLayer& L, const bf16_t* X
         const int64_t gx = std::min<int64_t>(ceil_div64(ntile, 4), 256);
         hipLaunchKernelGGL(ds48_stream_kernel, dim3((unsigned)gx), dim3(kThreads), lds, ctx->stream, X, Y, (const bf16_t*)L.wfrag.p,
                            (const float*)L.scale.p, (const float*)L.shift.p, ncols, Tp, Fp);
-    } else if (mode == PIX_DS) {                             // 96 -> 144
+    } else if (mode == PIX_DS && L.M == DsSplitCfg<96>::M) { // 96 -> 144
         const size_t lds = 64 * DsSplitCfg<96>::M * sizeof(bf16_t);
         const int64_t gx = std::min<int64_t>(ntile, 512);
-        hipLaunchKernelGGL(ds_split_stream_kernel<96>, dim3((unsigned)gx), dim3(kThreads), lds, ctx->stream, X, Y,
+        hipLaunchKernelGGL((ds_split_stream_kernel<96, 2>), dim3((unsigned)gx), dim3(kThreads), lds, ctx->stream, X, Y,
                            (const bf16_t*)L.wfrag.p, (const float*)L.scale.p, (const float*)L.shift.p, ncols, Tp, Fp);
-    } else if (L.K == 96) {                                  // us 96 -> 48
-        const size_t lds = 2 * 128 * 48 * sizeof(float);
+    } else if (mode == PIX_DS) {                             // 144 -> 192
+        const size_t lds = 64 * DsSplitCfg<144>::M * sizeof(bf16_t);
         const int64_t gx = std::min<int64_t>(ntile, 512);
-        hipLaunchKernelGGL((us_stream_kernel<96, 48>), dim3((unsigned)gx), dim3(kThreads), lds, ctx->stream, X, Y,
-                           (const bf16_t*)L.wfrag.p, (const float*)L.scale.p, (const float*)L.shift.p, skip, ncols, Tp, Fp);
-    } else {                                                 // us 144 -> 96
-        const size_t lds = 2 * 128 * 96 * sizeof(float);
-        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)us_stream_kernel<144, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds));
-        const int64_t gx = std::min<int64_t>(ntile, 256);
-        hipLaunchKernelGGL((us_stream_kernel<144, 96>), dim3((unsigned)gx), dim3(kThreads), lds, ctx->stream, X, Y,
-                           (const bf16_t*)L.wfrag.p, (const float*)L.scale.p, (const float*)L.shift.p, skip, ncols, Tp, Fp);
+        hipLaunchKernelGGL((ds_split_stream_kernel<144, 1>), dim3((unsigned)gx), dim3(kThreads), lds, ctx->stream, X, Y,
+                           (const bf16_t*)L.wfrag.p, (const float*)L.scale.p, (const float*)L.shift.p, ncols, Tp, Fp);
+    } else {
+#define ALSEP_US(CIN_, C2_, NI_, OCC_, GX_)                                                                                 \
+    {                                                                                                                       \
+        typedef UsCfg<CIN_, C2_, NI_> U;                                                                                    \
+        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)us_stream_kernel<CIN_, C2_, NI_, OCC_>,                             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)U::lds_bytes));                 \
+        const int64_t gx = std::min<int64_t>(ncols / U::PX, GX_);                                                           \
+        hipLaunchKernelGGL((us_stream_kernel<CIN_, C2_, NI_, OCC_>), dim3((unsigned)gx), dim3(kThreads), U::lds_bytes,      \
+                           ctx->stream, X, Y, (const bf16_t*)L.wfrag.p, (const float*)L.scale.p, (const float*)L.shift.p,   \
+                           skip, ncols, Tp, Fp);                                                                            \
+    }
+        if (L.K == 96) ALSEP_US(96, 48, 4, 1, 512)               // 96 -> 48
+        else if (L.K == 144) ALSEP_US(144, 96, 2, 2, 512)        // 144 -> 96: 32-pixel tiles, two workgroups per CU
+        else ALSEP_US(192, 144, 2, 1, 256)                       // 192 -> 144: 32-pixel tiles (accumulators beside 54 fragments)
+#undef ALSEP_US
     }
     ALSEP_LAUNCH_CHECK(ctx, "pix stream kernel");
     return ALSEP_OK;

@@ -18,7 +18,7 @@ from audiolab_amd import _lib
 from audiolab_amd.synth import synthetic_state_dict
 from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
 ctx = _lib.Context("cuda:0")
-cfg = TDFNetConfig(dim_f=1024, dim_t=128, n_fft=2048, hop=256, num_blocks=5, g=48)
+cfg = TDFNetConfig(dim_f=1024, dim_t=128, n_fft=2048, hop=256, num_blocks=7, g=48)
 sd = synthetic_state_dict(cfg, seed=1, calib_frames=32)
 net = TDFNet(cfg, sd, ctx=ctx, dtype=torch.bfloat16, max_batch=6)
 outs = []
@@ -47,7 +47,7 @@ def test_persistent_conv_bit_identical(tmp_path):
 
 
 def test_streaming_ds_us_match_tile_gemm(tmp_path):
-    """The register-weight streaming ds / us kernels (48<->96 and 96<->144 channels) against the generic tile GEMM on the
+    """The register-weight streaming ds / us kernels (48<->96, 96<->144 and 144<->192 channels) against the generic tile GEMM on the
     same layers: same bf16 MFMA and the same k order, so the results must agree bit for bit."""
     base = run_mode((1, 0, 1), str(tmp_path / "s0.npy"), ALSEP_PIX_STREAM="0")
     got = run_mode((1, 0, 1), str(tmp_path / "s1.npy"), ALSEP_PIX_STREAM="1")
