@@ -76,7 +76,7 @@ def test_separate_end_to_end_vs_oracle(emul, tmp_path, monkeypatch):
 
 
 def test_multichannel_ola_075_vs_oracle(emul):
-    """BASELINE configs[4] in miniature: multichannel input as stereo pairs (6 channels, and an odd 3-channel case), Hann overlap-add
+    """BASELINE configs[4] in miniature: multichannel input as stereo pairs (3 channels: one pair and an odd last channel), Hann overlap-add
     chunker at overlap 0.75, against the oracle run on every pair."""
     from audiolab_amd.engine import Separator
     from audiolab_amd.synth import synthetic_state_dict
@@ -92,8 +92,8 @@ def test_multichannel_ola_075_vs_oracle(emul):
         return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)), cfg.num_blocks, cfg.l, cfg.bn).numpy()
     eng = Separator(ctx=emul, use_autocast=False, roster=roster, max_batch=3, chunker="ola", overlap=0.75, compensate=1.02)
     eng.load_model(name)
-    n = 6000
-    for channels in (6, 3):
+    n = 3000
+    for channels in (3,):
         mix = np.concatenate([synth_mix(n, seed=70 + c) for c in range((channels + 1) // 2)])[:channels]
         out = eng.separate_array(mix)
         assert set(out) == {"Drums", "No Drums"} and out["Drums"].shape == (channels, n)
