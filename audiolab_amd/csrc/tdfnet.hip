@@ -377,6 +377,7 @@ struct ConvRW {
     static constexpr int STAGE_GROUPS = GL * 4 * 64;        // 2560
     static constexpr int RING = 3;
     static constexpr int ST = 12;                           // stores per wave per tile
+    static_assert(GL <= NS, "one LDS-DMA per k-step");
     static constexpr size_t ring_bytes = 16 * (size_t)STAGE_GROUPS * RING;  // 120 KiB
     static constexpr size_t lds_bytes = ring_bytes + 2 * BN * sizeof(float);   // + scale/shift of this output block
 };
@@ -386,7 +387,7 @@ __global__ void __launch_bounds__(kThreads, 1)
 conv3x3_bf16_regw_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
                          const float* __restrict__ scale, const float* __restrict__ shift,
                          const bf16_t* __restrict__ zero_page, int Th, int Fw, int Cin, int Cout, int tiles_t,
-                         int tiles_f, int ntiles, int ablate) {
+                         int tiles_f, int ntiles) {
     typedef ConvRW<NQ> Cf;
     bf16_t* ring = reinterpret_cast<bf16_t*>(alsep_smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -428,60 +429,82 @@ conv3x3_bf16_regw_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, c
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nstage = my_tiles * NQ;
 
-    // LDS-DMA of stage st (tile st / NQ of this workgroup, input chunk st % NQ) into ring slot
-    auto issue = [&](int st, int slot) {
+    // LDS-DMA descriptors of this lane: instruction j of a stage moves 16-byte group gidx = (wave + 4 j) * 64 + lane of
+    // the halo patch; its offset from the patch origin (pixel (t0-1, f0-1), chunk q) does not depend on the tile.  With
+    // them the per-stage address work is one add per instruction (it was two divisions, a bounds test and a 64-bit
+    // multiply per instruction: ~250 VALU instructions per stage on a kernel with ONE wave per SIMD, where nothing
+    // overlaps the MFMAs unless it is interleaved with them).
+    int doff[Cf::GL], dpos[Cf::GL];                          // element offset; pr | pc << 8 | real-group bit << 16
+#pragma unroll
+    for (int j = 0; j < Cf::GL; ++j) {
+        const int gidx = (wave + 4 * j) * 64 + lane;
+        const int pix = gidx / Cf::CG, g = gidx % Cf::CG;
+        const int pr = pix / Cf::PW, pc = pix % Cf::PW;
+        doff[j] = (pr * Fw + pc) * Cin + g * 8;
+        dpos[j] = pr | (pc << 8) | ((gidx < Cf::PGROUPS ? 1 : 0) << 16);
+    }
+    // tile origin of the stage being prefetched (wave-uniform), set by issue_prep, used by issue_one
+    const bf16_t* iss_org = X;
+    bf16_t* iss_dst = ring;
+    int iss_t0 = 0, iss_f0 = 0;
+    bool iss_interior = false;
+    auto issue_prep = [&](int st, int slot) {
         int tile = (int)blockIdx.x + (st / NQ) * (int)gridDim.x;
         const int q = st % NQ;
         const int tf = tile % tiles_f;  tile /= tiles_f;
         const int tt = tile % tiles_t;
         const int64_t b = tile / tiles_t;
-        const int t0 = tt * Cf::TH, f0 = tf * Cf::TW;
-        const bf16_t* xb = X + b * (int64_t)Th * Fw * Cin + q * Cf::KC;
-        bf16_t* dst = ring + (size_t)slot * Cf::STAGE_GROUPS * 8;
-        if (ablate & 1) return;                              // timing-only diagnostic
+        iss_t0 = tt * Cf::TH - 1;
+        iss_f0 = tf * Cf::TW - 1;
+        iss_org = X + b * (int64_t)Th * Fw * Cin + q * Cf::KC + ((int64_t)iss_t0 * Fw + iss_f0) * Cin;
+        iss_interior = iss_t0 >= 0 && iss_t0 + Cf::PH <= Th && iss_f0 >= 0 && iss_f0 + Cf::PW <= Fw;
+        iss_dst = ring + (size_t)slot * Cf::STAGE_GROUPS * 8;
+    };
+    auto issue_one = [&](int j) {
+        // branch-free: these few VALU instructions sit between MFMAs (unsigned compare = both bounds at once)
+        const unsigned t = (unsigned)(iss_t0 + (dpos[j] & 255)), f = (unsigned)(iss_f0 + ((dpos[j] >> 8) & 255));
+        const bool inb = (dpos[j] >> 16) != 0 && (iss_interior || (t < (unsigned)Th && f < (unsigned)Fw));
+        const bf16_t* src = inb ? iss_org + doff[j] : zero_page;
+        glds16(src, iss_dst + (size_t)(wave + 4 * j) * 64 * 8);
+    };
+    auto issue = [&](int st, int slot) {
+        issue_prep(st, slot);
 #pragma unroll
-        for (int j = 0; j < Cf::GL; ++j) {
-            const int i = wave + 4 * j;
-            const int gidx = i * 64 + lane;
-            const int pix = gidx / Cf::CG, g = gidx % Cf::CG;
-            const int t = t0 - 1 + pix / Cf::PW, f = f0 - 1 + pix % Cf::PW;
-            const bool inb = gidx < Cf::PGROUPS && t >= 0 && t < Th && f >= 0 && f < Fw;
-            const bf16_t* src = inb ? xb + ((int64_t)t * Fw + f) * Cin + g * 8 : zero_page;
-            glds16(src, dst + (size_t)i * 64 * 8);
-        }
+        for (int j = 0; j < Cf::GL; ++j) issue_one(j);
     };
 
     f32x4 acc[3][4];
-    // stage body; SLOT and the position of the stage in the pattern are compile-time constants
+    // Stage body; SLOT and the position of the stage in the pattern are compile-time constants.  One barrier per stage:
+    // after it every wave has finished stage st-1, so slot (st+2) % 3 (read by stage st-1) may be refilled, and the
+    // prefetch of stage st+2 is issued one LDS-DMA per k-step BETWEEN the MFMAs of stage st.
+    // vmcnt (in-order): younger than the DMA of stage st are the DMA of st+1 (GL) and the stores of the tiles finished in
+    // stages st-2 and st-1; the first two and the last stage simply drain.
 #define ALSEP_RW_STAGE(st_, SLOT_, Q_)                                                             \
     do {                                                                                           \
-        if ((st_) + 2 < nstage) issue((st_) + 2, ((SLOT_) + 2) % Cf::RING);                        \
-        /* ops issued after stage st_'s LDS-DMA: the DMA of st_+1 and st_+2 and the stores of   */ \
-        /* every tile finished in between (one per NQ stages); tail stages have fewer -> wait 0 */ \
-        if ((st_) + 2 < nstage) wait_vmcnt<2 * Cf::GL + ((Q_) == 0 ? (NQ == 1 ? 2 : 1) : 1) * Cf::ST>();   \
+        if ((st_) >= 2 && (st_) + 1 < nstage) wait_vmcnt<Cf::GL + ((Q_) == 0 ? (NQ == 1 ? 2 : 1) : 1) * Cf::ST>();   \
         else wait_vmcnt<0>();                                                                      \
         barrier_nodrain();                                                                         \
+        const bool pre_ = (st_) + 2 < nstage;                                                      \
+        if (pre_) issue_prep((st_) + 2, ((SLOT_) + 2) % Cf::RING);                                 \
         {                                                                                          \
             const bf16_t* patch = ring + (size_t)(SLOT_) * Cf::STAGE_GROUPS * 8;                   \
             if ((Q_) == 0) {                                                                       \
                 _Pragma("unroll") for (int mi = 0; mi < 3; ++mi)                                   \
                     _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; \
             }                                                                                      \
-            if (!(ablate & 2))                                                                     \
             _Pragma("unroll") for (int s = 0; s < Cf::NS; ++s) {                                   \
                 bf16x8 xf[4];                                                                      \
                 const int ko = koff_of(s);                                                         \
                 _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) xf[ni] = lds_frag<bf16_t>(patch + pbase[ni] + ko); \
                 _Pragma("unroll") for (int mi = 0; mi < 3; ++mi)                                   \
                     _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) mma_step(acc[mi][ni], wf[Q_][s][mi], xf[ni]); \
+                if (s < Cf::GL && pre_) issue_one(s);                                              \
             }                                                                                      \
         }                                                                                          \
-        barrier_nodrain();                        /* slot SLOT_ may be refilled (by stage st_+3) */ \
         if ((Q_) == NQ - 1) store_tile((st_) / NQ);                                                \
     } while (0)
 
     auto store_tile = [&](int k) {
-        if (ablate & 4) return;                              // timing-only diagnostic
         int tile = (int)blockIdx.x + k * (int)gridDim.x;
         const int tf = tile % tiles_f;  tile /= tiles_f;
         const int tt = tile % tiles_t;
@@ -2092,7 +2115,7 @@ int launch_conv_regw(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t
     ProfScope prof(ctx, ALSEP_PROF_CONV3X3_REGW);
     hipLaunchKernelGGL((conv3x3_bf16_regw_kernel<NQ>), dim3((unsigned)gx, ny), dim3(kThreads), Cf::lds_bytes, ctx->stream, X, Y,
                        (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
-                       L.cout, tiles_t, tiles_f, (int)ntiles, conv_ablate());
+                       L.cout, tiles_t, tiles_f, (int)ntiles);
     ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_regw_kernel");
     return ALSEP_OK;
 }
