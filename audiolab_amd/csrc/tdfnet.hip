@@ -368,27 +368,32 @@ conv3x3_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const 
 // vmcnt bookkeeping (in-order counter; every wave issues exactly GL LDS-DMA per stage and ST
 // stores per tile, tiles are never partial): see wait_stage below.
 // ------------------------------------------------------------------------------------------
-template <int NQ>
+template <int NQ, int RING_ = 3, int TW_ = 64>
 struct ConvRW {
-    static constexpr int TW = 64, TH = 4, KC = 48, BN = 48, CG = 6, NG = 54, NS = 14, WGRP = 56;
+    static constexpr int TW = TW_, TH = 4, KC = 48, BN = 48, CG = 6, NG = 54, NS = 14, WGRP = 56;
+    static constexpr int NI = TW_ / 16;                     // 16-pixel MFMA column blocks per wave (one tile row)
     static constexpr int PW = TW + 2, PH = TH + 2;
-    static constexpr int PGROUPS = PH * PW * CG;            // 2376 real 16-byte groups per patch chunk
-    static constexpr int GL = 10;                           // LDS-DMA instructions per wave per stage (40 KiB stage)
-    static constexpr int STAGE_GROUPS = GL * 4 * 64;        // 2560
-    static constexpr int RING = 3;
-    static constexpr int ST = 12;                           // stores per wave per tile
+    static constexpr int PGROUPS = PH * PW * CG;            // real 16-byte groups per patch chunk (2376 / 1224)
+    static constexpr int GL = (PGROUPS + 255) / 256;        // LDS-DMA instructions per wave per stage (10 / 5)
+    static constexpr int STAGE_GROUPS = GL * 4 * 64;        // 2560 / 1280
+    static constexpr int RING = RING_, AHEAD = RING_ - 1;   // ring slots, prefetch distance in stages
+    static constexpr int ST = 3 * NI;                       // stores per wave per tile
     static_assert(GL <= NS, "one LDS-DMA per k-step");
     static constexpr size_t ring_bytes = 16 * (size_t)STAGE_GROUPS * RING;  // 120 KiB
     static constexpr size_t lds_bytes = ring_bytes + 2 * BN * sizeof(float);   // + scale/shift of this output block
 };
 
-template <int NQ>
-__global__ void __launch_bounds__(kThreads, 1)
+// RING_ = 3, OCC = 1: one workgroup per CU, prefetch two stages ahead.  RING_ = 2, OCC = 2 (NQ = 1): two workgroups per CU,
+// prefetch one stage ahead -- with ONE wave per SIMD the MFMA loop, the LDS-DMA issue and the epilogue of a stage run back to
+// back (each near its own hardware limit, profiles/r01_conv_ablation_*); a second, independent workgroup on the same SIMDs
+// fills those gaps.
+template <int NQ, int RING_ = 3, int OCC = 1, int TW_ = 64>
+__global__ void __launch_bounds__(kThreads, OCC)
 conv3x3_bf16_regw_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
                          const float* __restrict__ scale, const float* __restrict__ shift,
                          const bf16_t* __restrict__ zero_page, int Th, int Fw, int Cin, int Cout, int tiles_t,
                          int tiles_f, int ntiles) {
-    typedef ConvRW<NQ> Cf;
+    typedef ConvRW<NQ, RING_, TW_> Cf;
     bf16_t* ring = reinterpret_cast<bf16_t*>(alsep_smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
@@ -413,9 +418,9 @@ conv3x3_bf16_regw_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, c
         ss[tid] = scale[ny * Cf::BN + tid];
         ss[Cf::BN + tid] = shift[ny * Cf::BN + tid];
     }
-    int pbase[4];
+    int pbase[Cf::NI];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) pbase[ni] = (wave * Cf::PW + ni * 16 + l15) * Cf::KC;   // wave w = tile row w
+    for (int ni = 0; ni < Cf::NI; ++ni) pbase[ni] = (wave * Cf::PW + ni * 16 + l15) * Cf::KC;   // wave w = tile row w
     // patch offset of k-group (4s + lq): groups advance by 4 per step -> (tap, cg) by incremental update
     auto koff_of = [&](int s) {
         const int grp = 4 * s + lq;
@@ -434,14 +439,19 @@ conv3x3_bf16_regw_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, c
     // them the per-stage address work is one add per instruction (it was two divisions, a bounds test and a 64-bit
     // multiply per instruction: ~250 VALU instructions per stage on a kernel with ONE wave per SIMD, where nothing
     // overlaps the MFMAs unless it is interleaved with them).
-    int doff[Cf::GL], dpos[Cf::GL];                          // element offset; pr | pc << 8 | real-group bit << 16
-#pragma unroll
-    for (int j = 0; j < Cf::GL; ++j) {
+    // (two workgroups per CU: 256 registers per wave, the descriptors are recomputed -- constant divisions -- instead)
+    constexpr bool DESC_REGS = OCC == 1;
+    int doff[DESC_REGS ? Cf::GL : 1], dpos[DESC_REGS ? Cf::GL : 1];   // element offset; pr | pc << 8 | real-group bit << 16
+    auto desc = [&](int j, int& off, int& pos) {
         const int gidx = (wave + 4 * j) * 64 + lane;
         const int pix = gidx / Cf::CG, g = gidx % Cf::CG;
         const int pr = pix / Cf::PW, pc = pix % Cf::PW;
-        doff[j] = (pr * Fw + pc) * Cin + g * 8;
-        dpos[j] = pr | (pc << 8) | ((gidx < Cf::PGROUPS ? 1 : 0) << 16);
+        off = (pr * Fw + pc) * Cin + g * 8;
+        pos = pr | (pc << 8) | ((gidx < Cf::PGROUPS ? 1 : 0) << 16);
+    };
+    if (DESC_REGS) {
+#pragma unroll
+        for (int j = 0; j < Cf::GL; ++j) desc(j, doff[DESC_REGS ? j : 0], dpos[DESC_REGS ? j : 0]);
     }
     // tile origin of the stage being prefetched (wave-uniform), set by issue_prep, used by issue_one
     const bf16_t* iss_org = X;
@@ -462,9 +472,12 @@ conv3x3_bf16_regw_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, c
     };
     auto issue_one = [&](int j) {
         // branch-free: these few VALU instructions sit between MFMAs (unsigned compare = both bounds at once)
-        const unsigned t = (unsigned)(iss_t0 + (dpos[j] & 255)), f = (unsigned)(iss_f0 + ((dpos[j] >> 8) & 255));
-        const bool inb = (dpos[j] >> 16) != 0 && (iss_interior || (t < (unsigned)Th && f < (unsigned)Fw));
-        const bf16_t* src = inb ? iss_org + doff[j] : zero_page;
+        int off, pos;
+        if (DESC_REGS) { off = doff[DESC_REGS ? j : 0]; pos = dpos[DESC_REGS ? j : 0]; }
+        else desc(j, off, pos);
+        const unsigned t = (unsigned)(iss_t0 + (pos & 255)), f = (unsigned)(iss_f0 + ((pos >> 8) & 255));
+        const bool inb = (pos >> 16) != 0 && (iss_interior || (t < (unsigned)Th && f < (unsigned)Fw));
+        const bf16_t* src = inb ? iss_org + off : zero_page;
         glds16(src, iss_dst + (size_t)(wave + 4 * j) * 64 * 8);
     };
     auto issue = [&](int st, int slot) {
@@ -473,7 +486,7 @@ conv3x3_bf16_regw_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, c
         for (int j = 0; j < Cf::GL; ++j) issue_one(j);
     };
 
-    f32x4 acc[3][4];
+    f32x4 acc[3][Cf::NI];
     // Stage body; SLOT and the position of the stage in the pattern are compile-time constants.  One barrier per stage:
     // after it every wave has finished stage st-1, so slot (st+2) % 3 (read by stage st-1) may be refilled, and the
     // prefetch of stage st+2 is issued one LDS-DMA per k-step BETWEEN the MFMAs of stage st.
@@ -481,23 +494,28 @@ conv3x3_bf16_regw_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, c
     // stages st-2 and st-1; the first two and the last stage simply drain.
 #define ALSEP_RW_STAGE(st_, SLOT_, Q_)                                                             \
     do {                                                                                           \
-        if ((st_) >= 2 && (st_) + 1 < nstage) wait_vmcnt<Cf::GL + ((Q_) == 0 ? (NQ == 1 ? 2 : 1) : 1) * Cf::ST>();   \
-        else wait_vmcnt<0>();                                                                      \
+        if (Cf::AHEAD == 2) {                                                                      \
+            if ((st_) >= 2 && (st_) + 1 < nstage) wait_vmcnt<Cf::GL + ((Q_) == 0 ? (NQ == 1 ? 2 : 1) : 1) * Cf::ST>();   \
+            else wait_vmcnt<0>();                                                                  \
+        } else {                                /* AHEAD == 1 (NQ == 1): only the stores of stage st-1 are younger */ \
+            if ((st_) >= 1) wait_vmcnt<Cf::ST>();                                                  \
+            else wait_vmcnt<0>();                                                                  \
+        }                                                                                          \
         barrier_nodrain();                                                                         \
-        const bool pre_ = (st_) + 2 < nstage;                                                      \
-        if (pre_) issue_prep((st_) + 2, ((SLOT_) + 2) % Cf::RING);                                 \
+        const bool pre_ = (st_) + Cf::AHEAD < nstage;                                              \
+        if (pre_) issue_prep((st_) + Cf::AHEAD, ((SLOT_) + Cf::AHEAD) % Cf::RING);                 \
         {                                                                                          \
             const bf16_t* patch = ring + (size_t)(SLOT_) * Cf::STAGE_GROUPS * 8;                   \
             if ((Q_) == 0) {                                                                       \
                 _Pragma("unroll") for (int mi = 0; mi < 3; ++mi)                                   \
-                    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+                    _Pragma("unroll") for (int ni = 0; ni < Cf::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; \
             }                                                                                      \
             _Pragma("unroll") for (int s = 0; s < Cf::NS; ++s) {                                   \
-                bf16x8 xf[4];                                                                      \
+                bf16x8 xf[Cf::NI];                                                                 \
                 const int ko = koff_of(s);                                                         \
-                _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) xf[ni] = lds_frag<bf16_t>(patch + pbase[ni] + ko); \
+                _Pragma("unroll") for (int ni = 0; ni < Cf::NI; ++ni) xf[ni] = lds_frag<bf16_t>(patch + pbase[ni] + ko); \
                 _Pragma("unroll") for (int mi = 0; mi < 3; ++mi)                                   \
-                    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) mma_step(acc[mi][ni], wf[Q_][s][mi], xf[ni]); \
+                    _Pragma("unroll") for (int ni = 0; ni < Cf::NI; ++ni) mma_step(acc[mi][ni], wf[Q_][s][mi], xf[ni]); \
                 if (s < Cf::GL && pre_) issue_one(s);                                              \
             }                                                                                      \
         }                                                                                          \
@@ -511,7 +529,7 @@ conv3x3_bf16_regw_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, c
         const int64_t b = tile / tiles_t;
         bf16_t* yb = Y + ((b * Th + tt * Cf::TH + wave) * (int64_t)Fw + tf * Cf::TW) * Cout + ny * Cf::BN;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < Cf::NI; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 3; ++mi) {
                 // ext-vector loads on purpose: a HIP float4 (struct) load from LDS makes hipcc put
@@ -526,7 +544,15 @@ conv3x3_bf16_regw_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, c
     };
 
     if (nstage > 0) issue(0, 0);
-    if (nstage > 1) issue(1, 1);
+    if (Cf::AHEAD == 2 && nstage > 1) issue(1, 1);
+    if (Cf::RING == 2) {                                     // NQ == 1: slots alternate
+        static_assert(Cf::RING == 3 || NQ == 1, "two-slot ring: single input chunk only");
+        for (int st = 0; st < nstage; st += 2) {
+            ALSEP_RW_STAGE(st, 0, 0);
+            if (st + 1 < nstage) ALSEP_RW_STAGE(st + 1, 1, 0);
+        }
+        return;
+    }
     // the ring slot advances by one per stage and the chunk index by one mod NQ: period lcm(3, NQ)
     for (int st = 0; st < nstage; st += 3 * NQ) {
         if (NQ == 1) {
@@ -2100,20 +2126,20 @@ int launch_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     return ALSEP_OK;
 }
 
-template <int NQ>
+template <int NQ, int RING_ = 3, int OCC = 1, int TW_ = 64>
 int launch_conv_regw(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zero_page, int64_t B,
                      int Th, int Fw) {
-    typedef ConvRW<NQ> Cf;
+    typedef ConvRW<NQ, RING_, TW_> Cf;
     const int tiles_t = Th / Cf::TH, tiles_f = Fw / Cf::TW;
     const int64_t ntiles = B * tiles_t * tiles_f;
     if (ntiles > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "conv3x3: too many tiles");
-    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_regw_kernel<NQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)Cf::lds_bytes));
+    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_regw_kernel<NQ, RING_, OCC, TW_>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
     const int ny = L.cout / Cf::BN;
-    int gx = 256 / ny;                                      // one workgroup per CU over the whole grid
+    int gx = OCC * 256 / ny;                                // OCC workgroups per CU over the whole grid
     if (gx > ntiles) gx = (int)ntiles;
     ProfScope prof(ctx, ALSEP_PROF_CONV3X3_REGW);
-    hipLaunchKernelGGL((conv3x3_bf16_regw_kernel<NQ>), dim3((unsigned)gx, ny), dim3(kThreads), Cf::lds_bytes, ctx->stream, X, Y,
+    hipLaunchKernelGGL((conv3x3_bf16_regw_kernel<NQ, RING_, OCC, TW_>), dim3((unsigned)gx, ny), dim3(kThreads), Cf::lds_bytes, ctx->stream, X, Y,
                        (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
                        L.cout, tiles_t, tiles_f, (int)ntiles);
     ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_regw_kernel");
@@ -2175,7 +2201,8 @@ int conv_regw_enabled() {
 
 int run_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zp, int64_t B, int Th, int Fw) {
     if (conv_regw_enabled() && Th % 4 == 0 && Fw % 64 == 0 && L.cin == L.cout) {
-        if (L.cin == 48) return launch_conv_regw<1>(ctx, L, X, Y, zp, B, Th, Fw);
+        if (L.cin == 48 && conv_regw_enabled() == 3) return launch_conv_regw<1>(ctx, L, X, Y, zp, B, Th, Fw);   // one workgroup per CU
+        if (L.cin == 48) return launch_conv_regw<1, 3, 2, 32>(ctx, L, X, Y, zp, B, Th, Fw);   // 4 x 32 tiles, two workgroups per CU
         if (L.cin == 96 && conv_regw_enabled() >= 2) return launch_conv_regw<2>(ctx, L, X, Y, zp, B, Th, Fw);
     }
     if (conv_big_enabled() && Th % 8 == 0 && Fw % 64 == 0 && L.cin == L.cout &&

@@ -41,7 +41,7 @@ def run_mode(mode, path, **extra):
 def test_persistent_conv_bit_identical(tmp_path):
     base = run_mode((0, 0, 0), str(tmp_path / "m0.npy"))     # plain LDS-DMA kernel everywhere
     assert np.isfinite(base).all() and np.abs(base).max() > 1e-3
-    for mode in ((1, 0, 0), (2, 0, 0), (0, 1, 0), (1, 1, 0), (1, 0, 1), (0, 0, 2)):   # register-weight / pipelined / big-tile
+    for mode in ((1, 0, 0), (2, 0, 0), (3, 0, 0), (0, 1, 0), (1, 1, 0), (1, 0, 1), (0, 0, 2)):   # register-weight / pipelined / big-tile
         got = run_mode(mode, str(tmp_path / ("m%d%d%d.npy" % mode)))
         assert np.array_equal(base, got), f"REGW,PIPE,BIG={mode}: max diff {np.abs(base - got).max()}"
 
