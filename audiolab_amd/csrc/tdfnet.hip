@@ -843,34 +843,42 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
             }
         }
     };
-    auto issue_weights = [&](int s) {                        // stage s -> slot s & 1
+    // weight block of stage s -> slot s & 1: 42 LDS-DMA instructions over 8 waves (waves 0, 1: six; the others five)
+    const bf16_t* wsrc_next = Wp;
+    bf16_t* wdst_next = wring;
+    auto weights_prep = [&](int s) {
         const int ny = s % NY, q = (s / NY) % nq;
-        const bf16_t* wsrc = Wp + ((int64_t)ny * nq + q) * (Cf::WGROUPS * 8);
-        bf16_t* dst = wring + (size_t)(s & 1) * Cf::WGROUPS * 8;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int i = wave + 8 * j;
-            if (i < Cf::WINST) glds16(wsrc + ((size_t)i * 64 + lane) * 8, dst + (size_t)i * 64 * 8);
-        }
+        wsrc_next = Wp + ((int64_t)ny * nq + q) * (Cf::WGROUPS * 8);
+        wdst_next = wring + (size_t)(s & 1) * Cf::WGROUPS * 8;
+    };
+    auto weights_one = [&](int j) {
+        const int i = wave + 8 * j;
+        if (i < Cf::WINST) glds16(wsrc_next + ((size_t)i * 64 + lane) * 8, wdst_next + (size_t)i * 64 * 8);
     };
 
+    // Stage s: ny = s % NY, patch ps = s / NY (tile ps / nq, input chunk q = ps % nq).  In-order vmcnt bookkeeping:
+    //  * the weight block of stage s+1 is issued one LDS-DMA per k-step BETWEEN the MFMAs of stage s (its slot was read
+    //    by stage s-1, which every wave has left once it is past stage s's barrier);
+    //  * after the last stage of a patch: barrier (patch free), LDS-DMA of the next patch, THEN the epilogue stores of a
+    //    finished tile -- the next stage waits with vmcnt(ST), i.e. for the patch and weights but not for the stores.
+    // Barriers: one per stage plus one per patch (was two per stage plus one per patch, with every tile's stores and every
+    // patch's DMA latency drained at vmcnt(0)).
+    constexpr int ST = NY * 12;                              // epilogue stores per wave
     f32x4 acc[NY][3][4];
+    if (nstage > 0) {
+        issue_patch(0);
+        weights_prep(0);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) weights_one(j);
+    }
     for (int s = 0; s < nstage; ++s) {
         const int ny = s % NY, ps = s / NY, q = ps % nq;
         const bool last = s + 1 >= nstage;
-        if (ny == 0) {                                       // new patch: every older DMA / store is drained here
-            issue_patch(ps);
-            if (s == 0) issue_weights(0);
-            wait_vmcnt<0>();
-            barrier_nodrain();
-        }
-        if (!last) issue_weights(s + 1);
-        if (ny > 0) {                                        // weights(s) were prefetched one stage ago; only the
-            if (last) wait_vmcnt<0>();                       // prefetch just issued is younger (6 / 5 per wave)
-            else if (wave < 2) wait_vmcnt<6>();
-            else wait_vmcnt<5>();
-            barrier_nodrain();
-        }
+        const bool after_epilogue = ny == 0 && q == 0 && s > 0;   // the previous stage ended a tile: its stores are younger
+        if (after_epilogue) wait_vmcnt<ST>();
+        else wait_vmcnt<0>();
+        barrier_nodrain();
+        if (!last) weights_prep(s + 1);
         {
             const bf16_t* wts = wring + (size_t)(s & 1) * Cf::WGROUPS * 8;
 #pragma unroll
@@ -894,29 +902,33 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
                         for (int mi = 0; mi < 3; ++mi)
 #pragma unroll
                             for (int ni = 0; ni < 4; ++ni) mma_step(acc[yy][mi][ni], wf[mi], xf[ni]);
+                        if (st < 6 && !last) weights_one(st);
                     }
                 }
             }
         }
-        barrier_nodrain();                                   // slot s&1 (and the patch, when ny == NY-1) may be refilled
-        if (ny == NY - 1 && q == nq - 1) {
-            int t0, f0; int64_t b;
-            tile_coords(ps / nq, t0, f0, b);
-            bf16_t* yb = Y + ((b * Th + t0 + wave) * (int64_t)Fw + f0) * Cout;
+        if (ny == NY - 1) {
+            barrier_nodrain();                               // every wave has left the patch: it may be refilled
+            if (!last) issue_patch(ps + 1);
+            if (q == nq - 1) {
+                int t0, f0; int64_t b;
+                tile_coords(ps / nq, t0, f0, b);
+                bf16_t* yb = Y + ((b * Th + t0 + wave) * (int64_t)Fw + f0) * Cout;
 #pragma unroll
-            for (int yy = 0; yy < NY; ++yy)
+                for (int yy = 0; yy < NY; ++yy)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                    for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                    for (int mi = 0; mi < 3; ++mi) {
-                        const int co = yy * Cf::BN + mi * 16 + 4 * lq;
-                        const f32x4 scv = *reinterpret_cast<const f32x4*>(ss + co);      // ext-vector load: see regw kernel
-                        const f32x4 shv = *reinterpret_cast<const f32x4*>(ss + NY * Cf::BN + co);
-                        float y[4];
+                        for (int mi = 0; mi < 3; ++mi) {
+                            const int co = yy * Cf::BN + mi * 16 + 4 * lq;
+                            const f32x4 scv = *reinterpret_cast<const f32x4*>(ss + co);      // ext-vector load: see regw kernel
+                            const f32x4 shv = *reinterpret_cast<const f32x4*>(ss + NY * Cf::BN + co);
+                            float y[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[yy][mi][ni][r], scv[r], shv[r]), 0.f);
-                        store4(yb + (int64_t)(ni * 16 + l15) * Cout + co, y);
-                    }
+                            for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[yy][mi][ni][r], scv[r], shv[r]), 0.f);
+                            store4(yb + (int64_t)(ni * 16 + l15) * Cout + co, y);
+                        }
+            }
         }
     }
 }
