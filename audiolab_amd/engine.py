@@ -9,6 +9,12 @@ is reachable offline, so every roster entry below is a TFC-TDF U-Net with random
 (audiolab_amd.synth) unless ``<model_file_dir>/<name>.pt`` holds a torch state_dict for it.
 Geometry per file name follows the public UVR/KUIELab model tables (PARITY UNPINNED).
 
+Multi-stem entries.  A roster value ``("multi", [(label, cfg), ...])`` describes a model file that yields several stems
+(the reference's drum-kit splitter ``MDX23C-DrumSep-aufr33-jarredou.ckpt`` returns six, stem_separator.py:563-574): one
+network per label.  The default roster holds MDX-Net models only; the other architectures the orchestrator names (MDX23C,
+VR, Roformer: SURVEY 8(f)) have no kernels yet, so those stages run only when the caller's roster supplies the file name --
+with whatever network it maps it to.
+
 MDX runner.  ``chunker="margin"`` (default): margin chunker + trim stitching exactly as the in-tree
 runner (mdxnet.py:109-197, pinned).  ``chunker="ola"``: Hann-window overlap-add with ``overlap`` and
 ``compensate`` as the third-party MDXSeparator does (unpinned).  The secondary stem is
@@ -60,6 +66,7 @@ class _ModelInstance:
         self.secondary_stem_name = secondary
         self.output_dir = None
         self.model_run = net                                  # callable(spek) -> pred, the patch_separate seam
+        self.extra: List[tuple] = []                          # multi-stem models: further (label, net, predictor)
 
 
 class Separator:
@@ -102,24 +109,37 @@ class Separator:
             return
         if model_filename not in self.roster:
             raise AlsepError(f"model '{model_filename}' is not available in this build (MDX-Net roster: {sorted(self.roster)})")
-        primary, secondary, cfg = self.roster[model_filename]
-        pt = os.path.join(self.model_file_dir, model_filename + ".pt")
-        if os.path.exists(pt):
-            sd = torch.load(pt, map_location="cpu")
+        entry = self.roster[model_filename]
+        if entry[0] == "multi":                                 # ("multi", [(label, cfg), ...]): one network per stem
+            stems = [(label, None, cfg) for label, cfg in entry[1]]
         else:
-            seed = int.from_bytes(hashlib.sha256(model_filename.encode()).digest()[:4], "little")
-            sd = synthetic_state_dict(cfg, seed=seed)
-        net = TDFNet(cfg, sd, ctx=self.ctx, dtype=self.dtype, max_batch=self.max_batch)
-        dim_t_arg = int(cfg.dim_t).bit_length() - 1
-        args = types.SimpleNamespace(margin=self.margin, chunks=self.chunks, denoise=self.denoise, dim_f=cfg.dim_f,
-                                     dim_t=dim_t_arg, n_fft=cfg.n_fft)
-        if self.chunker == "ola":
-            from .mdx import OlaRunner
-            pred = OlaRunner(net, ctx=self.ctx, overlap=self.overlap, compensate=self.compensate, denoise=self.denoise,
-                             max_batch=self.max_batch)
-        else:
-            pred = Predictor(args, net, ctx=self.ctx, hop=cfg.hop, sharded=self.sharded)
+            stems = [entry]
+
+        def build(tag: str, cfg: TDFNetConfig):
+            pt = os.path.join(self.model_file_dir, tag + ".pt")
+            if os.path.exists(pt):
+                sd = torch.load(pt, map_location="cpu")
+            else:
+                seed = int.from_bytes(hashlib.sha256(tag.encode()).digest()[:4], "little")
+                sd = synthetic_state_dict(cfg, seed=seed)
+            net = TDFNet(cfg, sd, ctx=self.ctx, dtype=self.dtype, max_batch=self.max_batch)
+            dim_t_arg = int(cfg.dim_t).bit_length() - 1
+            args = types.SimpleNamespace(margin=self.margin, chunks=self.chunks, denoise=self.denoise, dim_f=cfg.dim_f,
+                                         dim_t=dim_t_arg, n_fft=cfg.n_fft)
+            if self.chunker == "ola":
+                from .mdx import OlaRunner
+                pred = OlaRunner(net, ctx=self.ctx, overlap=self.overlap, compensate=self.compensate, denoise=self.denoise,
+                                 max_batch=self.max_batch)
+            else:
+                pred = Predictor(args, net, ctx=self.ctx, hop=cfg.hop, sharded=self.sharded)
+            return net, pred
+
+        primary, secondary, cfg = stems[0]
+        net, pred = build(model_filename if len(stems) == 1 else f"{model_filename}#{primary}", cfg)
         inst = _ModelInstance(model_filename, net, pred, primary, secondary)
+        for label, _, cfg_i in stems[1:]:
+            net_i, pred_i = build(f"{model_filename}#{label}", cfg_i)
+            inst.extra.append((label, net_i, pred_i))
         inst.output_dir = self.output_dir
         self._cache[model_filename] = inst
         self.model_instance = inst
@@ -160,6 +180,9 @@ class Separator:
             self.ctx.check(self.ctx.lib.alsep_axpby(self.ctx.handle, -1.0, _lib.ptr(primary.contiguous()), 1.0, _lib.ptr(sec),
                                                     sec.numel()), "alsep_axpby")
             out[inst.secondary_stem_name] = sec
+        for label, _, pred in inst.extra:                       # multi-stem model: every further stem from the same input
+            t = pred.demix(m)
+            out[label] = t[0] if t.dim() == 3 else t
         return out
 
     def separate(self, audio_file_path: str) -> List[str]:

@@ -4,12 +4,14 @@ stem labels and progress protocol as the reference's ``modules/separator/stem_se
 ``EnsembleDemucsMDXMusicSeparationModel`` :82-840), with the arithmetic on the GPU and tensors
 resident in HBM between stages (no temp PCM16 WAV per model, :57-75 / :278).
 
-Roster differences (the build owns its roster; all weights are synthetic
-offline): the vocal ensemble is the reference's MDX-Net members (:384-386); the multistem stage
-uses the 4-stem MDX-Net set instead of htdemucs_6s (:466) and therefore yields drums/bass/other
-(no guitar/piano); stages whose models are Roformer / MDX23C / VR architectures (dereverb, echo,
-noise, BG-vocal split, drum split, woodwinds) are skipped with a log line -- they are SURVEY 8(f)
-"next" rows.  crowd removal with ``UVR-MDX-NET_Crowd_HQ_1.onnx`` (MDX-Net) is available.
+Roster differences (the build owns its roster; all weights are synthetic offline): the vocal
+ensemble is the reference's MDX-Net members (:384-386); the multistem stage uses the 4-stem MDX-Net set instead of
+htdemucs_6s (:466) and therefore yields drums/bass/other (no guitar/piano).  Every other stage of the reference --
+reverb / echo / crowd / noise transform chain (:777-840), BG-vocal split (:737-775), drum-kit split (:534-587), woodwinds
+(:589-623) -- is built with the reference's stage order, label matching, residual-subtract bookkeeping and progress
+accounting; it RUNS when the engine's roster knows the model file the reference names for it (the default roster knows the
+MDX-Net ones, e.g. ``UVR-MDX-NET_Crowd_HQ_1.onnx``; Roformer / MDX23C / VR architectures have no kernels yet -- SURVEY 8(f)
+-- so those files are absent from it and their stages are skipped with a log line instead of failing the whole job).
 """
 from __future__ import annotations
 
@@ -76,6 +78,8 @@ class EnsembleDemucsMDXMusicSeparationModel:
         self.crowd_removal = options.get("crowd_removal", "Nothing")
         self.noise_removal = options.get("noise_removal", "Nothing")
         self.crowd_removal_model = options.get("crowd_removal_model", "UVR-MDX-NET_Crowd_HQ_1.onnx")
+        self.delay_removal_model = options.get("delay_removal_model", "dereverb-echo_mel_band_roformer_sdr_13.4843_v2.ckpt")
+        self.noise_removal_model = options.get("noise_removal_model", "UVR-DeNoise.pth")
         self.separate_bg_vocals = options.get("separate_bg_vocals", True)
         self.bg_vocal_layers = options.get("bg_vocal_layers", 1)
         self.store_reverb_ir = options.get("store_reverb_ir", False)
@@ -127,7 +131,12 @@ class EnsembleDemucsMDXMusicSeparationModel:
             del res["vocals_list"], res["instrumental_list"]
         return results
 
-    # -- transform chain (:777-840): only MDX-Net members of the roster can run ---------------------
+    # -- transform chain (:777-840), BG-vocal split (:737-775) ----------------------------------------
+    REVERB_MODEL = "dereverb_mel_band_roformer_anvuew_sdr_19.1729.ckpt"     # :796
+    BG_VOCAL_MODEL = "UVR-BVE-4B_SN-44100-1.pth"                            # :752
+    DRUM_MODEL = "MDX23C-DrumSep-aufr33-jarredou.ckpt"                      # :541
+    WOODWIND_MODEL = "17_HP-Wind_Inst-UVR.pth"                              # :596
+
     @staticmethod
     def _should_apply_transform(stem_name: str, setting: str) -> bool:
         """:680-699."""
@@ -141,24 +150,138 @@ class EnsembleDemucsMDXMusicSeparationModel:
             return "vocals)" in stem_name and "(bg_vocals" not in stem_name.lower()
         return False
 
+    @staticmethod
+    def _rename_file(base_in: str, filepath: str) -> str:
+        """:702-735 -- the name a transformed stem file gets (model references stripped from the parenthesised tags).
+        The in-memory path writes no intermediate files, so nothing is renamed on disk; the function is kept for the
+        callers that build names."""
+        import re
+        dirname = os.path.dirname(filepath)
+        ext = os.path.splitext(filepath)[1]
+        base_only = os.path.splitext(os.path.basename(base_in))[0]
+        all_parens = re.findall(r"\([^)]*\)", os.path.basename(filepath))
+        to_strip = ["deverb_bs_roformer", "UVR-DeEcho-DeReverb", "UVR-De-Echo-Normal", "UVR-DeNoise", "UVR-DeNoise-Lite",
+                    "mel_band_roformer", "MDX23C", "UVR-MDX-NET", "drumsep", "roformer", "viperx", "crowd", "karaoke",
+                    "instrumental", "_InstVoc", "_VOCFT", "NoReverb", "NoEcho", "NoDelay", "NoCrowd", "NoNoise",
+                    "_mel_band_roformer_karaoke_aufr33_viperx_sdr_10"]
+        filtered = [g for g in all_parens if not any(p.lower() in g.lower() for p in to_strip)]
+        final_name = (base_only + "_" + "".join(filtered) + ext).replace(") (", ")(").replace("__", "_")
+        return os.path.join(dirname, final_name)
+
+    def _have(self, model_file: str, what: str) -> bool:
+        if model_file in self.separator.roster:
+            return True
+        logger.warning("%s needs '%s', which is not in this engine's roster (architecture without kernels yet); skipped",
+                       what, model_file)
+        return False
+
+    def _run_model(self, model_file: str, x: torch.Tensor):
+        """load + separate on a device tensor; returns [(simulated output file name, tensor)] in the engine's output order
+        (the reference matches labels against the FILE NAMES ``<base>_(<Label>)_<model>.wav``, :808-833)."""
+        self.separator.load_model(model_file)
+        outs = self.separator.separate_array(x)
+        tag = os.path.splitext(model_file)[0]
+        return [(f"tmp_(%s)_%s.wav" % (label, tag), t) for label, t in outs.items()]
+
     def _apply_transform_chain(self, stem: torch.Tensor, base_name: str, stem_label: str, skip_transforms=None) -> torch.Tensor:
+        """:777-840.  Output selection as the reference: with two outputs the one whose name contains the wanted label
+        (spaces removed, lower case) -- else the SECOND one; otherwise the first match, or the input unchanged."""
         skip_transforms = skip_transforms or []
-        chain = [(None, "No Reverb", self.reverb_removal), (None, "dry", self.echo_removal),
-                 (self.crowd_removal_model, "No Crowd", self.crowd_removal), (None, "No Noise", self.noise_removal)]
+        chain = [(self.REVERB_MODEL, "No Reverb", self.reverb_removal), (self.delay_removal_model, "dry", self.echo_removal),
+                 (self.crowd_removal_model, "No Crowd", self.crowd_removal), (self.noise_removal_model, "No Noise", self.noise_removal)]
         cur = stem
         for model_file, out_label, flag in chain:
             if out_label in skip_transforms or not self._should_apply_transform(f"({stem_label})", flag):
                 continue
-            if model_file is None or model_file not in self.separator.roster:
-                logger.warning("transform '%s' needs a model outside this build's MDX-Net roster; skipped", out_label)
-                continue
-            self.separator.load_model(model_file)
-            outs = self.separator.separate_array(cur)
-            for label, t in outs.items():
-                if out_label.replace(" ", "").lower() in label.replace(" ", "").lower():
-                    cur = t
+            if self._have(model_file, f"transform '{out_label}'"):
+                outs = self._run_model(model_file, cur)
+                want = out_label.replace(" ", "").lower()
+                chosen = None
+                if len(outs) == 2:
+                    chosen = outs[0][1] if want in outs[0][0].replace(" ", "").lower() else outs[1][1]
+                    if out_label in ("No Echo", "No Reverb") and stem_label.lower() == "vocals" and self.store_reverb_ir:
+                        logger.info("reverb impulse-response extraction (handlers/reverb.py:112-172) is not part of this build")
+                else:
+                    for name, t in outs:
+                        if want in name.replace(" ", "").lower():
+                            chosen = t
+                            break
+                if chosen is not None:
+                    cur = chosen
             self._advance_progress(f"TRANSFORM: {out_label} on {stem_label} for {base_name}")
         return cur
+
+    def _apply_bg_vocal_splitting(self, vocals: torch.Tensor, base_name: str):
+        """:737-775 -- the BVE model's "(Vocals)" output is the BACKGROUND, its "(Instrumental)" the main vocal."""
+        if not self._have(self.BG_VOCAL_MODEL, "background-vocal split"):
+            self._advance_progress("Background vocal splitting skipped.")
+            return vocals, None
+        outs = self._run_model(self.BG_VOCAL_MODEL, vocals)
+        self._advance_progress("Background vocal splitting executed.")
+        bg = main = None
+        for name, t in outs:
+            if "(Vocals)" in name:
+                bg = t
+            elif "(Instrumental)" in name:
+                main = t
+        if bg is not None and main is not None:
+            if float(ensemble.peak_abs(self.ctx, bg.contiguous()).cpu()) > 0.0:
+                return main, bg
+            logger.info("Background vocals are empty after splitting.")
+        return vocals, None
+
+    # -- drum kit (:534-587), woodwinds (:589-623) -------------------------------------------------
+    DRUM_PARTS = (("(kick)", "drums_kick"), ("(snare)", "drums_snare"), ("(toms)", "drums_toms"), ("(hh)", "drums_hh"),
+                  ("(ride)", "drums_ride"), ("(crash)", "drums_crash"))
+
+    def _advanced_drum_separation_all(self, results: Dict[str, Dict]) -> None:
+        if not self._have(self.DRUM_MODEL, "drum-kit split"):
+            for base_name in results:
+                self._advance_progress(f"Advanced drum separation skipped for {base_name}.")
+            return
+        for base_name, res in results.items():
+            drums = res.get("drums")
+            if drums is None:
+                drums = torch.zeros_like(res["instrumental"])
+            parts = self._run_model(self.DRUM_MODEL, drums)
+            drums_other = drums.clone()
+            for _, key in self.DRUM_PARTS:
+                res[key] = None
+            for name, arrp in parts:                             # every part is subtracted, named or not (:557-561)
+                low = name.lower()
+                n = arrp.shape[-1]
+                if n <= drums_other.shape[-1]:
+                    drums_other[:, :n] = ensemble.residual_subtract(self.ctx, drums_other[:, :n].contiguous(), arrp, res["sr"])
+                for tag, key in self.DRUM_PARTS:
+                    if tag in low:
+                        res[key] = arrp
+                        break
+            for key in ("drums", "bass", "guitar", "piano", "other"):
+                if res.get(key) is None:
+                    res[key] = torch.zeros_like(drums)
+            res["drums_other"] = drums_other
+            self._advance_progress(f"Advanced drum separation done for {base_name}.")
+
+    def _woodwinds_separation_all(self, results: Dict[str, Dict]) -> None:
+        if not self._have(self.WOODWIND_MODEL, "woodwinds split"):
+            for base_name in results:
+                self._advance_progress(f"Woodwinds separation skipped for {base_name}.")
+            return
+        for base_name, res in results.items():
+            other = res.get("other")
+            if other is None:
+                other = torch.zeros_like(res["instrumental"])
+            new_ww = torch.zeros_like(other)
+            for name, arrw in self._run_model(self.WOODWIND_MODEL, other):
+                if "(woodwinds)" in name.lower():
+                    new_ww = arrw
+            leftover = other.clone()
+            n = new_ww.shape[-1]
+            if n <= leftover.shape[-1]:
+                leftover[:, :n] = ensemble.residual_subtract(self.ctx, leftover[:, :n].contiguous(), new_ww, res["sr"])
+            res["woodwinds"] = new_ww
+            res["other"] = leftover
+            self._advance_progress(f"Woodwinds separated for {base_name}.")
 
     # -- multistem (:459-503), alt bass (:505-532) ---------------------------------------------------
     def _multistem_separation_all(self, results: Dict[str, Dict]) -> None:
@@ -231,25 +354,42 @@ def predict_with_model(options: Dict, callback: Callable = None, separator: Opti
     trans_opts = [model.reverb_removal, model.crowd_removal, model.noise_removal]
     count_v = sum(1 for o in trans_opts if o in {"All", "All Vocals", "Main Vocals"})
     count_i = sum(1 for o in trans_opts if o == "All")
-    model.total_steps = (min(max(1, model.ensemble_strength), len(model.ENSEMBLE)) * n + (count_v + count_i) * n +
-                         (n if not model.vocals_only else 0) + (n if (model.alt_bass_model and not model.vocals_only) else 0) + 1 + n)
+    multi = not model.vocals_only
+    model.total_steps = (min(max(1, model.ensemble_strength), len(model.ENSEMBLE)) * n          # ensemble (:884-886)
+                         + (n if model.separate_bg_vocals else 0) + (count_v + count_i) * n      # bg split, transforms
+                         + (n if multi else 0) + (n if (model.alt_bass_model and multi) else 0)
+                         + (n if (model.separate_drums and multi) else 0) + (n if (model.separate_woodwinds and multi) else 0)
+                         + 1 + n)                                                                 # saving (:897)
     if model.callback is not None:
         _call_progress(model.callback, 0, "Starting ensemble separation...", model.total_steps)
     results = model._ensemble_separate_all(files_data)
-    if model.separate_bg_vocals:
-        logger.info("BG-vocal splitting needs UVR-BVE-4B_SN-44100-1.pth (VR architecture): not in this build; skipped")
-    if any(o != "Nothing" for o in (model.crowd_removal, model.noise_removal, model.reverb_removal, model.echo_removal)):
+    # stage order of :903-945: reverb removal on the vocals BEFORE the background split (the first call runs the WHOLE
+    # chain, so with reverb removal on, the vocals meet the crowd / noise transforms twice -- reference behaviour)
+    if model.reverb_removal != "Nothing":
         for base_name, res in results.items():
-            res["vocals"] = model._apply_transform_chain(res["vocals"], base_name, "vocals")
-            res["instrumental"] = model._apply_transform_chain(res["instrumental"], base_name, "instrumental")
+            if res.get("vocals") is not None:
+                res["vocals"] = model._apply_transform_chain(res["vocals"], base_name, "vocals")
+    if model.separate_bg_vocals:
+        for base_name, res in results.items():
+            if res.get("vocals") is not None:
+                main_v, bg_v = model._apply_bg_vocal_splitting(res["vocals"], base_name)
+                res["vocals"] = main_v
+                if bg_v is not None:
+                    res["bg_vocals"] = bg_v
+    if any(o != "Nothing" for o in (model.crowd_removal, model.noise_removal)):
+        for base_name, res in results.items():
+            if res.get("vocals") is not None:
+                res["vocals"] = model._apply_transform_chain(res["vocals"], base_name, "vocals", skip_transforms=["No Reverb"])
+            if res.get("instrumental") is not None:
+                res["instrumental"] = model._apply_transform_chain(res["instrumental"], base_name, "instrumental")
     if not model.vocals_only:
         model._multistem_separation_all(results)
         if model.alt_bass_model:
             model._alt_bass_separation_all(results)
         if model.separate_drums:
-            logger.info("drum-kit split needs MDX23C-DrumSep (not in this build); skipped")
+            model._advanced_drum_separation_all(results)
         if model.separate_woodwinds:
-            logger.info("woodwinds split needs 17_HP-Wind_Inst-UVR.pth (VR architecture, not in this build); skipped")
+            model._woodwinds_separation_all(results)
     return model._save_all_stems(results)
 
 

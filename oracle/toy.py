@@ -42,3 +42,23 @@ def resid_case(lag: int, gain: float, n: int = 48000):
     shifted = np.stack([np.roll(c, lag) for c in comp])
     base = (np.float32(gain) * shifted + other).astype(np.float32)
     return base, comp.astype(np.float32)
+
+
+# Deterministic stand-in "models" for the orchestration fixtures: model file name -> [(output label, gain, shift)] in the
+# engine's output order.  y = gain * roll(x, shift) per output: enough structure for the lag search / gain fit of the
+# residual subtraction (stem_separator.py:173-239) and the label matching of the transform chain (:808-833) to matter.
+TOY_MODELS = {
+    "dereverb_mel_band_roformer_anvuew_sdr_19.1729.ckpt": [("No Reverb", 0.8, 0), ("Reverb", 0.2, 7)],
+    "dereverb-echo_mel_band_roformer_sdr_13.4843_v2.ckpt": [("No dry", 0.15, 11), ("dry", 0.85, 0)],     # wanted label second
+    "UVR-MDX-NET_Crowd_HQ_1.onnx": [("No Crowd", 0.9, 0), ("Crowd", 0.1, 3)],
+    "UVR-DeNoise.pth": [("Noise", 0.05, 1), ("No Noise", 0.95, 0)],
+    "UVR-BVE-4B_SN-44100-1.pth": [("Vocals", 0.25, 5), ("Instrumental", 0.75, 0)],
+    "MDX23C-DrumSep-aufr33-jarredou.ckpt": [("Kick", 0.30, 0), ("Snare", 0.22, 2), ("Toms", 0.15, -3), ("HH", 0.10, 5),
+                                            ("Ride", 0.08, -1), ("Crash", 0.05, 4)],
+    "17_HP-Wind_Inst-UVR.pth": [("No Woodwinds", 0.7, 0), ("Woodwinds", 0.3, 6)],
+}
+
+
+def toy_model_outputs(model_file: str, x: np.ndarray):
+    """[(label, y)] for a [C,N] input."""
+    return [(label, (np.float32(g) * np.roll(x, s, axis=-1)).astype(np.float32)) for label, g, s in TOY_MODELS[model_file]]
