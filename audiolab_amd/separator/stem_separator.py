@@ -284,10 +284,32 @@ class EnsembleDemucsMDXMusicSeparationModel:
             self._advance_progress(f"Woodwinds separated for {base_name}.")
 
     # -- multistem (:459-503), alt bass (:505-532) ---------------------------------------------------
+    MULTISTEM_MODEL = "htdemucs_6s.yaml"                                     # :466
+
     def _multistem_separation_all(self, results: Dict[str, Dict]) -> None:
+        """:459-503.  When the roster knows ``htdemucs_6s.yaml`` (a multi-stem entry) the stage runs as the reference
+        does: that model on the full mix, outputs mapped to drums / bass / guitar / piano / other by substring of their
+        file names (the vocals output is ignored).  Otherwise (default roster: no Demucs kernels yet) the 4-stem MDX-Net
+        set stands in and yields drums / bass / other."""
         for key in ("drums", "bass", "guitar", "piano", "other"):
             for res in results.values():
                 res[key] = None
+        if self.MULTISTEM_MODEL in self.separator.roster:
+            for base_name, res in results.items():
+                for name, arr in self._run_model(self.MULTISTEM_MODEL, res["mix"]):
+                    low = name.lower()
+                    if "(drums)" in low or "drums" in low or "drum" in low:
+                        res["drums"] = arr
+                    elif "(bass)" in low or "bass" in low:
+                        res["bass"] = arr
+                    elif "(guitar)" in low or "guitar" in low:
+                        res["guitar"] = arr
+                    elif "(piano)" in low or "piano" in low:
+                        res["piano"] = arr
+                    elif "(other)" in low or "other" in low or "accompaniment" in low or "rest" in low:
+                        res["other"] = arr
+                self._advance_progress(f"6-stem separation completed for {base_name}.")
+            return
         for model_name in FOUR_STEM_SET[1:]:                     # vocals output is ignored, as :491-500
             self.separator.load_model(model_name)
             label = self.separator.roster[model_name][0]

@@ -3,7 +3,7 @@
 
 Runs the REFERENCE's own stage methods -- modules/separator/stem_separator.py ``_apply_transform_chain`` (:777-840),
 ``_apply_bg_vocal_splitting`` (:737-775), ``_advanced_drum_separation_all`` (:534-587), ``_woodwinds_separation_all``
-(:589-623), ``_should_apply_transform`` (:680-699), ``_rename_file`` (:702-735) -- imported in this container with the absent
+(:589-623), ``_multistem_separation_all`` (:459-503), ``_should_apply_transform`` (:680-699), ``_rename_file`` (:702-735) -- imported in this container with the absent
 third-party packages stubbed (as oracle/make_golden.py), against a FAKE separator: ``load_model`` / ``separate`` with
 deterministic toy "models" (gain + shift per output label, oracle/toy.py ``toy_model_outputs``) and an in-memory file
 system behind the stubbed ``soundfile.write`` / ``librosa.load`` (PCM_16 temp files are quantised like libsndfile does).
@@ -145,6 +145,14 @@ def main():
     eng._woodwinds_separation_all(results)
     out["ww_woodwinds"], out["ww_other"] = np.asarray(r["woodwinds"], np.float32), np.asarray(r["other"], np.float32)
     meta["drum_ww_steps"] = eng.global_step
+    # 6-stem stage on the full mix (a10 orchestration: label mapping only; the model is a toy)
+    eng = make_engine(ss)
+    FS.clear()
+    mix = (vocals + inst).astype(np.float32)
+    results = {"song": {"sr": sr, "mix_np": mix, "instrumental": inst.copy(), "output_folder": folder}}
+    eng._multistem_separation_all(results)
+    for k in ("drums", "bass", "guitar", "piano", "other"):
+        out[f"multi_{k}"] = np.asarray(results["song"][k], np.float32)
     meta["inputs"] = {"n": n, "sr": sr, "vocals": [301, 0.6], "inst": [302, 0.7], "drums": [303, 0.5], "other": [304, 0.5],
                       "note": "synth_mix(n, seed) * gain; arrays in the npz are decimated [:, ::8]"}
     os.makedirs(OUT, exist_ok=True)

@@ -56,6 +56,8 @@ TOY_MODELS = {
     "MDX23C-DrumSep-aufr33-jarredou.ckpt": [("Kick", 0.30, 0), ("Snare", 0.22, 2), ("Toms", 0.15, -3), ("HH", 0.10, 5),
                                             ("Ride", 0.08, -1), ("Crash", 0.05, 4)],
     "17_HP-Wind_Inst-UVR.pth": [("No Woodwinds", 0.7, 0), ("Woodwinds", 0.3, 6)],
+    "htdemucs_6s.yaml": [("Vocals", 0.30, 0), ("Drums", 0.20, 1), ("Bass", 0.15, -2), ("Guitar", 0.12, 3), ("Piano", 0.10, -4),
+                         ("Other", 0.13, 2)],
 }
 
 

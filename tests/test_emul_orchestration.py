@@ -109,6 +109,17 @@ def test_drum_kit_and_woodwinds_match_reference(emul, golden):
     assert model.global_step == meta["drum_ww_steps"]
 
 
+def test_six_stem_label_mapping_matches_reference(emul, golden):
+    z, meta = golden
+    x, sr = inputs(meta)
+    model, eng = make_model(emul)
+    mix = torch.from_numpy((x["vocals"] + x["inst"]).astype(np.float32))
+    results = {"song": {"sr": sr, "mix": mix, "instrumental": torch.from_numpy(x["inst"].copy()), "output_folder": "/mem"}}
+    model._multistem_separation_all(results)
+    for k in ("drums", "bass", "guitar", "piano", "other"):
+        close(results["song"][k], z[f"multi_{k}"])
+
+
 def test_stages_are_skipped_without_their_models(emul, tmp_path):
     """Default roster (MDX-Net files only): the stages whose model architectures have no kernels yet are skipped with a
     log line, the job still completes and the progress reaches 1."""
