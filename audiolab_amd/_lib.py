@@ -74,6 +74,13 @@ _SIGNATURES = {
     "alsep_xcorr_window": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "alsep_shift_subtract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float,
                                        C.c_void_p]),
+    "alsep_vr_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] +
+                        [C.c_int] * 12),
+    "alsep_vr_depthwise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 7),
+    "alsep_vr_resize_bilinear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 7),
+    "alsep_vr_copy_slice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 6),
+    "alsep_vr_mean_h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "alsep_vr_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 5 + [C.c_float]),
 }
 
 EXPORTS: Tuple[str, ...] = tuple(_SIGNATURES)

@@ -1,0 +1,230 @@
+// Building blocks of the VR-architecture networks (CascadedASPPNet: reference
+// modules/rvc/infer/lib/uvr5_pack/lib_v5/nets*.py, layers*.py) on channels-last fp32 tensors [B, H = bins, W = frames, C].
+//
+// First HIP path for this family: correct and generic (any channel count, kernel size, stride, dilation), fp32 storage
+// and exact-f32 MFMA (v_mfma_f32_16x16x4_f32, a k-ordered fmaf chain) so that it can be pinned against the in-tree torch
+// modules; not yet tuned (operands come straight from global memory / L1, no LDS staging).
+//   conv2d      : implicit GEMM, one wave = 16 output pixels x 32 output channels, K = (tap, ci) in steps of 4;
+//                 epilogue y = act(acc * scale + shift) (BatchNorm folded), written into a channel slice of the output
+//                 tensor (so the concatenations of the decoders / ASPP need no copy)
+//   depthwise   : 3x3 dilated, one thread per (pixel, channel)
+//   resize      : bilinear, align_corners=True (F.interpolate in layers*.py:84, 111), into a channel slice
+//   copy_slice  : crop_center along frames (spec_utils.py:12-27) + concat
+//   mean_h      : AdaptiveAvgPool2d((1, None)) (layers*.py:93)
+//   vr_mask     : sigmoid, replicate pad along bins, aggressiveness powers, * mix (nets*.py:80-111)
+#include "alsep_common.h"
+#include "mma.h"
+
+namespace {
+
+constexpr int kVrThreads = 256;
+
+__device__ __forceinline__ float vr_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return v > 0.f ? v : 0.01f * v;            // nn.LeakyReLU default slope
+    return v;
+}
+
+// x [B,H,W,Cin], w [Cout][KH][KW][Cin], y [B,Ho,Wo,y_ct] at channel offset y_c0
+__global__ void __launch_bounds__(kVrThreads)
+vr_conv2d_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+                 const float* __restrict__ shift, float* __restrict__ y, int64_t npix, int H, int W, int Cin, int Cout,
+                 int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int act, int y_ct, int y_c0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int64_t p = ((int64_t)blockIdx.x * 4 + wave) * 16 + l15;      // this lane's output pixel (B column of the MFMA)
+    const int co0 = blockIdx.y * 32;
+    const bool pv = p < npix;
+    const int64_t pp = pv ? p : 0;
+    const int ox = (int)(pp % Wo), oy = (int)((pp / Wo) % Ho);
+    const int64_t b = pp / ((int64_t)Wo * Ho);
+    const float* xb = x + b * (int64_t)H * W * Cin;
+    const int taps = KH * KW;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (int tap = 0; tap < taps; ++tap) {
+        const int iy = oy * stride - pad + (tap / KW) * dil, ix = ox * stride - pad + (tap % KW) * dil;
+        const bool inb = pv && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const float* xp = xb + ((int64_t)(inb ? iy : 0) * W + (inb ? ix : 0)) * Cin;
+        for (int c = 0; c < Cin; c += 4) {
+            const int ci = c + lq;
+            const float bv = (inb && ci < Cin) ? xp[ci] : 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int co = co0 + m * 16 + l15;
+                const float av = (co < Cout && ci < Cin) ? w[((int64_t)co * taps + tap) * Cin + ci] : 0.f;
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[m], 0, 0, 0);
+            }
+        }
+    }
+    if (!pv) return;
+    float* yp = y + p * y_ct + y_c0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + m * 16 + 4 * lq + r;         // C/D layout: row = 4*(l>>4)+r, col = l&15
+            if (co < Cout) yp[co] = vr_act(fmaf(acc[m][r], scale[co], shift[co]), act);
+        }
+}
+
+// depthwise KHxKW (groups = C), stride 1: x [B,H,W,C], w [C][KH][KW], y [B,H,W,C]
+__global__ void __launch_bounds__(kVrThreads)
+vr_depthwise_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int64_t n, int H, int W,
+                    int C, int KH, int KW, int pad, int dil) {
+    const int64_t i = (int64_t)blockIdx.x * kVrThreads + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int ox = (int)(p % W), oy = (int)((p / W) % H);
+    const int64_t b = p / ((int64_t)W * H);
+    const float* xb = x + b * (int64_t)H * W * C;
+    float s = 0.f;
+    for (int ky = 0; ky < KH; ++ky)
+        for (int kx = 0; kx < KW; ++kx) {
+            const int iy = oy - pad + ky * dil, ix = ox - pad + kx * dil;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) s = fmaf(xb[((int64_t)iy * W + ix) * C + c], w[(c * KH + ky) * KW + kx], s);
+        }
+    y[i] = s;
+}
+
+// bilinear resize, align_corners=True: x [B,H,W,C] -> y [B,Ho,Wo,y_ct] channel slice
+__global__ void __launch_bounds__(kVrThreads)
+vr_resize_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int H, int W, int C, int Ho, int Wo, int y_ct,
+                 int y_c0) {
+    const int64_t i = (int64_t)blockIdx.x * kVrThreads + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho);
+    const int64_t b = p / ((int64_t)Wo * Ho);
+    // torch area_pixel_compute_source_index(align_corners=True): src = dst * (in - 1) / (out - 1)
+    const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const float fy = sy * (float)oy, fx = sx * (float)ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* xb = x + b * (int64_t)H * W * C + c;
+    const float v00 = xb[((int64_t)y0 * W + x0) * C], v01 = xb[((int64_t)y0 * W + x1) * C];
+    const float v10 = xb[((int64_t)y1 * W + x0) * C], v11 = xb[((int64_t)y1 * W + x1) * C];
+    // same association as torch's upsample_bilinear2d: h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11)
+    const float hx = 1.f - lx, hy = 1.f - ly;
+    y[p * y_ct + y_c0 + c] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+}
+
+// y[b, h, wq, y_c0 + c] = x[b, h, w_off + wq, c]
+__global__ void __launch_bounds__(kVrThreads)
+vr_copy_slice_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int Wx, int C, int w_off, int Wy, int y_ct,
+                     int y_c0) {
+    const int64_t i = (int64_t)blockIdx.x * kVrThreads + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int wq = (int)(p % Wy);
+    const int64_t row = p / Wy;                              // (b, h)
+    y[p * y_ct + y_c0 + c] = x[(row * Wx + w_off + wq) * C + c];
+}
+
+// y[b, 0, w, c] = mean_h x[b, h, w, c]
+__global__ void __launch_bounds__(kVrThreads)
+vr_mean_h_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int H, int W, int C) {
+    const int64_t i = (int64_t)blockIdx.x * kVrThreads + threadIdx.x;
+    if (i >= n) return;
+    const int64_t b = i / ((int64_t)W * C), wc = i % ((int64_t)W * C);
+    const float* xb = x + b * (int64_t)H * W * C + wc;
+    float s = 0.f;
+    for (int h = 0; h < H; ++h) s += xb[(int64_t)h * W * C];
+    y[i] = s / (float)H;
+}
+
+// out[b,h,w,c] = mask^pow * mix, mask = sigmoid(logit[b, min(h, Hm-1), w, c]); pow = 1 + v/3 below split_bin, 1 + v above
+__global__ void __launch_bounds__(kVrThreads)
+vr_mask_kernel(const float* __restrict__ logit, const float* __restrict__ mix, float* __restrict__ out, int64_t n, int Hm,
+               int Hout, int W, int C, int split_bin, float aggr) {
+    const int64_t i = (int64_t)blockIdx.x * kVrThreads + threadIdx.x;
+    if (i >= n) return;
+    const int64_t wc = i % ((int64_t)W * C);
+    const int h = (int)((i / ((int64_t)W * C)) % Hout);
+    const int64_t b = i / ((int64_t)W * C * Hout);
+    const int hm = h < Hm ? h : Hm - 1;                      // F.pad(mode="replicate") along bins
+    float m = 1.f / (1.f + expf(-logit[(b * Hm + hm) * (int64_t)W * C + wc]));
+    if (aggr >= 0.f) m = powf(m, h < split_bin ? 1.f + aggr / 3.f : 1.f + aggr);
+    out[i] = m * mix[i];
+}
+
+}  // namespace
+
+extern "C" int alsep_vr_conv2d(alsep_ctx* ctx, const float* x, const float* w, const float* scale, const float* shift, float* y,
+                               int64_t B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil,
+                               int act, int y_ctotal, int y_coff) {
+    if (!ctx || !x || !w || !scale || !shift || !y) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_conv2d: null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0 || dil <= 0 ||
+        act < 0 || act > 2 || y_coff < 0 || y_coff + Cout > y_ctotal)
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_conv2d: bad shape");
+    const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_conv2d: empty output");
+    const int64_t npix = B * Ho * Wo;
+    const int64_t gx = ceil_div64(npix, 64);
+    if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_conv2d: too many pixels");
+    hipLaunchKernelGGL(vr_conv2d_kernel, dim3((unsigned)gx, (unsigned)((Cout + 31) / 32)), dim3(kVrThreads), 0, ctx->stream, x, w,
+                       scale, shift, y, npix, H, W, Cin, Cout, Ho, Wo, KH, KW, stride, pad, dil, act, y_ctotal, y_coff);
+    ALSEP_LAUNCH_CHECK(ctx, "vr_conv2d_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_vr_depthwise(alsep_ctx* ctx, const float* x, const float* w, float* y, int64_t B, int H, int W, int C,
+                                  int KH, int KW, int pad, int dil) {
+    if (!ctx || !x || !w || !y) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_depthwise: null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || KH <= 0 || KW <= 0 || pad < 0 || dil <= 0 || 2 * pad != dil * (KH - 1) ||
+        2 * pad != dil * (KW - 1))
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_depthwise: bad shape (same-size output only)");
+    const int64_t n = B * H * W * C;
+    hipLaunchKernelGGL(vr_depthwise_kernel, dim3((unsigned)ceil_div64(n, kVrThreads)), dim3(kVrThreads), 0, ctx->stream, x, w, y, n,
+                       H, W, C, KH, KW, pad, dil);
+    ALSEP_LAUNCH_CHECK(ctx, "vr_depthwise_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_vr_resize_bilinear(alsep_ctx* ctx, const float* x, float* y, int64_t B, int H, int W, int C, int Ho, int Wo,
+                                        int y_ctotal, int y_coff) {
+    if (!ctx || !x || !y) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_resize_bilinear: null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || y_coff < 0 || y_coff + C > y_ctotal)
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_resize_bilinear: bad shape");
+    const int64_t n = B * Ho * Wo * C;
+    hipLaunchKernelGGL(vr_resize_kernel, dim3((unsigned)ceil_div64(n, kVrThreads)), dim3(kVrThreads), 0, ctx->stream, x, y, n, H, W,
+                       C, Ho, Wo, y_ctotal, y_coff);
+    ALSEP_LAUNCH_CHECK(ctx, "vr_resize_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_vr_copy_slice(alsep_ctx* ctx, const float* x, float* y, int64_t BH, int Wx, int C, int w_off, int Wy,
+                                   int y_ctotal, int y_coff) {
+    if (!ctx || !x || !y) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_copy_slice: null argument");
+    if (BH <= 0 || Wx <= 0 || C <= 0 || Wy <= 0 || w_off < 0 || w_off + Wy > Wx || y_coff < 0 || y_coff + C > y_ctotal)
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_copy_slice: bad shape");
+    const int64_t n = BH * Wy * C;
+    hipLaunchKernelGGL(vr_copy_slice_kernel, dim3((unsigned)ceil_div64(n, kVrThreads)), dim3(kVrThreads), 0, ctx->stream, x, y, n,
+                       Wx, C, w_off, Wy, y_ctotal, y_coff);
+    ALSEP_LAUNCH_CHECK(ctx, "vr_copy_slice_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_vr_mean_h(alsep_ctx* ctx, const float* x, float* y, int64_t B, int H, int W, int C) {
+    if (!ctx || !x || !y) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_mean_h: null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_mean_h: bad shape");
+    const int64_t n = B * W * C;
+    hipLaunchKernelGGL(vr_mean_h_kernel, dim3((unsigned)ceil_div64(n, kVrThreads)), dim3(kVrThreads), 0, ctx->stream, x, y, n, H, W,
+                       C);
+    ALSEP_LAUNCH_CHECK(ctx, "vr_mean_h_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_vr_mask(alsep_ctx* ctx, const float* logit, const float* mix, float* out, int64_t B, int Hm, int Hout, int W,
+                             int C, int split_bin, float aggressiveness) {
+    if (!ctx || !logit || !mix || !out) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_mask: null argument");
+    if (B <= 0 || Hm <= 0 || Hout < Hm || W <= 0 || C <= 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_mask: bad shape");
+    const int64_t n = B * Hout * W * C;
+    hipLaunchKernelGGL(vr_mask_kernel, dim3((unsigned)ceil_div64(n, kVrThreads)), dim3(kVrThreads), 0, ctx->stream, logit, mix, out,
+                       n, Hm, Hout, W, C, split_bin, aggressiveness);
+    ALSEP_LAUNCH_CHECK(ctx, "vr_mask_kernel");
+    return ALSEP_OK;
+}

@@ -1,0 +1,267 @@
+"""VR-architecture network (``CascadedASPPNet``) on the HIP kernels of csrc/vrnet.hip.
+
+Mirrors the in-tree reference modules -- modules/rvc/infer/lib/uvr5_pack/lib_v5/nets*.py (``BaseASPPNet``,
+``CascadedASPPNet.forward`` / ``predict``) and layers*.py (``Conv2DBNActiv``, ``SeperableConv2DBNActiv``, ``Encoder``,
+``Decoder``, ``ASPPModule``) -- with the same parameter names, so a state_dict of the reference module loads unchanged.
+Inference only: BatchNorm uses its running statistics (folded into a per-channel scale / shift), Dropout2d is the identity.
+
+This is the network of the VR models the orchestrator names (woodwinds: stem_separator.py:596).  It is
+pinned against the reference module itself (oracle/make_golden_vr.py).  The multi-band STFT front / back end of the VR
+models (spec_utils.py, librosa resampling) is not built, so the network is reachable through this class only.
+
+Tensors are channels-last on the device: ``[B, bins, frames, C]``; the reference layout ``[B, C, bins, frames]`` exists
+at the ``forward`` / ``predict`` boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import AlsepError, Context
+
+# (stage-1 band net width, stage-2 bridge out, stage-2 width, stage-3 bridge out, stage-3 width) per reference file
+WIDTHS = {"nets": (16, 8, 16, 16, 32), "nets_61968KB": (32, 16, 32, 32, 64), "nets_123821KB": (32, 16, 32, 32, 64),
+          "nets_123812KB": (32, 16, 32, 32, 64)}
+ACT = {"none": 0, "relu": 1, "leaky": 2}
+
+
+def base_aspp_param_shapes(prefix: str, nin: int, ch: int):
+    """(name, shape) of every tensor of a ``BaseASPPNet(nin, ch)`` in module order (nets*.py:9-21)."""
+    out = []
+
+    def cba(p, ci, co, k):                                   # Conv2DBNActiv: conv.0 (Conv2d), conv.1 (BatchNorm2d)
+        out.append((f"{p}.conv.0.weight", (co, ci, k, k)))
+        for n in ("weight", "bias", "running_mean", "running_var"):
+            out.append((f"{p}.conv.1.{n}", (co,)))
+
+    def sep(p, ci, co):                                      # SeperableConv2DBNActiv: depthwise, pointwise, BN
+        out.append((f"{p}.conv.0.weight", (ci, 1, 3, 3)))
+        out.append((f"{p}.conv.1.weight", (co, ci, 1, 1)))
+        for n in ("weight", "bias", "running_mean", "running_var"):
+            out.append((f"{p}.conv.2.{n}", (co,)))
+
+    chans = [(nin, ch), (ch, 2 * ch), (2 * ch, 4 * ch), (4 * ch, 8 * ch)]
+    for i, (ci, co) in enumerate(chans, 1):
+        cba(f"{prefix}.enc{i}.conv1", ci, co, 3)
+        cba(f"{prefix}.enc{i}.conv2", co, co, 3)
+    c8 = 8 * ch
+    cba(f"{prefix}.aspp.conv1.1", c8, c8, 1)
+    cba(f"{prefix}.aspp.conv2", c8, c8, 1)
+    for j in (3, 4, 5):
+        sep(f"{prefix}.aspp.conv{j}", c8, c8)
+    cba(f"{prefix}.aspp.bottleneck.0", 5 * c8, 16 * ch, 1)
+    for i, (ci, co) in zip((4, 3, 2, 1), ((24 * ch, 8 * ch), (12 * ch, 4 * ch), (6 * ch, 2 * ch), (3 * ch, ch))):
+        cba(f"{prefix}.dec{i}.conv", ci, co, 3)
+    return out
+
+
+def cascaded_param_shapes(widths: Sequence[int]):
+    w1, b2, w2, b3, w3 = widths
+    out = base_aspp_param_shapes("stg1_low_band_net", 2, w1) + base_aspp_param_shapes("stg1_high_band_net", 2, w1)
+    out.append(("stg2_bridge.conv.0.weight", (b2, 2 + w1, 1, 1)))
+    out += [(f"stg2_bridge.conv.1.{n}", (b2,)) for n in ("weight", "bias", "running_mean", "running_var")]
+    out += base_aspp_param_shapes("stg2_full_band_net", b2, w2)
+    out.append(("stg3_bridge.conv.0.weight", (b3, 2 + w1 + w2, 1, 1)))
+    out += [(f"stg3_bridge.conv.1.{n}", (b3,)) for n in ("weight", "bias", "running_mean", "running_var")]
+    out += base_aspp_param_shapes("stg3_full_band_net", b3, w3)
+    out += [("out.weight", (2, w3, 1, 1)), ("aux1_out.weight", (2, w1, 1, 1)), ("aux2_out.weight", (2, w2, 1, 1))]
+    return out
+
+
+def random_state_dict(widths: Sequence[int], seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded random weights with the reference's parameter names (fixtures, smoke runs): Kaiming-scaled convolutions,
+    BatchNorm statistics away from the identity so that the folding is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in cascaded_param_shapes(widths):
+        if name.endswith("running_var"):
+            t = 0.5 + torch.rand(shape, generator=g)
+        elif name.endswith("running_mean") or name.endswith(".bias"):
+            t = 0.1 * torch.randn(shape, generator=g)
+        elif len(shape) == 1:                                # BatchNorm gamma
+            t = 0.8 + 0.4 * torch.rand(shape, generator=g)
+        else:
+            fan_in = shape[1] * shape[2] * shape[3]
+            t = torch.randn(shape, generator=g) * (2.0 / fan_in) ** 0.5
+        sd[name] = t.float()
+    return sd
+
+
+class _Conv:
+    """Conv2d(bias=False) [+ BatchNorm2d eval] with weights packed [Cout][KH][KW][Cin] on the device."""
+
+    def __init__(self, ctx: Context, sd, conv_key: str, bn_prefix: Optional[str], act: str, stride=1, pad=0, dil=1, eps=1e-5):
+        w = sd[conv_key].float()
+        self.cout, self.cin, self.kh, self.kw = w.shape
+        self.w = w.permute(0, 2, 3, 1).contiguous().to(ctx.device)
+        if bn_prefix is not None:
+            gamma, beta = sd[bn_prefix + ".weight"].float(), sd[bn_prefix + ".bias"].float()
+            mean, var = sd[bn_prefix + ".running_mean"].float(), sd[bn_prefix + ".running_var"].float()
+            scale = gamma / torch.sqrt(var + eps)
+            shift = beta - mean * scale
+        else:
+            scale, shift = torch.ones(self.cout), torch.zeros(self.cout)
+        self.scale, self.shift = scale.contiguous().to(ctx.device), shift.contiguous().to(ctx.device)
+        self.act, self.stride, self.pad, self.dil = ACT[act], stride, pad, dil
+
+    def out_hw(self, h, w):
+        return ((h + 2 * self.pad - self.dil * (self.kh - 1) - 1) // self.stride + 1,
+                (w + 2 * self.pad - self.dil * (self.kw - 1) - 1) // self.stride + 1)
+
+
+class VRNet:
+    """``CascadedASPPNet(n_fft)`` of the reference; ``variant`` picks the channel widths of one of its files."""
+
+    def __init__(self, n_fft: int, state_dict: Dict[str, torch.Tensor], variant: str = "nets_61968KB", ctx: Optional[Context] = None):
+        self.ctx = ctx if ctx is not None else _lib.default_context(None)
+        if variant not in WIDTHS:
+            raise AlsepError(f"unknown VR net variant '{variant}' (have {sorted(WIDTHS)})")
+        self.widths = WIDTHS[variant]
+        missing = [n for n, _ in cascaded_param_shapes(self.widths) if n not in state_dict]
+        if missing:
+            raise AlsepError(f"VR state_dict lacks {len(missing)} tensors, e.g. {missing[:3]}")
+        for n, shape in cascaded_param_shapes(self.widths):
+            if tuple(state_dict[n].shape) != tuple(shape):
+                raise AlsepError(f"VR state_dict: {n} has shape {tuple(state_dict[n].shape)}, expected {shape}")
+        self.max_bin, self.output_bin, self.offset = n_fft // 2, n_fft // 2 + 1, 128
+        sd = state_dict
+        w1, b2, w2, b3, w3 = self.widths
+        self.nets = {p: self._build_base(sd, p, nin, ch) for p, nin, ch in (
+            ("stg1_low_band_net", 2, w1), ("stg1_high_band_net", 2, w1), ("stg2_full_band_net", b2, w2), ("stg3_full_band_net", b3, w3))}
+        self.stg2_bridge = _Conv(self.ctx, sd, "stg2_bridge.conv.0.weight", "stg2_bridge.conv.1", "relu")
+        self.stg3_bridge = _Conv(self.ctx, sd, "stg3_bridge.conv.0.weight", "stg3_bridge.conv.1", "relu")
+        self.out = _Conv(self.ctx, sd, "out.weight", None, "none")
+
+    # -- construction ------------------------------------------------------------------------------
+    def _build_base(self, sd, p, nin, ch):
+        c = self.ctx
+        net = {"ch": ch}
+        for i in (1, 2, 3, 4):                                # Encoder: LeakyReLU, conv2 has stride 2 (nets*.py:12-15)
+            net[f"enc{i}.conv1"] = _Conv(c, sd, f"{p}.enc{i}.conv1.conv.0.weight", f"{p}.enc{i}.conv1.conv.1", "leaky", 1, 1)
+            net[f"enc{i}.conv2"] = _Conv(c, sd, f"{p}.enc{i}.conv2.conv.0.weight", f"{p}.enc{i}.conv2.conv.1", "leaky", 2, 1)
+        net["aspp.conv1"] = _Conv(c, sd, f"{p}.aspp.conv1.1.conv.0.weight", f"{p}.aspp.conv1.1.conv.1", "relu")
+        net["aspp.conv2"] = _Conv(c, sd, f"{p}.aspp.conv2.conv.0.weight", f"{p}.aspp.conv2.conv.1", "relu")
+        for j, d in zip((3, 4, 5), (4, 8, 16)):              # separable: depthwise 3x3 dilated, pointwise + BN + ReLU
+            dw = sd[f"{p}.aspp.conv{j}.conv.0.weight"].float()
+            net[f"aspp.conv{j}.dw"] = (dw.reshape(dw.shape[0], 3, 3).contiguous().to(c.device), d)
+            net[f"aspp.conv{j}.pw"] = _Conv(c, sd, f"{p}.aspp.conv{j}.conv.1.weight", f"{p}.aspp.conv{j}.conv.2", "relu")
+        net["aspp.bottleneck"] = _Conv(c, sd, f"{p}.aspp.bottleneck.0.conv.0.weight", f"{p}.aspp.bottleneck.0.conv.1", "relu")
+        for i in (4, 3, 2, 1):
+            net[f"dec{i}"] = _Conv(c, sd, f"{p}.dec{i}.conv.conv.0.weight", f"{p}.dec{i}.conv.conv.1", "relu", 1, 1)
+        return net
+
+    # -- kernels -------------------------------------------------------------------------------------
+    def _conv(self, L: _Conv, x: torch.Tensor, y: Optional[torch.Tensor] = None, c0: int = 0) -> torch.Tensor:
+        b, h, w, cin = x.shape
+        if cin != L.cin:
+            raise AlsepError(f"conv expects {L.cin} input channels, got {cin}")
+        ho, wo = L.out_hw(h, w)
+        if y is None:
+            y = self.ctx.empty((b, ho, wo, L.cout))
+        ctx = self.ctx
+        ctx.check(ctx.lib.alsep_vr_conv2d(ctx.handle, _lib.ptr(x), _lib.ptr(L.w), _lib.ptr(L.scale), _lib.ptr(L.shift), _lib.ptr(y),
+                                          b, h, w, L.cin, L.cout, L.kh, L.kw, L.stride, L.pad, L.dil, L.act, y.shape[3], c0),
+                  "alsep_vr_conv2d")
+        return y
+
+    def _resize(self, x, ho, wo, y, c0):
+        b, h, w, c = x.shape
+        ctx = self.ctx
+        ctx.check(ctx.lib.alsep_vr_resize_bilinear(ctx.handle, _lib.ptr(x), _lib.ptr(y), b, h, w, c, ho, wo, y.shape[3], c0),
+                  "alsep_vr_resize_bilinear")
+
+    def _copy(self, x, y, c0, w_off=0):
+        b, h, wx, c = x.shape
+        ctx = self.ctx
+        ctx.check(ctx.lib.alsep_vr_copy_slice(ctx.handle, _lib.ptr(x), _lib.ptr(y), b * h, wx, c, w_off, y.shape[2], y.shape[3], c0),
+                  "alsep_vr_copy_slice")
+
+    # -- modules ---------------------------------------------------------------------------------------
+    def _decoder(self, L: _Conv, x, skip):
+        """layers*.py:83-93: upsample x2 (bilinear, align_corners), crop_center(skip) along frames, cat, conv."""
+        b, h, w, c = x.shape
+        ho, wo = 2 * h, 2 * w
+        if skip.shape[1] != ho or skip.shape[2] < wo:
+            raise AlsepError(f"decoder: skip {tuple(skip.shape)} does not fit the upsampled {ho}x{wo} map")
+        cat = self.ctx.empty((b, ho, wo, c + skip.shape[3]))
+        self._resize(x, ho, wo, cat, 0)
+        self._copy(skip, cat, c, (skip.shape[2] - wo) // 2)
+        return self._conv(L, cat)
+
+    def _aspp(self, net, x):
+        """layers*.py:96-125."""
+        ctx = self.ctx
+        b, h, w, c = x.shape
+        cat = ctx.empty((b, h, w, 5 * c))
+        pooled = ctx.empty((b, 1, w, c))
+        ctx.check(ctx.lib.alsep_vr_mean_h(ctx.handle, _lib.ptr(x), _lib.ptr(pooled), b, h, w, c), "alsep_vr_mean_h")
+        self._resize(self._conv(net["aspp.conv1"], pooled), h, w, cat, 0)
+        self._conv(net["aspp.conv2"], x, cat, c)
+        for k, j in enumerate((3, 4, 5)):
+            dw, d = net[f"aspp.conv{j}.dw"]
+            t = ctx.empty((b, h, w, c))
+            ctx.check(ctx.lib.alsep_vr_depthwise(ctx.handle, _lib.ptr(x), _lib.ptr(dw), _lib.ptr(t), b, h, w, c, 3, 3, d, d),
+                      "alsep_vr_depthwise")
+            self._conv(net[f"aspp.conv{j}.pw"], t, cat, (2 + k) * c)
+        return self._conv(net["aspp.bottleneck"], cat)
+
+    def _base(self, name, x):
+        """nets*.py:23-37."""
+        net = self.nets[name]
+        skips = []
+        h = x
+        for i in (1, 2, 3, 4):
+            s = self._conv(net[f"enc{i}.conv1"], h)
+            h = self._conv(net[f"enc{i}.conv2"], s)
+            skips.append(s)
+        h = self._aspp(net, h)
+        for i in (4, 3, 2, 1):
+            h = self._decoder(net[f"dec{i}"], h, skips[i - 1])
+        return h
+
+    # -- forward -------------------------------------------------------------------------------------------
+    def forward_nhwc(self, x: torch.Tensor, aggressiveness: Optional[dict] = None) -> torch.Tensor:
+        """x [B, bins >= max_bin, frames, 2] magnitudes -> mask * x, [B, output_bin, frames, 2] (nets*.py:59-111, eval)."""
+        ctx = self.ctx
+        if x.dim() != 4 or x.shape[3] != 2 or x.shape[1] < self.output_bin or x.dtype != torch.float32:
+            raise AlsepError(f"VRNet input must be float32 [B, >= {self.output_bin} bins, frames, 2], got {tuple(x.shape)}")
+        x = x.contiguous()
+        mix = x[:, : self.output_bin].contiguous()
+        xin = x[:, : self.max_bin].contiguous()
+        b, hh, w, _ = xin.shape
+        bandw = hh // 2
+        w1, b2, w2, b3, w3 = self.widths
+        low = self._base("stg1_low_band_net", xin[:, :bandw].contiguous())
+        high = self._base("stg1_high_band_net", xin[:, bandw:].contiguous())
+        h1 = ctx.empty((b, hh, w, 2 + w1))                      # cat([x, aux1], channels)
+        self._copy(xin, h1, 0)
+        aux1 = torch.cat([low, high], dim=1).contiguous()       # along bins: plain tensor plumbing
+        self._copy(aux1, h1, 2)
+        aux2 = self._base("stg2_full_band_net", self._conv(self.stg2_bridge, h1))
+        h2 = ctx.empty((b, hh, w, 2 + w1 + w2))
+        self._copy(h1, h2, 0)
+        self._copy(aux2, h2, 2 + w1)
+        h3 = self._base("stg3_full_band_net", self._conv(self.stg3_bridge, h2))
+        logit = self._conv(self.out, h3)
+        out = ctx.empty(tuple(mix.shape))
+        split, aggr = (int(aggressiveness["split_bin"]), float(aggressiveness["value"])) if aggressiveness else (0, -1.0)
+        ctx.check(ctx.lib.alsep_vr_mask(ctx.handle, _lib.ptr(logit), _lib.ptr(mix), _lib.ptr(out), b, logit.shape[1], self.output_bin,
+                                        w, 2, split, C.c_float(aggr)), "alsep_vr_mask")
+        return out
+
+    def forward(self, x_mag: torch.Tensor, aggressiveness: Optional[dict] = None) -> torch.Tensor:
+        """Reference layout [B, 2, bins, frames] in and out."""
+        x = torch.as_tensor(x_mag, dtype=torch.float32).permute(0, 2, 3, 1).contiguous().to(self.ctx.device)
+        return self.forward_nhwc(x, aggressiveness).permute(0, 3, 1, 2).contiguous()
+
+    def predict(self, x_mag: torch.Tensor, aggressiveness: Optional[dict] = None) -> torch.Tensor:
+        """nets*.py:113-121: forward, then drop ``offset`` frames on both sides."""
+        h = self.forward(x_mag, aggressiveness)
+        if self.offset > 0:
+            h = h[:, :, :, self.offset:-self.offset]
+            if h.shape[3] <= 0:
+                raise AlsepError("predict: fewer than 2 * offset frames")
+        return h

@@ -166,6 +166,30 @@ int alsep_xcorr_window(alsep_ctx* ctx, const float* ref, const float* sig, int64
 int alsep_shift_subtract(alsep_ctx* ctx, const float* ref, const float* sig, int64_t len, int lag,
                          float alpha, float* out);
 
+/* ---- VR-architecture building blocks (CascadedASPPNet: reference modules/rvc/infer/lib/uvr5_pack/lib_v5/nets*.py,
+ * layers*.py).  Channels-last float32 tensors [B, H = bins, W = frames, C].  Outputs that feed a
+ * torch.cat are written into the channel slice [y_coff, y_coff + C) of a tensor with y_ctotal channels. ---- */
+/* y = act(conv2d(x, w) * scale + shift): nn.Conv2d(bias=False) + folded BatchNorm2d + activation (layers*.py:9-27);
+ * w packed [Cout][KH][KW][Cin]; act 0 none, 1 ReLU, 2 LeakyReLU(0.01).  Output size as torch: (H + 2 pad - dil (KH-1) - 1) / stride + 1. */
+int alsep_vr_conv2d(alsep_ctx* ctx, const float* x, const float* w, const float* scale, const float* shift, float* y,
+                    int64_t B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int act,
+                    int y_ctotal, int y_coff);
+/* depthwise (groups = C) KHxKW dilated convolution, same-size output (layers*.py:30-52); w packed [C][KH][KW] */
+int alsep_vr_depthwise(alsep_ctx* ctx, const float* x, const float* w, float* y, int64_t B, int H, int W, int C, int KH, int KW,
+                       int pad, int dil);
+/* F.interpolate(mode="bilinear", align_corners=True) to (Ho, Wo) (layers*.py:84, 111) */
+int alsep_vr_resize_bilinear(alsep_ctx* ctx, const float* x, float* y, int64_t B, int H, int W, int C, int Ho, int Wo,
+                             int y_ctotal, int y_coff);
+/* spec_utils.crop_center (spec_utils.py:12-27) + concat: y[bh, wq, y_coff + c] = x[bh, w_off + wq, c]; BH = B * H rows */
+int alsep_vr_copy_slice(alsep_ctx* ctx, const float* x, float* y, int64_t BH, int Wx, int C, int w_off, int Wy, int y_ctotal,
+                        int y_coff);
+/* nn.AdaptiveAvgPool2d((1, None)) (layers*.py:93): mean over bins -> [B, 1, W, C] */
+int alsep_vr_mean_h(alsep_ctx* ctx, const float* x, float* y, int64_t B, int H, int W, int C);
+/* nets*.py:80-111: mask = sigmoid(logit) replicate-padded from Hm to Hout bins, mask ** (1 + a/3) below split_bin and
+ * ** (1 + a) from it on when aggressiveness a >= 0, out = mask * mix */
+int alsep_vr_mask(alsep_ctx* ctx, const float* logit, const float* mix, float* out, int64_t B, int Hm, int Hout, int W, int C,
+                  int split_bin, float aggressiveness);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Golden vectors for the VR-architecture network (TEST INFRASTRUCTURE).
+
+Imports the REFERENCE modules modules/rvc/infer/lib/uvr5_pack/lib_v5/nets.py / nets_61968KB.py (+ layers*.py) in this
+container with ``librosa`` / ``soundfile`` stubbed (spec_utils.py imports them at module scope; the network classes do
+not use them), loads the seeded random state_dict of audiolab_amd.vrnet.random_state_dict into ``CascadedASPPNet`` (eval
+mode) and records its output on a seeded random magnitude spectrogram.  Weights are regenerated from the seed by the
+tests, so the fixture holds only inputs / outputs: tests/golden/vrnet.npz.
+
+    python oracle/make_golden_vr.py       (only where /root/reference exists)
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+from audiolab_amd.vrnet import WIDTHS, random_state_dict  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def load_ref_nets(variant: str):
+    for name in ("librosa", "soundfile"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    pkg_dir = os.path.join(REF, "modules/rvc/infer/lib/uvr5_pack/lib_v5")
+    pkg = types.ModuleType("ref_lib_v5")
+    pkg.__path__ = [pkg_dir]
+    sys.modules["ref_lib_v5"] = pkg
+    if variant == "nets":                                     # nets.py does a top-level "import layers"
+        sys.modules["layers"] = importlib.import_module("ref_lib_v5.layers")
+    return importlib.import_module(f"ref_lib_v5.{variant}")
+
+
+def main():
+    out = {}
+    cases = [("nets", 128, 48, 11, None), ("nets", 128, 32, 12, {"split_bin": 24, "value": 0.3}),
+             ("nets_61968KB", 64, 32, 13, None)]
+    for k, (variant, n_fft, frames, seed, aggr) in enumerate(cases):
+        mod = load_ref_nets(variant)
+        net = mod.CascadedASPPNet(n_fft)
+        sd = random_state_dict(WIDTHS[variant], seed=seed)
+        missing, unexpected = net.load_state_dict(sd, strict=False)
+        assert not unexpected, unexpected
+        assert all(m.endswith("num_batches_tracked") for m in missing), missing
+        net.eval()
+        g = torch.Generator().manual_seed(100 + seed)
+        x = torch.rand((2, 2, n_fft // 2 + 1, frames), generator=g) * 3.0
+        with torch.no_grad():
+            y = net.forward(x, aggr)
+        out[f"c{k}_cfg"] = np.array([n_fft, frames, seed, -1 if aggr is None else aggr["split_bin"]], dtype=np.int64)
+        out[f"c{k}_aggr"] = np.array([-1.0 if aggr is None else aggr["value"]], dtype=np.float64)
+        out[f"c{k}_variant"] = np.array(variant)
+        out[f"c{k}_x"] = x.numpy()
+        out[f"c{k}_y"] = y.numpy()
+        print(variant, n_fft, frames, "out", tuple(y.shape), "peak", float(y.abs().max()))
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "vrnet.npz"), **out)
+    print(os.path.getsize(os.path.join(OUT, "vrnet.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

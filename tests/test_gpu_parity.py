@@ -229,3 +229,19 @@ def test_long_form_8ch_ola_075(ctx):
     b = OlaRunner(Lin(ident), ctx=ctx, overlap=0.25, compensate=1.0, max_batch=8).demix(torch.from_numpy(mix8[2:4]).cuda())
     lo, hi = 300000 - 100000, 300000 + 100000               # interior: every sample fully covered at both overlaps
     assert float((a[:, lo:hi] - b[:, lo:hi]).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_vrnet_matches_reference_module(ctx, golden_dir, k):
+    """VR-architecture network (csrc/vrnet.hip) against the reference's own CascadedASPPNet outputs
+    (tests/golden/vrnet.npz, oracle/make_golden_vr.py); fp32 storage + exact-f32 MFMA, |delta| < 1e-4."""
+    from audiolab_amd.vrnet import WIDTHS, VRNet, random_state_dict
+    z = np.load(os.path.join(golden_dir, "vrnet.npz"))
+    n_fft, frames, seed, split = (int(v) for v in z[f"c{k}_cfg"])
+    aggr = None if split < 0 else {"split_bin": split, "value": float(z[f"c{k}_aggr"][0])}
+    variant = str(z[f"c{k}_variant"])
+    net = VRNet(n_fft, random_state_dict(WIDTHS[variant], seed=seed), variant=variant, ctx=ctx)
+    got = net.forward(torch.from_numpy(z[f"c{k}_x"]), aggr).cpu().numpy()
+    want = z[f"c{k}_y"]
+    assert got.shape == want.shape
+    assert float(np.max(np.abs(got - want))) < 1e-4 * max(1.0, float(np.max(np.abs(want))))
