@@ -4,7 +4,7 @@
 // First HIP path for this family: correct and generic (any channel count, kernel size, stride, dilation), fp32 storage
 // and exact-f32 MFMA (v_mfma_f32_16x16x4_f32, a k-ordered fmaf chain) so that it can be pinned against the in-tree torch
 // modules; not yet tuned (operands come straight from global memory / L1, no LDS staging).
-//   conv2d      : implicit GEMM, one wave = 16 output pixels x 32 output channels, K = (tap, ci) in steps of 4;
+//   conv2d      : implicit GEMM, one wave = 32 output pixels x 64 output channels, K = (tap, ci) in steps of 4;
 //                 epilogue y = act(acc * scale + shift) (BatchNorm folded), written into a channel slice of the output
 //                 tensor (so the concatenations of the decoders / ASPP need no copy)
 //   depthwise   : 3x3 dilated, one thread per (pixel, channel)
@@ -25,46 +25,74 @@ __device__ __forceinline__ float vr_act(float v, int act) {
     return v;
 }
 
-// x [B,H,W,Cin], w [Cout][KH][KW][Cin], y [B,Ho,Wo,y_ct] at channel offset y_c0
+// x [B,H,W,Cin], w [KH][KW][Cin][Cout] (output channel fastest: the A-fragment loads of 16 lanes are one 64-byte run),
+// y [B,Ho,Wo,y_ct] at channel offset y_c0.  One wave = 32 output pixels x 64 output channels: 8 MFMAs per k-step for
+// 2 activation + 4 weight loads per lane.
 __global__ void __launch_bounds__(kVrThreads)
 vr_conv2d_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                  const float* __restrict__ shift, float* __restrict__ y, int64_t npix, int H, int W, int Cin, int Cout,
                  int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int act, int y_ct, int y_c0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int64_t p = ((int64_t)blockIdx.x * 4 + wave) * 16 + l15;      // this lane's output pixel (B column of the MFMA)
-    const int co0 = blockIdx.y * 32;
-    const bool pv = p < npix;
-    const int64_t pp = pv ? p : 0;
-    const int ox = (int)(pp % Wo), oy = (int)((pp / Wo) % Ho);
-    const int64_t b = pp / ((int64_t)Wo * Ho);
-    const float* xb = x + b * (int64_t)H * W * Cin;
+    const int co0 = blockIdx.y * 64;
+    int64_t p[2];
+    bool pv[2];
+    int oy[2], ox[2];
+    const float* xb[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        p[n] = ((int64_t)blockIdx.x * 4 + wave) * 32 + n * 16 + l15;     // this lane's output pixels (B columns)
+        pv[n] = p[n] < npix;
+        const int64_t pp = pv[n] ? p[n] : 0;
+        ox[n] = (int)(pp % Wo);
+        oy[n] = (int)((pp / Wo) % Ho);
+        xb[n] = x + (pp / ((int64_t)Wo * Ho)) * (int64_t)H * W * Cin;
+    }
     const int taps = KH * KW;
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int tap = 0; tap < taps; ++tap) {
-        const int iy = oy * stride - pad + (tap / KW) * dil, ix = ox * stride - pad + (tap % KW) * dil;
-        const bool inb = pv && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        const float* xp = xb + ((int64_t)(inb ? iy : 0) * W + (inb ? ix : 0)) * Cin;
+        const float* xp[2];
+        bool inb[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int iy = oy[n] * stride - pad + (tap / KW) * dil, ix = ox[n] * stride - pad + (tap % KW) * dil;
+            inb[n] = pv[n] && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            xp[n] = xb[n] + ((int64_t)(inb[n] ? iy : 0) * W + (inb[n] ? ix : 0)) * Cin;
+        }
+        const float* wt = w + (int64_t)tap * Cin * Cout;
         for (int c = 0; c < Cin; c += 4) {
             const int ci = c + lq;
-            const float bv = (inb && ci < Cin) ? xp[ci] : 0.f;
+            const bool cv = ci < Cin;
+            float bv[2], av[4];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+            for (int n = 0; n < 2; ++n) bv[n] = (inb[n] && cv) ? xp[n][ci] : 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
                 const int co = co0 + m * 16 + l15;
-                const float av = (co < Cout && ci < Cin) ? w[((int64_t)co * taps + tap) * Cin + ci] : 0.f;
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[m], 0, 0, 0);
+                av[m] = (cv && co < Cout) ? wt[(int64_t)ci * Cout + co] : 0.f;
             }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[n], acc[m][n], 0, 0, 0);
         }
     }
-    if (!pv) return;
-    float* yp = y + p * y_ct + y_c0;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int n = 0; n < 2; ++n) {
+        if (!pv[n]) continue;
+        float* yp = y + p[n] * y_ct + y_c0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = co0 + m * 16 + 4 * lq + r;         // C/D layout: row = 4*(l>>4)+r, col = l&15
-            if (co < Cout) yp[co] = vr_act(fmaf(acc[m][r], scale[co], shift[co]), act);
-        }
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + m * 16 + 4 * lq + r;         // C/D layout: row = 4*(l>>4)+r, col = l&15
+                if (co < Cout) yp[co] = vr_act(fmaf(acc[m][n][r], scale[co], shift[co]), act);
+            }
+    }
 }
 
 // depthwise KHxKW (groups = C), stride 1: x [B,H,W,C], w [C][KH][KW], y [B,H,W,C]
@@ -163,9 +191,9 @@ extern "C" int alsep_vr_conv2d(alsep_ctx* ctx, const float* x, const float* w, c
     const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_conv2d: empty output");
     const int64_t npix = B * Ho * Wo;
-    const int64_t gx = ceil_div64(npix, 64);
+    const int64_t gx = ceil_div64(npix, 128);
     if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_conv2d: too many pixels");
-    hipLaunchKernelGGL(vr_conv2d_kernel, dim3((unsigned)gx, (unsigned)((Cout + 31) / 32)), dim3(kVrThreads), 0, ctx->stream, x, w,
+    hipLaunchKernelGGL(vr_conv2d_kernel, dim3((unsigned)gx, (unsigned)((Cout + 63) / 64)), dim3(kVrThreads), 0, ctx->stream, x, w,
                        scale, shift, y, npix, H, W, Cin, Cout, Ho, Wo, KH, KW, stride, pad, dil, act, y_ctotal, y_coff);
     ALSEP_LAUNCH_CHECK(ctx, "vr_conv2d_kernel");
     return ALSEP_OK;

@@ -91,12 +91,12 @@ def random_state_dict(widths: Sequence[int], seed: int = 0) -> Dict[str, torch.T
 
 
 class _Conv:
-    """Conv2d(bias=False) [+ BatchNorm2d eval] with weights packed [Cout][KH][KW][Cin] on the device."""
+    """Conv2d(bias=False) [+ BatchNorm2d eval] with weights packed [KH][KW][Cin][Cout] on the device."""
 
     def __init__(self, ctx: Context, sd, conv_key: str, bn_prefix: Optional[str], act: str, stride=1, pad=0, dil=1, eps=1e-5):
         w = sd[conv_key].float()
         self.cout, self.cin, self.kh, self.kw = w.shape
-        self.w = w.permute(0, 2, 3, 1).contiguous().to(ctx.device)
+        self.w = w.permute(2, 3, 1, 0).contiguous().to(ctx.device)
         if bn_prefix is not None:
             gamma, beta = sd[bn_prefix + ".weight"].float(), sd[bn_prefix + ".bias"].float()
             mean, var = sd[bn_prefix + ".running_mean"].float(), sd[bn_prefix + ".running_var"].float()

@@ -170,7 +170,7 @@ int alsep_shift_subtract(alsep_ctx* ctx, const float* ref, const float* sig, int
  * layers*.py).  Channels-last float32 tensors [B, H = bins, W = frames, C].  Outputs that feed a
  * torch.cat are written into the channel slice [y_coff, y_coff + C) of a tensor with y_ctotal channels. ---- */
 /* y = act(conv2d(x, w) * scale + shift): nn.Conv2d(bias=False) + folded BatchNorm2d + activation (layers*.py:9-27);
- * w packed [Cout][KH][KW][Cin]; act 0 none, 1 ReLU, 2 LeakyReLU(0.01).  Output size as torch: (H + 2 pad - dil (KH-1) - 1) / stride + 1. */
+ * w packed [KH][KW][Cin][Cout]; act 0 none, 1 ReLU, 2 LeakyReLU(0.01).  Output size as torch: (H + 2 pad - dil (KH-1) - 1) / stride + 1. */
 int alsep_vr_conv2d(alsep_ctx* ctx, const float* x, const float* w, const float* scale, const float* shift, float* y,
                     int64_t B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int act,
                     int y_ctotal, int y_coff);
