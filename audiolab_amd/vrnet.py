@@ -265,3 +265,54 @@ class VRNet:
             if h.shape[3] <= 0:
                 raise AlsepError("predict: fewer than 2 * offset frames")
         return h
+
+
+def make_padding(width: int, cropsize: int, offset: int) -> Tuple[int, int, int]:
+    """utils.py:15-22."""
+    left = offset
+    roi_size = cropsize - left * 2
+    if roi_size == 0:
+        roi_size = cropsize
+    right = roi_size - (width % roi_size) + left
+    return left, right, roi_size
+
+
+def vr_inference(net: VRNet, x_spec: torch.Tensor, aggressiveness: Optional[dict], window_size: int, tta: bool = False,
+                 max_batch: int = 4):
+    """The VR runner: reference modules/rvc/infer/lib/uvr5_pack/utils.py:25-100 (``inference``) on the device.
+
+    x_spec complex64 [2, bins, frames] -> (pred * coef [2, bins, frames], |X|, exp(i angle X)).  The magnitude is
+    normalised by its maximum, zero-padded by ``offset`` frames (plus the remainder of the last window), cut into windows
+    of ``window_size`` frames every ``roi_size = window_size - 2 offset`` and each window goes through ``predict`` (the
+    network, then ``offset`` frames dropped on both sides); with ``tta`` a second pass shifted by half a window is
+    averaged in.  Windows are independent: here they run ``max_batch`` at a time instead of one by one."""
+    ctx = net.ctx
+    x_spec = x_spec.to(ctx.device)
+    x_mag = x_spec.abs().float()
+    phase = torch.polar(torch.ones_like(x_mag), torch.angle(x_spec))
+    coef = x_mag.max()
+    pre = x_mag / coef
+    n_frame = pre.shape[2]
+    off = net.offset
+
+    def execute(pad_l, pad_r, roi, n_window):
+        padded = torch.nn.functional.pad(pre, (pad_l, pad_r))                      # [2, bins, frames]
+        nhwc = padded.permute(1, 2, 0).contiguous()                                # [bins, frames, 2]
+        preds = []
+        for w0 in range(0, n_window, max_batch):
+            nb = min(max_batch, n_window - w0)
+            win = torch.stack([nhwc[:, (w0 + i) * roi:(w0 + i) * roi + window_size] for i in range(nb)]).contiguous()
+            if win.shape[2] != window_size:
+                raise AlsepError("vr_inference: window runs past the padded spectrogram")
+            out = net.forward_nhwc(win, aggressiveness)                            # [nb, output_bin, window, 2]
+            out = out[:, :, off:window_size - off] if off > 0 else out
+            preds.extend(out[i] for i in range(nb))
+        return torch.cat(preds, dim=1).permute(2, 0, 1)                            # [2, bins, n_window * roi]
+
+    pad_l, pad_r, roi = make_padding(n_frame, window_size, off)
+    n_window = -(-n_frame // roi)
+    pred = execute(pad_l, pad_r, roi, n_window)[:, :, :n_frame]
+    if tta:
+        pred_t = execute(pad_l + roi // 2, pad_r + roi // 2, roi, n_window + 1)[:, :, roi // 2:][:, :, :n_frame]
+        pred = (pred + pred_t) * 0.5
+    return pred * coef, x_mag, phase

@@ -12,6 +12,7 @@ tests, so the fixture holds only inputs / outputs: tests/golden/vrnet.npz.
 from __future__ import annotations
 
 import importlib
+import importlib.util
 import os
 import sys
 import types
@@ -61,6 +62,25 @@ def main():
         out[f"c{k}_x"] = x.numpy()
         out[f"c{k}_y"] = y.numpy()
         print(variant, n_fft, frames, "out", tuple(y.shape), "peak", float(y.abs().max()))
+    # the VR runner (utils.py:25-100 ``inference``: normalise, pad, window, predict, concat, optional TTA) with the same net;
+    # ``offset`` is an attribute of the module (128 in the reference): 8 here so that the windows stay small
+    spec = importlib.util.spec_from_file_location("ref_uvr5_utils", os.path.join(REF, "modules/rvc/infer/lib/uvr5_pack/utils.py"))
+    utils = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(utils)
+    utils.tqdm = lambda it: it
+    mod = load_ref_nets("nets")
+    net = mod.CascadedASPPNet(64)
+    net.load_state_dict(random_state_dict(WIDTHS["nets"], seed=21), strict=False)
+    net.eval()
+    net.offset = 8
+    g = torch.Generator().manual_seed(77)
+    xs = (torch.randn((2, 33, 70), generator=g) + 1j * torch.randn((2, 33, 70), generator=g)).numpy().astype(np.complex64)
+    for tag, tta, aggr in (("plain", False, None), ("tta", True, {"split_bin": 12, "value": 0.2})):
+        pred, x_mag, phase = utils.inference(xs, "cpu", net, aggr, {"window_size": 48, "tta": tta})
+        out[f"inf_{tag}_pred"] = pred.astype(np.float32)
+        print("inference", tag, pred.shape, float(np.abs(pred).max()))
+    out["inf_x"] = xs
+    out["inf_mag"], out["inf_phase"] = x_mag.astype(np.float32), phase.astype(np.complex64)
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, "vrnet.npz"), **out)
     print(os.path.getsize(os.path.join(OUT, "vrnet.npz")), "bytes")

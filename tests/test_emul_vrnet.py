@@ -15,7 +15,7 @@ def load_case(z, k):
     return str(z[f"c{k}_variant"]), n_fft, seed, aggr, z[f"c{k}_x"], z[f"c{k}_y"]
 
 
-@pytest.mark.parametrize("k", [0, 1, 2])
+@pytest.mark.parametrize("k", [1])       # all three cases run on the GPU (tests/test_gpu_parity.py); one keeps the CPU suite short
 def test_vrnet_matches_reference_module(emul, golden_dir, k):
     from audiolab_amd.vrnet import WIDTHS, VRNet, random_state_dict
     z = np.load(os.path.join(golden_dir, "vrnet.npz"))
@@ -40,3 +40,19 @@ def test_vrnet_rejects_bad_state(emul):
     net = VRNet(128, sd, variant="nets", ctx=emul)
     with pytest.raises(AlsepError):
         net.forward_nhwc(torch.zeros((1, 40, 16, 2)))           # fewer bins than n_fft / 2 + 1
+
+
+@pytest.mark.parametrize("tag,tta,aggr", [("plain", False, None)])      # the TTA case runs on the GPU
+def test_vr_runner_matches_reference_inference(emul, golden_dir, tag, tta, aggr):
+    """utils.py:25-100 ``inference`` (normalise by the peak, pad, window every roi_size frames, predict, concat, TTA) run by
+    the reference on its own net with offset 8 / window 48 -- against vr_inference on the HIP network."""
+    from audiolab_amd.vrnet import WIDTHS, VRNet, random_state_dict, vr_inference
+    z = np.load(os.path.join(golden_dir, "vrnet.npz"))
+    net = VRNet(64, random_state_dict(WIDTHS["nets"], seed=21), variant="nets", ctx=emul)
+    net.offset = 8
+    pred, mag, phase = vr_inference(net, torch.from_numpy(z["inf_x"]), aggr, window_size=48, tta=tta, max_batch=3)
+    want = z[f"inf_{tag}_pred"]
+    assert pred.shape == want.shape
+    assert float(np.max(np.abs(pred.numpy() - want))) < 1e-4 * max(1.0, float(np.max(np.abs(want))))
+    assert float(np.max(np.abs(mag.numpy() - z["inf_mag"]))) < 1e-6
+    assert float(np.max(np.abs(phase.numpy() - z["inf_phase"]))) < 1e-5

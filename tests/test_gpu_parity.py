@@ -245,3 +245,18 @@ def test_vrnet_matches_reference_module(ctx, golden_dir, k):
     want = z[f"c{k}_y"]
     assert got.shape == want.shape
     assert float(np.max(np.abs(got - want))) < 1e-4 * max(1.0, float(np.max(np.abs(want))))
+
+
+@pytest.mark.parametrize("tag,tta,aggr", [("plain", False, None), ("tta", True, {"split_bin": 12, "value": 0.2})])
+def test_vr_runner_matches_reference_inference(ctx, golden_dir, tag, tta, aggr):
+    """The VR runner (utils.py:25-100 ``inference``) as run by the reference on its own net, against vr_inference."""
+    from audiolab_amd.vrnet import WIDTHS, VRNet, random_state_dict, vr_inference
+    z = np.load(os.path.join(golden_dir, "vrnet.npz"))
+    net = VRNet(64, random_state_dict(WIDTHS["nets"], seed=21), variant="nets", ctx=ctx)
+    net.offset = 8
+    pred, mag, phase = vr_inference(net, torch.from_numpy(z["inf_x"]), aggr, window_size=48, tta=tta, max_batch=3)
+    want = z[f"inf_{tag}_pred"]
+    assert pred.shape == want.shape
+    assert float(np.max(np.abs(pred.cpu().numpy() - want))) < 1e-4 * max(1.0, float(np.max(np.abs(want))))
+    assert float(np.max(np.abs(mag.cpu().numpy() - z["inf_mag"]))) < 1e-6
+    assert float(np.max(np.abs(phase.cpu().numpy() - z["inf_phase"]))) < 1e-5
