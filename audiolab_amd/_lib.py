@@ -75,7 +75,8 @@ _SIGNATURES = {
     "alsep_shift_subtract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float,
                                        C.c_void_p]),
     "alsep_vr_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] +
-                        [C.c_int] * 12),
+                        [C.c_int] * 14),
+    "alsep_vr_lstm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6),
     "alsep_vr_depthwise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 7),
     "alsep_vr_resize_bilinear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 7),
     "alsep_vr_copy_slice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 6),

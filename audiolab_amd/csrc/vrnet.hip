@@ -31,7 +31,8 @@ __device__ __forceinline__ float vr_act(float v, int act) {
 __global__ void __launch_bounds__(kVrThreads)
 vr_conv2d_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                  const float* __restrict__ shift, float* __restrict__ y, int64_t npix, int H, int W, int Cin, int Cout,
-                 int Ho, int Wo, int KH, int KW, int stride, int pad, int dil, int act, int y_ct, int y_c0) {
+                 int Ho, int Wo, int KH, int KW, int stride, int pad_h, int pad_w, int dil_h, int dil_w, int act, int y_ct,
+                 int y_c0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int co0 = blockIdx.y * 64;
@@ -59,7 +60,7 @@ vr_conv2d_kernel(const float* __restrict__ x, const float* __restrict__ w, const
         bool inb[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            const int iy = oy[n] * stride - pad + (tap / KW) * dil, ix = ox[n] * stride - pad + (tap % KW) * dil;
+            const int iy = oy[n] * stride - pad_h + (tap / KW) * dil_h, ix = ox[n] * stride - pad_w + (tap % KW) * dil_w;
             inb[n] = pv[n] && iy >= 0 && iy < H && ix >= 0 && ix < W;
             xp[n] = xb[n] + ((int64_t)(inb[n] ? iy : 0) * W + (inb[n] ? ix : 0)) * Cin;
         }
@@ -179,22 +180,77 @@ vr_mask_kernel(const float* __restrict__ logit, const float* __restrict__ mix, f
     out[i] = m * mix[i];
 }
 
+// One direction of nn.LSTM (layers_new.py:117-121), recurrent part.  pre [T, N, 4 Hd] holds x_t W_ih^T + b_ih + b_hh (gate
+// order i, f, g, o as torch), whh [4 Hd][Hd]; out [T, N, out_stride] receives h_t at column out_off.  One workgroup per
+// (n, direction given by `reverse`): thread r < 4 Hd keeps row r of W_hh in registers, h_{t-1} lives in LDS.
+template <int HD>
+__global__ void __launch_bounds__(4 * HD)
+vr_lstm_kernel(const float* __restrict__ pre, const float* __restrict__ whh, float* __restrict__ out, int T, int N, int out_stride,
+               int out_off, int reverse) {
+    float* hs = reinterpret_cast<float*>(alsep_smem);        // [HD] h_{t-1}
+    float* gs = hs + HD;                                     // [4 HD] gate pre-activations of this step
+    const int r = threadIdx.x, n = blockIdx.x;
+    float wrow[HD];
+#pragma unroll
+    for (int k = 0; k < HD; ++k) wrow[k] = whh[r * HD + k];
+    float c = 0.f;
+    if (r < HD) hs[r] = 0.f;
+    __syncthreads();
+    for (int s = 0; s < T; ++s) {
+        const int t = reverse ? T - 1 - s : s;
+        float g = pre[((int64_t)t * N + n) * (4 * HD) + r];
+#pragma unroll
+        for (int k = 0; k < HD; ++k) g = fmaf(wrow[k], hs[k], g);
+        gs[r] = g;
+        __syncthreads();
+        if (r < HD) {
+            const float gi = 1.f / (1.f + expf(-gs[r])), gf = 1.f / (1.f + expf(-gs[HD + r]));
+            const float gg = tanhf(gs[2 * HD + r]), go = 1.f / (1.f + expf(-gs[3 * HD + r]));
+            c = gf * c + gi * gg;
+            const float h = go * tanhf(c);
+            hs[r] = h;
+            out[((int64_t)t * N + n) * out_stride + out_off + r] = h;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
+extern "C" int alsep_vr_lstm(alsep_ctx* ctx, const float* pre, const float* whh, float* out, int T, int N, int hidden,
+                             int out_stride, int out_off, int reverse) {
+    if (!ctx || !pre || !whh || !out) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_lstm: null argument");
+    if (T <= 0 || N <= 0 || out_off < 0 || out_off + hidden > out_stride)
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_lstm: bad shape");
+    const size_t lds = 5 * (size_t)hidden * sizeof(float);
+    switch (hidden) {
+#define ALSEP_LSTM(HD_)                                                                                                  \
+    case HD_:                                                                                                            \
+        hipLaunchKernelGGL(vr_lstm_kernel<HD_>, dim3((unsigned)N), dim3(4 * HD_), lds, ctx->stream, pre, whh, out, T, N, \
+                           out_stride, out_off, reverse);                                                                \
+        break;
+        ALSEP_LSTM(16) ALSEP_LSTM(32) ALSEP_LSTM(64)
+#undef ALSEP_LSTM
+        default: return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_lstm: hidden size %d (have 16, 32, 64)", hidden);
+    }
+    ALSEP_LAUNCH_CHECK(ctx, "vr_lstm_kernel");
+    return ALSEP_OK;
+}
+
 extern "C" int alsep_vr_conv2d(alsep_ctx* ctx, const float* x, const float* w, const float* scale, const float* shift, float* y,
-                               int64_t B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil,
-                               int act, int y_ctotal, int y_coff) {
+                               int64_t B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,
+                               int dil_h, int dil_w, int act, int y_ctotal, int y_coff) {
     if (!ctx || !x || !w || !scale || !shift || !y) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_conv2d: null argument");
-    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0 || dil <= 0 ||
-        act < 0 || act > 2 || y_coff < 0 || y_coff + Cout > y_ctotal)
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad_h < 0 || pad_w < 0 ||
+        dil_h <= 0 || dil_w <= 0 || act < 0 || act > 2 || y_coff < 0 || y_coff + Cout > y_ctotal)
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_conv2d: bad shape");
-    const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+    const int Ho = (H + 2 * pad_h - dil_h * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad_w - dil_w * (KW - 1) - 1) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_conv2d: empty output");
     const int64_t npix = B * Ho * Wo;
     const int64_t gx = ceil_div64(npix, 128);
     if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_conv2d: too many pixels");
     hipLaunchKernelGGL(vr_conv2d_kernel, dim3((unsigned)gx, (unsigned)((Cout + 63) / 64)), dim3(kVrThreads), 0, ctx->stream, x, w,
-                       scale, shift, y, npix, H, W, Cin, Cout, Ho, Wo, KH, KW, stride, pad, dil, act, y_ctotal, y_coff);
+                       scale, shift, y, npix, H, W, Cin, Cout, Ho, Wo, KH, KW, stride, pad_h, pad_w, dil_h, dil_w, act, y_ctotal, y_coff);
     ALSEP_LAUNCH_CHECK(ctx, "vr_conv2d_kernel");
     return ALSEP_OK;
 }

@@ -105,11 +105,12 @@ class _Conv:
         else:
             scale, shift = torch.ones(self.cout), torch.zeros(self.cout)
         self.scale, self.shift = scale.contiguous().to(ctx.device), shift.contiguous().to(ctx.device)
-        self.act, self.stride, self.pad, self.dil = ACT[act], stride, pad, dil
+        pair = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+        self.act, self.stride, self.pad, self.dil = ACT[act], stride, pair(pad), pair(dil)
 
     def out_hw(self, h, w):
-        return ((h + 2 * self.pad - self.dil * (self.kh - 1) - 1) // self.stride + 1,
-                (w + 2 * self.pad - self.dil * (self.kw - 1) - 1) // self.stride + 1)
+        return ((h + 2 * self.pad[0] - self.dil[0] * (self.kh - 1) - 1) // self.stride + 1,
+                (w + 2 * self.pad[1] - self.dil[1] * (self.kw - 1) - 1) // self.stride + 1)
 
 
 class VRNet:
@@ -163,7 +164,8 @@ class VRNet:
             y = self.ctx.empty((b, ho, wo, L.cout))
         ctx = self.ctx
         ctx.check(ctx.lib.alsep_vr_conv2d(ctx.handle, _lib.ptr(x), _lib.ptr(L.w), _lib.ptr(L.scale), _lib.ptr(L.shift), _lib.ptr(y),
-                                          b, h, w, L.cin, L.cout, L.kh, L.kw, L.stride, L.pad, L.dil, L.act, y.shape[3], c0),
+                                          b, h, w, L.cin, L.cout, L.kh, L.kw, L.stride, L.pad[0], L.pad[1], L.dil[0], L.dil[1], L.act,
+                                          y.shape[3], c0),
                   "alsep_vr_conv2d")
         return y
 
@@ -316,3 +318,208 @@ def vr_inference(net: VRNet, x_spec: torch.Tensor, aggressiveness: Optional[dict
         pred_t = execute(pad_l + roi // 2, pad_r + roi // 2, roi, n_window + 1)[:, :, roi // 2:][:, :, :n_frame]
         pred = (pred + pred_t) * 0.5
     return pred * coef, x_mag, phase
+
+
+# ==================================================================================================
+# nets_new.py: CascadedNet (BaseNet with an LSTM branch) -- the architecture of the in-tree DeEcho / DeReverb runner
+# (modules/rvc/infer/modules/uvr5/vr.py AudioPreDeEcho) and of the "VR 5.1" models the orchestrator names for noise / echo
+# removal and the BG-vocal split (stem_separator.py:752, 798-799).
+# ==================================================================================================
+def _cba_shapes(out, p, ci, co, k):
+    out.append((f"{p}.conv.0.weight", (co, ci, k, k)))
+    for n in ("weight", "bias", "running_mean", "running_var"):
+        out.append((f"{p}.conv.1.{n}", (co,)))
+
+
+def basenet_param_shapes(prefix: str, nin: int, nout: int, nin_lstm: int, nout_lstm: int):
+    """(name, shape) of a ``BaseNet`` (nets_new.py:9-29) in module order."""
+    out = []
+    _cba_shapes(out, f"{prefix}.enc1", nin, nout, 3)
+    for i, (ci, co) in zip((2, 3, 4, 5), ((nout, 2 * nout), (2 * nout, 4 * nout), (4 * nout, 6 * nout), (6 * nout, 8 * nout))):
+        _cba_shapes(out, f"{prefix}.enc{i}.conv1", ci, co, 3)
+        _cba_shapes(out, f"{prefix}.enc{i}.conv2", co, co, 3)
+    c8 = 8 * nout
+    _cba_shapes(out, f"{prefix}.aspp.conv1.1", c8, c8, 1)
+    _cba_shapes(out, f"{prefix}.aspp.conv2", c8, c8, 1)
+    for j in (3, 4, 5):
+        _cba_shapes(out, f"{prefix}.aspp.conv{j}", c8, c8, 3)
+    _cba_shapes(out, f"{prefix}.aspp.bottleneck", 5 * c8, c8, 1)
+    for i, (ci, co) in zip((4, 3, 2), ((14 * nout, 6 * nout), (10 * nout, 4 * nout), (6 * nout, 2 * nout))):
+        _cba_shapes(out, f"{prefix}.dec{i}.conv1", ci, co, 3)
+    _cba_shapes(out, f"{prefix}.lstm_dec2.conv", 2 * nout, 1, 1)
+    hd = nout_lstm // 2
+    for sfx in ("", "_reverse"):
+        out += [(f"{prefix}.lstm_dec2.lstm.weight_ih_l0{sfx}", (4 * hd, nin_lstm)), (f"{prefix}.lstm_dec2.lstm.weight_hh_l0{sfx}", (4 * hd, hd)),
+                (f"{prefix}.lstm_dec2.lstm.bias_ih_l0{sfx}", (4 * hd,)), (f"{prefix}.lstm_dec2.lstm.bias_hh_l0{sfx}", (4 * hd,))]
+    out += [(f"{prefix}.lstm_dec2.dense.0.weight", (nin_lstm, nout_lstm)), (f"{prefix}.lstm_dec2.dense.0.bias", (nin_lstm,))]
+    out += [(f"{prefix}.lstm_dec2.dense.1.{n}", (nin_lstm,)) for n in ("weight", "bias", "running_mean", "running_var")]
+    _cba_shapes(out, f"{prefix}.dec1.conv1", 3 * nout + 1, nout, 3)
+    return out
+
+
+def cascaded_new_param_shapes(n_fft: int, nout: int, nout_lstm: int):
+    nin_lstm = (n_fft // 2) // 2
+    out = basenet_param_shapes("stg1_low_band_net.0", 2, nout // 2, nin_lstm // 2, nout_lstm)
+    _cba_shapes(out, "stg1_low_band_net.1", nout // 2, nout // 4, 1)
+    out += basenet_param_shapes("stg1_high_band_net", 2, nout // 4, nin_lstm // 2, nout_lstm // 2)
+    out += basenet_param_shapes("stg2_low_band_net.0", nout // 4 + 2, nout, nin_lstm // 2, nout_lstm)
+    _cba_shapes(out, "stg2_low_band_net.1", nout, nout // 2, 1)
+    out += basenet_param_shapes("stg2_high_band_net", nout // 4 + 2, nout // 2, nin_lstm // 2, nout_lstm // 2)
+    out += basenet_param_shapes("stg3_full_band_net", 3 * nout // 4 + 2, nout, nin_lstm, nout_lstm)
+    out += [("out.weight", (2, nout, 1, 1)), ("aux_out.weight", (2, 3 * nout // 4, 1, 1))]
+    return out
+
+
+def random_state_dict_new(n_fft: int, nout: int, nout_lstm: int, seed: int = 0) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in cascaded_new_param_shapes(n_fft, nout, nout_lstm):
+        if name.endswith("running_var"):
+            t = 0.5 + torch.rand(shape, generator=g)
+        elif name.endswith("running_mean") or ".bias" in name:
+            t = 0.1 * torch.randn(shape, generator=g)
+        elif len(shape) == 1:
+            t = 0.8 + 0.4 * torch.rand(shape, generator=g)
+        elif len(shape) == 2:                                # LSTM / Linear matrices
+            t = torch.randn(shape, generator=g) * (1.0 / shape[1]) ** 0.5
+        else:
+            t = torch.randn(shape, generator=g) * (2.0 / (shape[1] * shape[2] * shape[3])) ** 0.5
+        sd[name] = t.float()
+    return sd
+
+
+class VRNetNew(VRNet):
+    """``CascadedNet(n_fft, nout, nout_lstm)`` of nets_new.py; parameter names as in the reference module."""
+
+    def __init__(self, n_fft: int, state_dict: Dict[str, torch.Tensor], nout: int = 32, nout_lstm: int = 128,
+                 ctx: Optional[Context] = None):
+        self.ctx = ctx if ctx is not None else _lib.default_context(None)
+        shapes = cascaded_new_param_shapes(n_fft, nout, nout_lstm)
+        for n, shape in shapes:
+            if n not in state_dict:
+                raise AlsepError(f"VR (new) state_dict lacks {n}")
+            if tuple(state_dict[n].shape) != tuple(shape):
+                raise AlsepError(f"VR (new) state_dict: {n} has shape {tuple(state_dict[n].shape)}, expected {shape}")
+        self.max_bin, self.output_bin, self.offset = n_fft // 2, n_fft // 2 + 1, 64
+        self.nout = nout
+        sd = state_dict
+        self.base = {p: self._build_basenet(sd, p) for p in ("stg1_low_band_net.0", "stg1_high_band_net", "stg2_low_band_net.0",
+                                                             "stg2_high_band_net", "stg3_full_band_net")}
+        self.stg1_low_tail = _Conv(self.ctx, sd, "stg1_low_band_net.1.conv.0.weight", "stg1_low_band_net.1.conv.1", "relu")
+        self.stg2_low_tail = _Conv(self.ctx, sd, "stg2_low_band_net.1.conv.0.weight", "stg2_low_band_net.1.conv.1", "relu")
+        self.out = _Conv(self.ctx, sd, "out.weight", None, "none")
+
+    def _build_basenet(self, sd, p):
+        c = self.ctx
+        net = {"enc1": _Conv(c, sd, f"{p}.enc1.conv.0.weight", f"{p}.enc1.conv.1", "relu", 1, 1)}
+        for i in (2, 3, 4, 5):                                # Encoder (layers_new.py:30-40): conv1 strided, LeakyReLU
+            net[f"enc{i}.conv1"] = _Conv(c, sd, f"{p}.enc{i}.conv1.conv.0.weight", f"{p}.enc{i}.conv1.conv.1", "leaky", 2, 1)
+            net[f"enc{i}.conv2"] = _Conv(c, sd, f"{p}.enc{i}.conv2.conv.0.weight", f"{p}.enc{i}.conv2.conv.1", "leaky", 1, 1)
+        net["aspp.conv1"] = _Conv(c, sd, f"{p}.aspp.conv1.1.conv.0.weight", f"{p}.aspp.conv1.1.conv.1", "relu")
+        net["aspp.conv2"] = _Conv(c, sd, f"{p}.aspp.conv2.conv.0.weight", f"{p}.aspp.conv2.conv.1", "relu")
+        for j, d in zip((3, 4, 5), ((4, 2), (8, 4), (12, 6))):           # nets_new.py:11, layers_new.py:83-91
+            net[f"aspp.conv{j}"] = _Conv(c, sd, f"{p}.aspp.conv{j}.conv.0.weight", f"{p}.aspp.conv{j}.conv.1", "relu", 1, d, d)
+        net["aspp.bottleneck"] = _Conv(c, sd, f"{p}.aspp.bottleneck.conv.0.weight", f"{p}.aspp.bottleneck.conv.1", "relu")
+        for i in (4, 3, 2, 1):
+            net[f"dec{i}"] = _Conv(c, sd, f"{p}.dec{i}.conv1.conv.0.weight", f"{p}.dec{i}.conv1.conv.1", "relu", 1, 1)
+        # LSTMModule (layers_new.py:108-125)
+        net["lstm.conv"] = _Conv(c, sd, f"{p}.lstm_dec2.conv.conv.0.weight", f"{p}.lstm_dec2.conv.conv.1", "relu")
+        lstm = {}
+        for d, sfx in enumerate(("", "_reverse")):
+            wih = sd[f"{p}.lstm_dec2.lstm.weight_ih_l0{sfx}"].float()
+            lstm[d] = {"wih": wih.t().contiguous().to(c.device),                       # [nin, 4 Hd] = 1x1 conv weights
+                       "bias": (sd[f"{p}.lstm_dec2.lstm.bias_ih_l0{sfx}"] + sd[f"{p}.lstm_dec2.lstm.bias_hh_l0{sfx}"]).float().contiguous().to(c.device),
+                       "ones": torch.ones(wih.shape[0]).to(c.device),
+                       "whh": sd[f"{p}.lstm_dec2.lstm.weight_hh_l0{sfx}"].float().contiguous().to(c.device)}
+        net["lstm"] = lstm
+        net["lstm.hidden"] = lstm[0]["whh"].shape[1]
+        wd, bd = sd[f"{p}.lstm_dec2.dense.0.weight"].float(), sd[f"{p}.lstm_dec2.dense.0.bias"].float()
+        gamma, beta = sd[f"{p}.lstm_dec2.dense.1.weight"].float(), sd[f"{p}.lstm_dec2.dense.1.bias"].float()
+        mean, var = sd[f"{p}.lstm_dec2.dense.1.running_mean"].float(), sd[f"{p}.lstm_dec2.dense.1.running_var"].float()
+        scale = gamma / torch.sqrt(var + 1e-5)
+        net["dense"] = {"w": wd.t().contiguous().to(c.device), "scale": scale.contiguous().to(c.device),
+                        "shift": ((bd - mean) * scale + beta).contiguous().to(c.device)}
+        return net
+
+    def _linear(self, x2d: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, act: int) -> torch.Tensor:
+        """rows x Cin -> rows x Cout through the 1x1 case of the conv kernel."""
+        rows, cin = x2d.shape
+        cout = w.shape[1]
+        y = self.ctx.empty((rows, cout))
+        ctx = self.ctx
+        ctx.check(ctx.lib.alsep_vr_conv2d(ctx.handle, _lib.ptr(x2d), _lib.ptr(w), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y),
+                                          1, rows, 1, cin, cout, 1, 1, 1, 0, 0, 1, 1, act, cout, 0), "alsep_vr_conv2d")
+        return y
+
+    def _lstm_module(self, net, h: torch.Tensor) -> torch.Tensor:
+        """h [N, bins, frames, C] -> [N, bins, frames, 1]."""
+        ctx = self.ctx
+        n, nbins, nframes, _ = h.shape
+        seq = self._conv(net["lstm.conv"], h)[..., 0].permute(2, 0, 1).contiguous()         # [frames, N, bins]
+        hd = net["lstm.hidden"]
+        both = ctx.empty((nframes, n, 2 * hd))
+        for d in (0, 1):
+            L = net["lstm"][d]
+            if L["wih"].shape[0] != nbins:
+                raise AlsepError(f"LSTM input size {L['wih'].shape[0]} != {nbins} bins")
+            pre = self._linear(seq.reshape(nframes * n, nbins), L["wih"], L["ones"], L["bias"], 0)
+            ctx.check(ctx.lib.alsep_vr_lstm(ctx.handle, _lib.ptr(pre), _lib.ptr(L["whh"]), _lib.ptr(both), nframes, n, hd, 2 * hd,
+                                            d * hd, d), "alsep_vr_lstm")
+        D = net["dense"]
+        out = self._linear(both.reshape(nframes * n, 2 * hd), D["w"], D["scale"], D["shift"], 1)   # [frames * N, bins]
+        return out.reshape(nframes, n, nbins).permute(1, 2, 0).unsqueeze(-1).contiguous()
+
+    def _basenet(self, name, x):
+        """nets_new.py:31-47."""
+        net = self.base[name]
+        e1 = self._conv(net["enc1"], x)
+        es = [e1]
+        h = e1
+        for i in (2, 3, 4, 5):
+            h = self._conv(net[f"enc{i}.conv2"], self._conv(net[f"enc{i}.conv1"], h))
+            es.append(h)
+        e1, e2, e3, e4, e5 = es
+        # ASPP with full dilated convolutions (layers_new.py:73-105); Dropout2d is the identity in eval
+        ctx = self.ctx
+        b, hh, ww, c = e5.shape
+        cat = ctx.empty((b, hh, ww, 5 * c))
+        pooled = ctx.empty((b, 1, ww, c))
+        ctx.check(ctx.lib.alsep_vr_mean_h(ctx.handle, _lib.ptr(e5), _lib.ptr(pooled), b, hh, ww, c), "alsep_vr_mean_h")
+        self._resize(self._conv(net["aspp.conv1"], pooled), hh, ww, cat, 0)
+        self._conv(net["aspp.conv2"], e5, cat, c)
+        for k, j in enumerate((3, 4, 5)):
+            self._conv(net[f"aspp.conv{j}"], e5, cat, (2 + k) * c)
+        h = self._conv(net["aspp.bottleneck"], cat)
+        h = self._decoder(net["dec4"], h, e4)
+        h = self._decoder(net["dec3"], h, e3)
+        h = self._decoder(net["dec2"], h, e2)
+        h = torch.cat([h, self._lstm_module(net, h)], dim=3).contiguous()
+        return self._decoder(net["dec1"], h, e1)
+
+    def mask_nhwc(self, x: torch.Tensor):
+        """x [B, bins >= max_bin, frames, 2] -> (logits [B, max_bin, frames, 2], the cropped input) (nets_new.py:81-105)."""
+        xin = x[:, : self.max_bin].contiguous()
+        bandw = xin.shape[1] // 2
+        l1_in, h1_in = xin[:, :bandw].contiguous(), xin[:, bandw:].contiguous()
+        l1 = self._conv(self.stg1_low_tail, self._basenet("stg1_low_band_net.0", l1_in))
+        h1 = self._basenet("stg1_high_band_net", h1_in)
+        aux1 = torch.cat([l1, h1], dim=1)
+        l2 = self._conv(self.stg2_low_tail, self._basenet("stg2_low_band_net.0", torch.cat([l1_in, l1], dim=3).contiguous()))
+        h2 = self._basenet("stg2_high_band_net", torch.cat([h1_in, h1], dim=3).contiguous())
+        aux2 = torch.cat([l2, h2], dim=1)
+        f3 = self._basenet("stg3_full_band_net", torch.cat([xin, aux1, aux2], dim=3).contiguous())
+        return self._conv(self.out, f3)
+
+    def forward_nhwc(self, x: torch.Tensor, aggressiveness: Optional[dict] = None) -> torch.Tensor:
+        """x [B, bins, frames, 2] -> x * mask [B, output_bin, frames, 2] (``predict`` before its offset crop; the new nets
+        ignore ``aggressiveness``, nets_new.py:124-132)."""
+        ctx = self.ctx
+        if x.dim() != 4 or x.shape[3] != 2 or x.shape[1] < self.output_bin or x.dtype != torch.float32:
+            raise AlsepError(f"VRNetNew input must be float32 [B, >= {self.output_bin} bins, frames, 2], got {tuple(x.shape)}")
+        x = x.contiguous()
+        mix = x[:, : self.output_bin].contiguous()
+        logit = self.mask_nhwc(x)
+        out = ctx.empty(tuple(mix.shape))
+        ctx.check(ctx.lib.alsep_vr_mask(ctx.handle, _lib.ptr(logit), _lib.ptr(mix), _lib.ptr(out), mix.shape[0], logit.shape[1],
+                                        self.output_bin, mix.shape[2], 2, 0, C.c_float(-1.0)), "alsep_vr_mask")
+        return out

@@ -170,10 +170,17 @@ int alsep_shift_subtract(alsep_ctx* ctx, const float* ref, const float* sig, int
  * layers*.py).  Channels-last float32 tensors [B, H = bins, W = frames, C].  Outputs that feed a
  * torch.cat are written into the channel slice [y_coff, y_coff + C) of a tensor with y_ctotal channels. ---- */
 /* y = act(conv2d(x, w) * scale + shift): nn.Conv2d(bias=False) + folded BatchNorm2d + activation (layers*.py:9-27);
- * w packed [KH][KW][Cin][Cout]; act 0 none, 1 ReLU, 2 LeakyReLU(0.01).  Output size as torch: (H + 2 pad - dil (KH-1) - 1) / stride + 1. */
+ * w packed [KH][KW][Cin][Cout]; act 0 none, 1 ReLU, 2 LeakyReLU(0.01); padding / dilation per axis (layers_new.py:83-91 uses
+ * (4,2), (8,4), (12,6)).  Output size as torch: (H + 2 pad_h - dil_h (KH-1) - 1) / stride + 1.  A Linear (+ bias, BatchNorm1d)
+ * is the 1x1 case with the rows as pixels. */
 int alsep_vr_conv2d(alsep_ctx* ctx, const float* x, const float* w, const float* scale, const float* shift, float* y,
-                    int64_t B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil, int act,
-                    int y_ctotal, int y_coff);
+                    int64_t B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int dil_h,
+                    int dil_w, int act, int y_ctotal, int y_coff);
+/* recurrent part of one direction of nn.LSTM (layers_new.py:117-121): pre [T,N,4*hidden] = x W_ih^T + b_ih + b_hh (gates
+ * i,f,g,o), whh [4*hidden][hidden]; h_t is written to out[t, n, out_off .. out_off+hidden) of rows out_stride wide;
+ * reverse != 0 walks t from T-1 down (the backward direction).  hidden in {16, 32, 64}. */
+int alsep_vr_lstm(alsep_ctx* ctx, const float* pre, const float* whh, float* out, int T, int N, int hidden, int out_stride,
+                  int out_off, int reverse);
 /* depthwise (groups = C) KHxKW dilated convolution, same-size output (layers*.py:30-52); w packed [C][KH][KW] */
 int alsep_vr_depthwise(alsep_ctx* ctx, const float* x, const float* w, float* y, int64_t B, int H, int W, int C, int KH, int KW,
                        int pad, int dil);

@@ -23,7 +23,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
-from audiolab_amd.vrnet import WIDTHS, random_state_dict  # noqa: E402
+from audiolab_amd.vrnet import WIDTHS, random_state_dict, random_state_dict_new  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -79,6 +79,21 @@ def main():
         pred, x_mag, phase = utils.inference(xs, "cpu", net, aggr, {"window_size": 48, "tta": tta})
         out[f"inf_{tag}_pred"] = pred.astype(np.float32)
         print("inference", tag, pred.shape, float(np.abs(pred).max()))
+    # nets_new.CascadedNet (LSTM branch): predict = x * mask before the offset crop; offset 0 for a small fixture
+    modn = load_ref_nets("nets_new")
+    for k, (n_fft, nout, nout_lstm, frames, seed) in enumerate([(128, 16, 64, 32, 31), (64, 32, 128, 48, 32)]):
+        netn = modn.CascadedNet(n_fft, nout=nout, nout_lstm=nout_lstm)
+        missing, unexpected = netn.load_state_dict(random_state_dict_new(n_fft, nout, nout_lstm, seed=seed), strict=False)
+        assert not unexpected and all(m.endswith("num_batches_tracked") for m in missing), (missing, unexpected)
+        netn.eval()
+        netn.offset = 0
+        g = torch.Generator().manual_seed(200 + seed)
+        x = torch.rand((2, 2, n_fft // 2 + 1, frames), generator=g) * 3.0
+        with torch.no_grad():
+            y = netn.predict(x)
+        out[f"n{k}_cfg"] = np.array([n_fft, nout, nout_lstm, frames, seed], dtype=np.int64)
+        out[f"n{k}_x"], out[f"n{k}_y"] = x.numpy(), y.numpy()
+        print("nets_new", n_fft, nout, nout_lstm, tuple(y.shape), float(y.abs().max()))
     out["inf_x"] = xs
     out["inf_mag"], out["inf_phase"] = x_mag.astype(np.float32), phase.astype(np.complex64)
     os.makedirs(OUT, exist_ok=True)

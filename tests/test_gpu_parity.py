@@ -260,3 +260,16 @@ def test_vr_runner_matches_reference_inference(ctx, golden_dir, tag, tta, aggr):
     assert float(np.max(np.abs(pred.cpu().numpy() - want))) < 1e-4 * max(1.0, float(np.max(np.abs(want))))
     assert float(np.max(np.abs(mag.cpu().numpy() - z["inf_mag"]))) < 1e-6
     assert float(np.max(np.abs(phase.cpu().numpy() - z["inf_phase"]))) < 1e-5
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_vrnet_new_matches_reference_module(ctx, golden_dir, k):
+    """nets_new.py CascadedNet (LSTM branch, per-axis dilations) against the reference module's own predict()."""
+    from audiolab_amd.vrnet import VRNetNew, random_state_dict_new
+    z = np.load(os.path.join(golden_dir, "vrnet.npz"))
+    n_fft, nout, nout_lstm, frames, seed = (int(v) for v in z[f"n{k}_cfg"])
+    net = VRNetNew(n_fft, random_state_dict_new(n_fft, nout, nout_lstm, seed=seed), nout=nout, nout_lstm=nout_lstm, ctx=ctx)
+    got = net.forward(torch.from_numpy(z[f"n{k}_x"])).cpu().numpy()
+    want = z[f"n{k}_y"]
+    assert got.shape == want.shape
+    assert float(np.max(np.abs(got - want))) < 1e-4 * max(1.0, float(np.max(np.abs(want))))
