@@ -198,7 +198,12 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
     // LDS image after pass A: row i at i*16, its 16-byte granule g (values 2g, 2g+1) at position g ^ (i & 7):
     // conflict-free ds_write_b128 here, conflict-free ds_read_b64 in pass B.
     {
-        typedef float fvec __attribute__((ext_vector_type(NB == 3 ? 3 : 2), aligned(4)));
+        // NB consecutive floats, 4-byte aligned: exactly NB * 4 bytes (a 3-element ext_vector_type is 16 bytes wide on the
+        // host, where the CPU emulation / AddressSanitizer build would read one float past the last frame)
+        struct __attribute__((packed, aligned(4))) fvec {
+            float v[NB];
+            __device__ __forceinline__ float operator[](int i) const { return v[i]; }
+        };
         v2f u[NB][16];
         v2f wi[NB];
 #pragma unroll

@@ -49,3 +49,31 @@ a, b = torch.randn(2, 50007) * 0.1, torch.randn(2, 50007) * 0.1
 ensemble.blend_tracks(ctx, [a, b[:, :40001]], [1.0, 2.0])
 ensemble.debleed(ctx, a + b, a, b, 44100, 0.2)
 print("ensemble ok")
+# three-pass STFT / iSTFT (fft_r16.h): production sizes, small dim_t (edge + interior frames), narrow / full / Nyquist bands
+for (n_fft, dim_f, dim_t) in [(6144, 3072, 8), (6144, 3073, 7), (6144, 500, 7), (4096, 2049, 6)]:
+    plan = StftPlan(ctx, n_fft, 1024, dim_f, dim_t)
+    x = torch.randn(2, 2, plan.chunk_size)
+    for dt in (torch.float32, torch.bfloat16):
+        sp = plan.stft_strided(x, plan.chunk_size, 2 * plan.chunk_size, 2, dt, _lib.LAYOUT_NHWC)
+        out = ctx.empty((2, 2, plan.chunk_size))
+        plan.istft_strided(sp, _lib.LAYOUT_NHWC, out, plan.chunk_size, 2 * plan.chunk_size, 0, plan.chunk_size, 3 * plan.chunk_size)
+        assert torch.isfinite(out).all()
+    ref = plan.stft_strided(x, plan.chunk_size, 2 * plan.chunk_size, 2, torch.float32, _lib.LAYOUT_REF)
+    plan.istft_strided(ref, _lib.LAYOUT_REF, out, plan.chunk_size, 2 * plan.chunk_size, 0, plan.chunk_size, 3 * plan.chunk_size)
+print("three-pass stft/istft ok")
+# streaming ds / us kernels of levels 0<->1<->2<->3 (Fp % 64 == 0 at every level) and the two-workgroup register-weight conv
+cfg = TDFNetConfig(dim_f=512, dim_t=8, n_fft=1024, hop=64, num_blocks=7, g=48)
+net = TDFNet(cfg, synthetic_state_dict(cfg, calib_frames=8), ctx=ctx, dtype=torch.bfloat16, max_batch=2)
+y = net.forward_nhwc(torch.randn(2, cfg.dim_t, cfg.dim_f, 4).to(torch.bfloat16))
+assert torch.isfinite(y.float()).all()
+print("stream ds/us ok")
+# VR networks
+from audiolab_amd.vrnet import WIDTHS, VRNet, VRNetNew, random_state_dict, random_state_dict_new, vr_inference  # noqa: E402
+vr = VRNet(64, random_state_dict(WIDTHS["nets"], seed=1), variant="nets", ctx=ctx)
+assert torch.isfinite(vr.forward(torch.rand(1, 2, 33, 32), {"split_bin": 10, "value": 0.1})).all()   # frames: a multiple of 16
+vr.offset = 8
+pred, _, _ = vr_inference(vr, torch.randn(2, 33, 40, dtype=torch.complex64), None, window_size=32, tta=True, max_batch=2)
+assert torch.isfinite(pred).all()
+vn = VRNetNew(64, random_state_dict_new(64, 16, 64, seed=2), nout=16, nout_lstm=64, ctx=ctx)
+assert torch.isfinite(vn.forward(torch.rand(1, 2, 33, 32))).all()
+print("vr ok")
