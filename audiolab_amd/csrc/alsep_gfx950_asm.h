@@ -160,3 +160,13 @@ __device__ __forceinline__ float sgpr_literal(float c) {
     asm volatile("" : "+s"(c));
     return c;
 }
+
+// NB (2 or 3) consecutive floats from a 4-byte aligned address as ONE global_load_dwordx2 / x3.  The vector type of the
+// 3-float case is 16 bytes wide in C++ (the instruction reads 12), so the host emulation has its own byte-exact version.
+template <int NB>
+__device__ __forceinline__ void load_floats(const void* p, float (&v)[NB]) {
+    typedef float vec_t __attribute__((ext_vector_type(NB), aligned(4)));
+    const vec_t q = *reinterpret_cast<const vec_t*>(p);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) v[i] = q[i];
+}

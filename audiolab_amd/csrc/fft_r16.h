@@ -198,12 +198,6 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
     // LDS image after pass A: row i at i*16, its 16-byte granule g (values 2g, 2g+1) at position g ^ (i & 7):
     // conflict-free ds_write_b128 here, conflict-free ds_read_b64 in pass B.
     {
-        // NB consecutive floats, 4-byte aligned: exactly NB * 4 bytes (a 3-element ext_vector_type is 16 bytes wide on the
-        // host, where the CPU emulation / AddressSanitizer build would read one float past the last frame)
-        struct __attribute__((packed, aligned(4))) fvec {
-            float v[NB];
-            __device__ __forceinline__ float operator[](int i) const { return v[i]; }
-        };
         v2f u[NB][16];
         v2f wi[NB];
 #pragma unroll
@@ -213,8 +207,9 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
             const unsigned voff = (unsigned)tid * (4u * NB);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const fvec l = *reinterpret_cast<const fvec*>(reinterpret_cast<const char*>(xl + p0 + M * r) + voff);
-                const fvec rr = *reinterpret_cast<const fvec*>(reinterpret_cast<const char*>(xr + p0 + M * r) + voff);
+                float l[NB], rr[NB];
+                load_floats<NB>(reinterpret_cast<const char*>(xl + p0 + M * r) + voff, l);
+                load_floats<NB>(reinterpret_cast<const char*>(xr + p0 + M * r) + voff, rr);
 #pragma unroll
                 for (int bb = 0; bb < NB; ++bb) u[bb][r] = mk(l[bb], rr[bb]);
             }

@@ -53,3 +53,5 @@ static inline v2f cx_conj_add_pi(v2f a, v2f b) { return v2f{a.x - b.y, -a.y - b.
 static inline float sgpr_literal(float c) { return c; }
 static inline v2f cx_mul_p1(v2f a, v2f w) { return v2f{-(a.y * w.y), a.y * w.x}; }
 static inline v2f cx_mul_p2(v2f a, v2f w, v2f t) { return v2f{fmaf(a.x, w.x, t.x), fmaf(a.x, w.y, t.y)}; }
+template <int NB>
+static inline void load_floats(const void* p, float (&v)[NB]) { std::memcpy(v, p, NB * sizeof(float)); }
