@@ -566,8 +566,9 @@ template <int N, typename OutT, int LAYOUT>
 static int launch_stft(alsep_ctx* ctx, const alsep_plan* p, const float* pcm, int64_t ch_stride,
                        int64_t chunk_stride, int64_t n_chunks, void* spec) {
     const size_t lds = sizeof(float2) * N;
-    if constexpr (N == 4096 || N == 6144) {
-        if (stft_r16_enabled()) {                            // default: one frame per two-wave workgroup
+    if constexpr (N == 4096 || N == 6144 || N == 7680) {
+        if (stft_r16_enabled()) {
+            const size_t lds = r16::stft_lds_bytes<N / 256>();                            // default: one frame per two-wave workgroup
             ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)r16::stft_r16_kernel<N / 256, OutT, LAYOUT>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ProfScope prof(ctx, ALSEP_PROF_STFT);

@@ -1,4 +1,4 @@
-// Three-pass STFT for n_fft = 256 * R2 (4096 = 16*16*16, 6144 = 16*16*24): the production front end.
+// Three-pass STFT for n_fft = 256 * R2 (4096 = 16*16*16, 6144 = 16*16*24, 7680 = 16*16*30): the production front end.
 //
 // Semantics: ConvTDFNetTrim.stft, reference modules/rvc/infer/modules/uvr5/mdxnet.py:41-56 (same as
 // stft_kernel in fft.hip, which stays as the generic-size kernel).
@@ -20,6 +20,8 @@
 namespace r16 {
 
 constexpr int kThreads = 128;
+// LDS bytes of stft_r16_kernel<R2>: the plain frame (n_fft values) or, when the pass-A rows are padded (R2 = 30), 18 per row
+template <int R2> constexpr int stft_lds_bytes() { return ((R2 % 8 == 0) ? 256 * R2 : 16 * R2 * 18) * 8; }
 
 __device__ __forceinline__ v2f mk(float x, float y) { v2f r = {x, y}; return r; }
 
@@ -123,6 +125,48 @@ template <> struct LastDft<24> {
     static __device__ __forceinline__ constexpr int slot(int q) { return in_idx(q % 3, q % 8); }
 };
 
+// forward DFT-5 in place
+__device__ __forceinline__ void dft5(v2f& u0, v2f& u1, v2f& u2, v2f& u3, v2f& u4) {
+    const float C1 = 0.30901699437494742410f, C2 = -0.80901699437494742410f;
+    const float S1 = 0.95105651629515357212f, S2 = 0.58778525229247312917f;
+    const v2f t1 = u1 + u4, t2 = u2 + u3, t3 = u1 - u4, t4 = u2 - u3;
+    const v2f m1 = u0 + C1 * t1 + C2 * t2, m2 = u0 + C2 * t1 + C1 * t2;
+    const v2f n1 = S1 * t3 + S2 * t4, n2 = S2 * t3 - S1 * t4;
+    u0 = u0 + t1 + t2;
+    u1 = cx_add_mi(m1, n1);                // m1 - i n1
+    u4 = cx_add_pi(m1, n1);                // m1 + i n1
+    u2 = cx_add_mi(m2, n2);
+    u3 = cx_add_pi(m2, n2);
+}
+// forward DFT-6 in place by the prime-factor map 2 x 3: X[m] ends up in v[dft6_pos(m)]
+__device__ __forceinline__ constexpr int dft6_in(int a, int b) { return (3 * a + 2 * b) % 6; }
+__device__ __forceinline__ constexpr int dft6_pos(int m) { return dft6_in(m % 2, m % 3); }
+__device__ __forceinline__ void dft6(v2f& v0, v2f& v1, v2f& v2, v2f& v3, v2f& v4, v2f& v5) {
+    v2f* v[6] = {&v0, &v1, &v2, &v3, &v4, &v5};
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {                            // DFT-2 over a
+        const v2f p = *v[dft6_in(0, b)], q = *v[dft6_in(1, b)];
+        *v[dft6_in(0, b)] = p + q;
+        *v[dft6_in(1, b)] = p - q;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) dft3(*v[dft6_in(a, 0)], *v[dft6_in(a, 1)], *v[dft6_in(a, 2)]);
+}
+// 30 = 5 x 6 by the prime-factor map: input r = (6 n1 + 5 n2) mod 30, output q = (6 k1 + 25 k2) mod 30 (k1 = q mod 5,
+// k2 = q mod 6); DFT-5 over n1, then DFT-6 (itself 2 x 3) over n2, all in place.
+template <> struct LastDft<30> {
+    static __device__ __forceinline__ constexpr int in_idx(int n1, int n2) { return (6 * n1 + 5 * n2) % 30; }
+    static __device__ __forceinline__ void run(v2f (&u)[30]) {
+#pragma unroll
+        for (int n2 = 0; n2 < 6; ++n2)
+            dft5(u[in_idx(0, n2)], u[in_idx(1, n2)], u[in_idx(2, n2)], u[in_idx(3, n2)], u[in_idx(4, n2)]);
+#pragma unroll
+        for (int k1 = 0; k1 < 5; ++k1)
+            dft6(u[in_idx(k1, 0)], u[in_idx(k1, 1)], u[in_idx(k1, 2)], u[in_idx(k1, 3)], u[in_idx(k1, 4)], u[in_idx(k1, 5)]);
+    }
+    static __device__ __forceinline__ constexpr int slot(int q) { return in_idx(q % 5, dft6_pos(q % 6)); }
+};
+
 // w[r] = w1^r for r = 1..R-1 by doubling: level by level, w[p + j] = w[p] w[j] (j < p) and w[2p] = w[p]^2 for
 // p = 1, 2, 4, ...; the products of one level are independent (first halves batched before second halves) and every
 // power is at most ceil(log2 R) products away from w1.
@@ -130,7 +174,7 @@ template <int R> __device__ __forceinline__ void twiddle_powers(v2f w1, v2f (&w)
     w[1] = w1;
 #pragma unroll
     for (int p = 1; p < R; p *= 2) {
-        v2f t[2 * 16];
+        v2f t[32];
 #pragma unroll
         for (int j = 1; j <= p; ++j)
             if (p + j < R) t[j] = cx_mul_p1(w[p], w[j]);
@@ -173,8 +217,13 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
                 int T, const float2* __restrict__ tw_, OutT* __restrict__ spec) {
     constexpr int N = 256 * R2, NT = kThreads;
     constexpr int M = N / 16;                 // butterflies of passes A and B
-    constexpr int NB = M / NT;                // per thread (2 or 3)
-    static_assert(M % NT == 0 && (M / 16) % 8 == 0, "geometry");
+    constexpr int NB = (M + NT - 1) / NT;     // per thread (2, 3; 4 for R2 = 30, where the last threads own fewer)
+    constexpr bool FULL = M % NT == 0;
+    // pass-A image: rows of 16 values.  With (M/16) % 8 == 0 the XOR key of a row survives pass B's row stride and the
+    // rows stay 16 wide (swizzled granules); otherwise (7680: M/16 = 30) rows are padded to 18 values instead
+    constexpr bool SWZ = (M / 16) % 8 == 0;
+    constexpr int RW = SWZ ? 16 : 18;
+    static_assert(NB <= 4, "geometry");
     const v2f* __restrict__ tw = reinterpret_cast<const v2f*>(tw_);
     v2f* buf = reinterpret_cast<v2f*>(alsep_smem);
     const int tid = threadIdx.x;
@@ -200,9 +249,15 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
     {
         v2f u[NB][16];
         v2f wi[NB];
+        const bool own = FULL || NB * tid < M;                   // 7680: threads 120..127 own no pass-A butterfly
 #pragma unroll
-        for (int bb = 0; bb < NB; ++bb) wi[bb] = tw[NB * tid + bb];
-        if (p0 >= 0 && p0 + N <= chunk) {                        // interior frame (wave-uniform)
+        for (int bb = 0; bb < NB; ++bb) wi[bb] = own ? tw[NB * tid + bb] : mk(1.f, 0.f);
+        if (!own) {
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u[bb][r] = mk(0.f, 0.f);
+        } else if (p0 >= 0 && p0 + N <= chunk) {                 // interior frame (wave-uniform)
             // uniform base (SGPR pair) + 32-bit lane offset: no per-load 64-bit address arithmetic
             const unsigned voff = (unsigned)tid * (4u * NB);
 #pragma unroll
@@ -238,12 +293,14 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
             }
             dft16(u[bb]);
             const int i = NB * tid + bb;
-            f32x4* row = reinterpret_cast<f32x4*>(buf + i * 16);
+            f32x4* row = reinterpret_cast<f32x4*>(buf + i * RW);
+            if (own) {
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const v2f lo = u[bb][dft16_slot(2 * g)], hi = u[bb][dft16_slot(2 * g + 1)];
-                f32x4 v = {lo.x, lo.y, hi.x, hi.y};
-                row[g ^ (i & 7)] = v;
+                for (int g = 0; g < 8; ++g) {
+                    const v2f lo = u[bb][dft16_slot(2 * g)], hi = u[bb][dft16_slot(2 * g + 1)];
+                    f32x4 v = {lo.x, lo.y, hi.x, hi.y};
+                    row[SWZ ? (g ^ (i & 7)) : g] = v;
+                }
             }
         }
     }
@@ -257,22 +314,26 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
             const int i = tid + NT * bb;
-            const int row = i >> 4;                              // (row + (M/16) r) & 7 == row & 7
-            const v2f* src = buf + row * 16 + ((((k >> 1) ^ (row & 7)) << 1) | (k & 1));
+            const int row = i >> 4;                              // SWZ: (row + (M/16) r) & 7 == row & 7
+            const v2f* src = buf + row * RW + (SWZ ? ((((k >> 1) ^ (row & 7)) << 1) | (k & 1)) : k);
+            if (FULL || i < M) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) u[bb][r] = src[M * r];
+                for (int r = 0; r < 16; ++r) u[bb][r] = src[(M / 16) * RW * r];
+            }
         }
         v2f w[16];
         twiddle_powers<16>(wB1, w);
         __syncthreads();                           // every read of the pass-A image is done
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
-            cx_mul_n<16>(u[bb], w);
-            dft16(u[bb]);
             const int i = tid + NT * bb;
-            v2f* dst = buf + (i >> 4) * 256 + k;
+            if (FULL || i < M) {
+                cx_mul_n<16>(u[bb], w);
+                dft16(u[bb]);
+                v2f* dst = buf + (i >> 4) * 256 + k;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) dst[16 * q] = u[bb][dft16_slot(q)];
+                for (int q = 0; q < 16; ++q) dst[16 * q] = u[bb][dft16_slot(q)];
+            }
         }
     }
     __syncthreads();

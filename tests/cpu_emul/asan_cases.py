@@ -50,7 +50,7 @@ ensemble.blend_tracks(ctx, [a, b[:, :40001]], [1.0, 2.0])
 ensemble.debleed(ctx, a + b, a, b, 44100, 0.2)
 print("ensemble ok")
 # three-pass STFT / iSTFT (fft_r16.h): production sizes, small dim_t (edge + interior frames), narrow / full / Nyquist bands
-for (n_fft, dim_f, dim_t) in [(6144, 3072, 8), (6144, 3073, 7), (6144, 500, 7), (4096, 2049, 6)]:
+for (n_fft, dim_f, dim_t) in [(6144, 3072, 8), (6144, 3073, 7), (6144, 500, 7), (4096, 2049, 6), (7680, 3072, 10), (7680, 3841, 9)]:
     plan = StftPlan(ctx, n_fft, 1024, dim_f, dim_t)
     x = torch.randn(2, 2, plan.chunk_size)
     for dt in (torch.float32, torch.bfloat16):

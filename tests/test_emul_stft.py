@@ -86,9 +86,10 @@ def test_istft_register_ring_hop1024(emul):
     assert float(st[:, limit:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("n_fft,dim_f,dim_t", [(6144, 3072, 8), (6144, 3073, 7), (6144, 1000, 8), (4096, 2049, 6), (4096, 2048, 9)])
+@pytest.mark.parametrize("n_fft,dim_f,dim_t", [(6144, 3072, 8), (6144, 3073, 7), (6144, 1000, 8), (4096, 2049, 6), (4096, 2048, 9),
+                                               (7680, 3072, 10), (7680, 3841, 10)])
 def test_three_pass_kernels_production_sizes(emul, n_fft, dim_f, dim_t):
-    """n_fft 4096 / 6144 with hop 1024 take the three-pass kernels of fft_r16.h (radix 16,16,R2 forward with the
+    """n_fft 4096 / 6144 (and, for the forward transform, 7680 = 16*16*30 with padded rows) with hop 1024 take the three-pass kernels of fft_r16.h (radix 16,16,R2 forward with the
     in-thread two-for-one split; radix R2,16,16 inverse with the in-thread Hermitian extension and the register
     overlap-add).  Small dim_t keeps both the reflect-padded edge frames and interior frames in play; dim_f covers
     the full band (Nyquist bin), the production band (n_fft/2) and a narrow band (zero-filled bins)."""
