@@ -6,8 +6,10 @@ model_instance.output_dir, :281 separate(path) -> [basenames]) plus an in-memory
 
 Model roster.  The reference downloads its models at run time (stem_separator.py:109-124); none
 is reachable offline, so every roster entry below is a TFC-TDF U-Net with random-init weights
-(audiolab_amd.synth) unless ``<model_file_dir>/<name>.pt`` holds a torch state_dict for it.
-Geometry per file name follows the public UVR/KUIELab model tables (PARITY UNPINNED).
+(audiolab_amd.synth) unless the model file itself is present: ``<model_file_dir>/<name>`` (an MDX-Net ``.onnx``, read by
+audiolab_amd.onnx_reader -- network hyper-parameters come from the graph, n_fft and the stem labels from the roster) or
+``<model_file_dir>/<name>.pt`` (a torch state_dict).  Geometry per file name follows the public UVR/KUIELab model tables
+(PARITY UNPINNED).
 
 Multi-stem entries.  A roster value ``("multi", [(label, cfg), ...])`` describes a model file that yields several stems
 (the reference's drum-kit splitter ``MDX23C-DrumSep-aufr33-jarredou.ckpt`` returns six, stem_separator.py:563-574): one
@@ -97,8 +99,12 @@ class Separator:
     # -- roster ---------------------------------------------------------------------------------
     def download_model_files(self, model_filename: str) -> None:
         """No network here: just validate that the name is known (or present on disk)."""
-        if model_filename not in self.roster and not os.path.exists(os.path.join(self.model_file_dir, model_filename + ".pt")):
+        if model_filename not in self.roster and not self._onnx_path(model_filename):
             logger.debug("model %s is not an MDX-Net model of this build's roster; load_model would fail", model_filename)
+
+    def _onnx_path(self, model_filename: str) -> Optional[str]:
+        p = os.path.join(self.model_file_dir, model_filename)
+        return p if model_filename.lower().endswith(".onnx") and os.path.isfile(p) else None
 
     def load_model(self, model_filename: str) -> None:
         """Weights stay resident per model name: the reference reloads per ensemble member
@@ -107,6 +113,9 @@ class Separator:
             self.model_instance = self._cache[model_filename]
             self.model_instance.output_dir = self.output_dir
             return
+        onnx_path = self._onnx_path(model_filename)
+        if model_filename not in self.roster and onnx_path:    # a real MDX-Net file outside the roster: vocal model defaults
+            self.roster[model_filename] = ("Vocals", "Instrumental", None)
         if model_filename not in self.roster:
             raise AlsepError(f"model '{model_filename}' is not available in this build (MDX-Net roster: {sorted(self.roster)})")
         entry = self.roster[model_filename]
@@ -115,9 +124,18 @@ class Separator:
         else:
             stems = [entry]
 
-        def build(tag: str, cfg: TDFNetConfig):
+        def build(tag: str, cfg: Optional[TDFNetConfig]):
             pt = os.path.join(self.model_file_dir, tag + ".pt")
-            if os.path.exists(pt):
+            if onnx_path and tag == model_filename:
+                from .onnx_reader import load_mdx_onnx
+                m = load_mdx_onnx(onnx_path, n_fft=cfg.n_fft if cfg else None, hop=cfg.hop if cfg else 1024)
+                if cfg is not None and (m.config.dim_f, m.config.dim_t) != (cfg.dim_f, cfg.dim_t):
+                    logger.warning("%s: the file holds dim_f=%d dim_t=%d, the roster says %d / %d; using the file's", model_filename,
+                                   m.config.dim_f, m.config.dim_t, cfg.dim_f, cfg.dim_t)
+                cfg, sd = m.config, m.state_dict
+            elif cfg is None:
+                raise AlsepError(f"model '{model_filename}': no geometry in the roster and no model file")
+            elif os.path.exists(pt):
                 sd = torch.load(pt, map_location="cpu")
             else:
                 seed = int.from_bytes(hashlib.sha256(tag.encode()).digest()[:4], "little")

@@ -72,12 +72,16 @@ class TDFNetConfig:
 
 
 def fold_batchnorm(sd: Dict[str, torch.Tensor], conv: str, bn: str, conv_bias_per_channel: bool = True):
-    """(scale, shift) with y = scale * conv_nobias(x) + shift  ==  BN(conv(x)) in eval mode."""
+    """(scale, shift) with y = scale * conv_nobias(x) + shift  ==  BN(conv(x)) in eval mode.  A layer without BatchNorm
+    entries (an ONNX export folds Conv+BN into the convolution: onnx_reader.py) is scale 1, shift = bias."""
+    b = sd.get(conv + ".bias")
+    if bn + ".weight" not in sd:
+        n = sd[conv + ".weight"].shape[1 if conv.startswith("us.") else 0]
+        return torch.ones(n), (b.float().clone() if b is not None and conv_bias_per_channel else torch.zeros(n))
     gamma, beta = sd[bn + ".weight"].double(), sd[bn + ".bias"].double()
     mean, var = sd[bn + ".running_mean"].double(), sd[bn + ".running_var"].double()
     scale = gamma / torch.sqrt(var + BN_EPS)
     shift = beta - mean * scale
-    b = sd.get(conv + ".bias")
     if b is not None and conv_bias_per_channel:
         shift = shift + b.double() * scale
     return scale.float(), shift.float()

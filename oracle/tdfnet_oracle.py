@@ -28,6 +28,8 @@ BN_EPS = 1e-5
 
 
 def _bn(x: torch.Tensor, w: Dict[str, torch.Tensor], p: str) -> torch.Tensor:
+    if p + ".weight" not in w:                            # BatchNorm folded into the convolution by an ONNX export
+        return x
     return F.batch_norm(x, w[p + ".running_mean"], w[p + ".running_var"],
                         w[p + ".weight"], w[p + ".bias"], training=False, eps=BN_EPS)
 
