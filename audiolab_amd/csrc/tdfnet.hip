@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(kThreads, 2)
 conv3x3_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
                     const float* __restrict__ scale, const float* __restrict__ shift,
                     const bf16_t* __restrict__ zero_page, int Th, int Fw, int Cin, int Cout, int tiles_t,
-                    int tiles_f, int ntiles, int ablate, int stagger) {
+                    int tiles_f, int ntiles, int ablate, int stagger, int ny_fastest) {
     typedef ConvB16<TW> Cf;
     // co-resident workgroups start together and would run their fill / MFMA / store phases in lockstep:
     // delay every other workgroup by about half a stage so that one fills while the other computes
@@ -277,12 +277,21 @@ conv3x3_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
 
-    int tile = xcd_remap(blockIdx.x, ntiles);
+    // ny_fastest (1-D grid, ntiles % 8 == 0): the Cout/48 workgroups of one tile are dispatched back to back onto the
+    // same XCD, so the tile's halo patch comes from HBM once and from that XCD's L2 afterwards
+    int tile, ny;
+    if (ny_fastest) {
+        const int nyc = Cout / Cf::BN, x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        tile = x * (ntiles >> 3) + i / nyc;
+        ny = i % nyc;
+    } else {
+        tile = xcd_remap(blockIdx.x, ntiles);
+        ny = blockIdx.y;
+    }
     const int tf = tile % tiles_f;  tile /= tiles_f;
     const int tt = tile % tiles_t;
     const int64_t b = tile / tiles_t;
     const int t0 = tt * Cf::TH, f0 = tf * TW;
-    const int ny = blockIdx.y;
     const int nq = Cin / Cf::KC;
 
     int pbase[4];
@@ -1362,19 +1371,28 @@ __device__ __forceinline__ void tdfw_read_x(bf16x8 (&xf)[3], const bf16_t* base)
     xf[2] = tdfw_read_frag<OFF + 64>(base);
 }
 
-template <int WM, bool RESIDUAL>
+template <int WM, bool RESIDUAL, int RPF = 2>               // RPF: units of residual rows requested ahead of the stores
 __global__ void __launch_bounds__(64 * WM, 2)
 tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wf,
                      const float* __restrict__ bias, const float* __restrict__ scale, const float* __restrict__ shift,
-                     const bf16_t* __restrict__ R, int M, int K, int64_t nunits, int C) {
+                     const bf16_t* __restrict__ R, int M, int K, int64_t nunits, int C, int nyb) {
     typedef TdfWide<WM> Tc;
     bf16_t* ring = reinterpret_cast<bf16_t*>(alsep_smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: row block, DMA duty and their bases live in SGPRs
     const int l15 = lane & 15, lq = lane >> 4;
-    const int rowblk = blockIdx.y * WM + wave;                       // 48-row block of the weight matrix
+    // nyb > 0 (1-D grid, column tiles % 8 == 0): the nyb row blocks that read the same four units are dispatched back to
+    // back onto one XCD (ids b, b+8, ... share an L2), so the activations come from HBM once instead of once per row
+    // block -- with row blocks on blockIdx.y they are re-streamed M/BM times, a whole grid.x apart
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (nyb > 0) {
+        const int i = (int)blockIdx.x >> 3;
+        by = i % nyb;
+        bx = (i / nyb) * 8 + ((int)blockIdx.x & 7);
+    }
+    const int rowblk = by * WM + wave;                               // 48-row block of the weight matrix
     const int upc = C / Tc::UC;
-    const int64_t u0 = (int64_t)blockIdx.x * Tc::UN;
+    const int64_t u0 = (int64_t)bx * Tc::UN;
     const int ntile = K / Tc::BK;
     if (ntile <= 0) return;                                          // (the launcher never does this; removes the zero-trip path)
 
@@ -1483,11 +1501,37 @@ tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const
     float bvv[3];
 #pragma unroll
     for (int mi = 0; mi < 3; ++mi) bvv[mi] = bias ? bias[rowblk * Tc::TR + mi * 16 + l15] : 0.f;
+    // 48 rows x 6 groups of 8 channels = 288 16-byte output groups per unit, 5 per lane (the last one half-filled)
+    // unit u: wave-uniform base (SGPR pair) + five 32-bit lane offsets shared by every unit and by R and Y
+    auto unit_base = [&](int u) {
+        const int64_t U = u0 + u;
+        return ((U / upc) * M + rowblk * Tc::TR) * (int64_t)C + (int)(U % upc) * Tc::UC;
+    };
+    unsigned loff[5];
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        const int gidx = it * 64 + lane;
+        loff[it] = (unsigned)(((gidx / 6) * C + (gidx % 6) * 8) * (int)sizeof(bf16_t));
+    }
+    // The residual rows are the only HBM reads of the epilogue and nothing else hides their latency (two waves per SIMD):
+    // unit u+PF's rows are requested before unit u is written, instead of one dependent load -> add -> store chain per unit.
+    constexpr int PF = RESIDUAL ? RPF : 0;
+    bf16x8 rr[Tc::UN][5];
+    auto load_res = [&](int u) {
+        const char* rb = opaque_uniform_ptr(reinterpret_cast<const char*>(R + unit_base(u)));
+#pragma unroll
+        for (int it = 0; it < 5; ++it)
+            if (it * 64 + lane < Tc::TR * 6) rr[u][it] = *reinterpret_cast<const bf16x8*>(rb + loff[it]);
+    };
+    if (RESIDUAL) {
+#pragma unroll
+        for (int u = 0; u < PF && u < Tc::UN; ++u) load_res(u);
+    }
 #pragma unroll
     for (int u = 0; u < Tc::UN; ++u) {
-        const int64_t U = u0 + u;
-        const int64_t bt = U / upc;
-        const int cb = (int)(U % upc) * Tc::UC;
+        const int cb = (int)((u0 + u) % upc) * Tc::UC;
+        if (RESIDUAL && u + PF < Tc::UN) load_res(u + PF);
+        char* yb = const_cast<char*>(opaque_uniform_ptr(reinterpret_cast<const char*>(Y + unit_base(u))));
 #pragma unroll
         for (int ni = 0; ni < 3; ++ni) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + cb + ni * 16 + 4 * lq);
@@ -1501,7 +1545,6 @@ tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // 48 rows x 6 groups of 8 channels = 288 16-byte output groups
 #pragma unroll
         for (int it = 0; it < 5; ++it) {
             const int gidx = it * 64 + lane;
@@ -1509,19 +1552,15 @@ tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const
             if (gidx < Tc::TR * 6) {
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + fr * Tc::UC + cg * 8);
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + fr * Tc::UC + cg * 8 + 4);
-                {
-                    const int64_t o = (bt * M + rowblk * Tc::TR + fr) * (int64_t)C + cb + cg * 8;
-                    float y[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    if (RESIDUAL) {
-                        const bf16x8 xr = *reinterpret_cast<const bf16x8*>(R + o);
+                float y[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (RESIDUAL) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) y[e] += (float)xr[e];
-                    }
-                    bf16x8 q;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) q[e] = (bf16_t)y[e];
-                    *reinterpret_cast<bf16x8*>(Y + o) = q;
+                    for (int e = 0; e < 8; ++e) y[e] += (float)rr[u][it][e];
                 }
+                bf16x8 q;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[e] = (bf16_t)y[e];
+                *reinterpret_cast<bf16x8*>(yb + loff[it]) = q;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -2121,6 +2160,11 @@ int conv_stagger() {
     return v;
 }
 
+int conv_ny_fastest() {
+    static const int v = [] { const char* e = getenv("ALSEP_CONV_NYFAST"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 template <int TW>
 int launch_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zero_page, int64_t B,
                     int Th, int Fw) {
@@ -2131,9 +2175,12 @@ int launch_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)Cf::lds_bytes));
     ProfScope prof(ctx, TW == 64 ? ALSEP_PROF_CONV3X3 : ALSEP_PROF_CONV3X3_SMALL);
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<TW>), dim3((unsigned)ntiles, L.cout / Cf::BN), dim3(kThreads), Cf::lds_bytes,
+    const int nyc = L.cout / Cf::BN;
+    const int ny_fastest = conv_ny_fastest() && ntiles % 8 == 0 && nyc > 1 && ntiles * nyc <= 0x7fffffff;
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<TW>), ny_fastest ? dim3((unsigned)(ntiles * nyc)) : dim3((unsigned)ntiles, nyc),
+                       dim3(kThreads), Cf::lds_bytes,
                        ctx->stream, X, Y, (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page,
-                       Th, Fw, L.cin, L.cout, tiles_t, tiles_f, (int)ntiles, conv_ablate(), conv_stagger());
+                       Th, Fw, L.cin, L.cout, tiles_t, tiles_f, (int)ntiles, conv_ablate(), conv_stagger(), ny_fastest);
     ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_kernel");
     return ALSEP_OK;
 }
@@ -2199,6 +2246,11 @@ int conv_big_enabled() {
     return v;
 }
 
+int conv_big3_enabled() {
+    static const int v = [] { const char* e = getenv("ALSEP_CONV_BIG3"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 int conv_pipe_enabled() {
     // opt-in: bit-identical to the plain kernel but not faster on MI355X (profiles/r01_conv_variants.txt):
     // the per-CU LDS-DMA intake, not the missing overlap, bounds these levels
@@ -2221,7 +2273,10 @@ int run_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y,
         (conv_big_enabled() >= 2 || B * (Th / 8) * (Fw / 64) >= 96)) {       // =2: no minimum tile count (tests)
         switch (L.cout / 48) {
             case 2: return launch_conv_big<2>(ctx, L, X, Y, zp, B, Th, Fw);
-            default: break;                                  // NY = 3, 4 spill at 2 waves/SIMD with ROCm 7.2
+            case 3:                                          // 8 VGPRs spill, outside the MFMA loops (ALSEP_CONV_BIG3=0: plain kernel)
+                if (conv_big3_enabled()) return launch_conv_big<3>(ctx, L, X, Y, zp, B, Th, Fw);
+                break;
+            default: break;                                  // NY = 4 spills heavily at 2 waves/SIMD with ROCm 7.2
         }
     }
     if (conv_pipe_enabled() && Th % 4 == 0 && Fw % 64 == 0 && L.cin == L.cout &&
@@ -2319,20 +2374,30 @@ int launch_tdf_wide(alsep_ctx* ctx, const GemmLayer& L, const bf16_t* X, bf16_t*
     const int64_t gx = ceil_div64(nunits, Tc::UN);
     if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "tdf: too many column tiles");
     const float* bias = L.has_bias ? (const float*)L.bias.p : nullptr;
-    const dim3 grid((unsigned)gx, L.M / Tc::BM);
+    static const int yfast = [] { const char* e = getenv("ALSEP_TDF_YFAST"); return e ? atoi(e) : 1; }();
+    const int nrb = L.M / Tc::BM;
+    const int nyb = (yfast && nrb > 1 && gx % 8 == 0 && gx * nrb <= 0x7fffffff) ? nrb : 0;
+    const dim3 grid = nyb ? dim3((unsigned)(gx * nrb)) : dim3((unsigned)gx, nrb);
     ProfScope prof(ctx, ALSEP_PROF_TDF);
-    if (R) {
+    static const int rpf = [] { const char* e = getenv("ALSEP_TDF_RPF"); return e ? atoi(e) : 2; }();
+    if (R && rpf == 0) {                                     // timing comparison only: residual rows loaded where they are used
+        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)tdf_bf16_wide_kernel<WM, true, 0>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Tc::lds_bytes));
+        hipLaunchKernelGGL((tdf_bf16_wide_kernel<WM, true, 0>), grid, dim3(Tc::THREADS), Tc::lds_bytes, ctx->stream, X, Y,
+                           (const bf16_t*)L.wwide.p, bias, (const float*)L.scale.p, (const float*)L.shift.p, R, L.M, L.K,
+                           nunits, C, nyb);
+    } else if (R) {
         ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)tdf_bf16_wide_kernel<WM, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Tc::lds_bytes));
         hipLaunchKernelGGL((tdf_bf16_wide_kernel<WM, true>), grid, dim3(Tc::THREADS), Tc::lds_bytes, ctx->stream, X, Y,
                            (const bf16_t*)L.wwide.p, bias, (const float*)L.scale.p, (const float*)L.shift.p, R, L.M, L.K,
-                           nunits, C);
+                           nunits, C, nyb);
     } else {
         ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)tdf_bf16_wide_kernel<WM, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Tc::lds_bytes));
         hipLaunchKernelGGL((tdf_bf16_wide_kernel<WM, false>), grid, dim3(Tc::THREADS), Tc::lds_bytes, ctx->stream, X, Y,
                            (const bf16_t*)L.wwide.p, bias, (const float*)L.scale.p, (const float*)L.shift.p, R, L.M, L.K,
-                           nunits, C);
+                           nunits, C, nyb);
     }
     ALSEP_LAUNCH_CHECK(ctx, "tdf_bf16_wide_kernel");
     return ALSEP_OK;
