@@ -46,11 +46,11 @@ def conv_flops_per_chunk(cfg, levels) -> float:
 
 def conv_kernel_levels(cfg, bf16: bool, batch: int):
     """Which U-Net levels run which 3x3 kernel -- mirrors run_conv_dma() in tdfnet.hip:
-    level 0 (c = 48) -> persistent register-weight kernel; c = 96 with T % 8 == 0 and >= 96 8x64 tiles -> the
-    8-wave big-tile kernel; the other levels with F % 64 == 0 -> conv3x3_bf16_kernel<64>.
-    Returns {class: [levels]} with classes "regw", "big", "plain"."""
+    level 0 (c = 48) -> persistent register-weight kernel; c = 96 / 144 with T % 8 == 0 and >= 96 8x64 tiles -> the
+    8-wave big-tile kernel (NY = 2 / 3); the other levels with F % 64 == 0 -> conv3x3_bf16_kernel<64>.
+    Returns {class: [levels]} with classes "regw", "big", "big3", "plain"."""
     lv = cfg.levels()
-    out = {"regw": [], "big": [], "plain": []}
+    out = {"regw": [], "big": [], "big3": [], "plain": []}
     for i, (c, t, f) in enumerate(lv):
         if f % 64:
             continue                                          # TW < 64 tiles: ALSEP_PROF_CONV3X3_SMALL, not reported
@@ -59,6 +59,9 @@ def conv_kernel_levels(cfg, bf16: bool, batch: int):
         elif (bf16 and c == 96 and t % 8 == 0 and batch * (t // 8) * (f // 64) >= 96
               and os.environ.get("ALSEP_CONV_BIG", "1") != "0"):
             out["big"].append(i)
+        elif (bf16 and c == 144 and t % 8 == 0 and batch * (t // 8) * (f // 64) >= 96
+              and os.environ.get("ALSEP_CONV_BIG", "1") != "0" and os.environ.get("ALSEP_CONV_BIG3", "1") != "0"):
+            out["big3"].append(i)
         else:
             out["plain"].append(i)
     return out
@@ -161,6 +164,7 @@ def main() -> None:
     fence()
     klevels = conv_kernel_levels(cfg, dtype == torch.bfloat16, args.batch)
     KCLASS = {"big": ("conv3x3_bf16_big_kernel<2>", _lib.PROF_CONV3X3_BIG),
+              "big3": ("conv3x3_bf16_big_kernel<3>", _lib.PROF_CONV3X3_BIG3),
               "regw": ("conv3x3_bf16_regw_kernel<1>", _lib.PROF_CONV3X3_REGW),
               "plain": ("conv3x3_bf16_kernel<64>" if dtype == torch.bfloat16 else "conv3x3_kernel<f32,16,48,64>",
                         _lib.PROF_CONV3X3)}
@@ -210,7 +214,7 @@ def main() -> None:
     roofline = conv_entry(primary, conv_ms, conv_launches, args.steps)
     # the other 3x3 kernel classes, one extra untimed pass each
     other = {}
-    for cls in ("regw", "big", "plain"):
+    for cls in ("regw", "big", "big3", "plain"):
         if cls == primary or not klevels[cls]:
             continue
         ctx.profile_begin(KCLASS[cls][1])

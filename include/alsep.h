@@ -66,7 +66,8 @@ enum {
     ALSEP_PROF_ISTFT = 7,
     ALSEP_PROF_CONV3X3_REGW = 8, /* conv3x3_bf16_regw_kernel (persistent, level 0) */
     ALSEP_PROF_CONV3X3_PIPE = 9, /* conv3x3_bf16_pipe_kernel (opt-in) */
-    ALSEP_PROF_CONV3X3_BIG = 10  /* conv3x3_bf16_big_kernel (8-wave 8x64 tile, level 1) */
+    ALSEP_PROF_CONV3X3_BIG = 10, /* conv3x3_bf16_big_kernel<2> (8-wave 8x64 tile, 96 channels: level 1) */
+    ALSEP_PROF_CONV3X3_BIG3 = 11 /* conv3x3_bf16_big_kernel<3> (same kernel, 144 channels: level 2) */
 };
 int alsep_profile_begin(alsep_ctx* ctx, int category);
 int alsep_profile_end(alsep_ctx* ctx, double* total_ms, int64_t* launches);

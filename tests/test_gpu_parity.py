@@ -131,6 +131,34 @@ def test_net_f32_vs_torch_reference(ctx):
         assert err < 5e-4, f"{kw}: max rel err {err:.3e}"
 
 
+def test_net_from_onnx_file_vs_torch_reference(ctx, tmp_path):
+    """Real-weight path: an MDX-Net .onnx (written in the torch.onnx export style by tests/onnx_writer.py) read by
+    audiolab_amd.onnx_reader, run on the HIP kernels, against the torch oracle on the ORIGINAL (un-folded) weights."""
+    from audiolab_amd.onnx_reader import load_mdx_onnx
+    from audiolab_amd.synth import synthetic_state_dict
+    from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
+    from oracle import tdfnet_oracle
+    from tests.onnx_writer import write_mdx_onnx
+    cfg = TDFNetConfig(dim_f=256, dim_t=32, n_fft=512, hop=128, num_blocks=7, g=48)
+    sd = synthetic_state_dict(cfg, seed=5, calib_frames=32)
+    gen = torch.Generator().manual_seed(9)
+    for k in list(sd):                                       # non-trivial BatchNorm statistics, so that the fold matters
+        if k.endswith("running_mean"):
+            sd[k] = 0.05 * torch.randn(sd[k].shape, generator=gen)
+        elif k.endswith("running_var"):
+            sd[k] = 0.8 + 0.4 * torch.rand(sd[k].shape, generator=gen)
+    path = str(tmp_path / "toy.onnx")
+    write_mdx_onnx(path, sd, cfg)
+    m = load_mdx_onnx(path, n_fft=cfg.n_fft, hop=cfg.hop)
+    assert m.config == cfg
+    net = TDFNet(m.config, m.state_dict, ctx=ctx, dtype=torch.float32, max_batch=4)
+    x = torch.randn((2, 4, cfg.dim_f, cfg.dim_t), generator=gen) * 4.0
+    want = tdfnet_oracle.forward(sd, x, cfg.num_blocks, cfg.l, cfg.bn)
+    got = net.forward_nhwc(x.permute(0, 3, 2, 1).contiguous().cuda()).float().cpu().permute(0, 3, 2, 1)
+    err = float((got - want).abs().max() / want.abs().max())
+    assert err < 5e-4, f"max rel err {err:.3e}"
+
+
 def test_net_bf16_vs_torch_reference(ctx):
     for nb, tol in ((1, 2e-2), (3, 6e-2), (7, 0.5)):
         got, want, *_ = _net_case(ctx, dict(dim_f=256, dim_t=32, n_fft=512, hop=128, num_blocks=nb, g=48), torch.bfloat16, 2)
