@@ -53,3 +53,15 @@ def test_streaming_ds_us_match_tile_gemm(tmp_path):
     got = run_mode((1, 0, 1), str(tmp_path / "s1.npy"), ALSEP_PIX_STREAM="1")
     assert np.isfinite(base).all() and np.abs(base).max() > 1e-3
     assert np.array_equal(base, got), f"max diff {np.abs(base - got).max()} (peak {np.abs(base).max()})"
+
+
+def test_dispatch_orders_and_prefetch_bit_identical(tmp_path):
+    """XCD-local dispatch orders (plain conv: ALSEP_CONV_NYFAST, wide TDF: ALSEP_TDF_YFAST), the NY = 3 big-tile conv
+    (ALSEP_CONV_BIG3) and the residual prefetch of the wide TDF epilogue (ALSEP_TDF_RPF) only change WHICH workgroup
+    computes a tile or when a row is loaded -- every switch off must reproduce the default bit for bit."""
+    base = run_mode((1, 0, 1), str(tmp_path / "d0.npy"))
+    assert np.isfinite(base).all() and np.abs(base).max() > 1e-3
+    for extra in (dict(ALSEP_CONV_NYFAST="0"), dict(ALSEP_TDF_YFAST="0"), dict(ALSEP_CONV_BIG3="0"), dict(ALSEP_TDF_RPF="0"),
+                  dict(ALSEP_CONV_NYFAST="0", ALSEP_TDF_YFAST="0", ALSEP_CONV_BIG3="0", ALSEP_TDF_RPF="0")):
+        got = run_mode((1, 0, 1), str(tmp_path / "d1.npy"), **extra)
+        assert np.array_equal(base, got), f"{extra}: max diff {np.abs(base - got).max()}"
