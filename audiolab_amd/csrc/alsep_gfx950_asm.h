@@ -53,6 +53,17 @@ __device__ __forceinline__ const T* opaque_uniform_ptr(const T* p) {
     return (const T*)v;
 }
 
+// The same, typed as a GLOBAL (address space 1) pointer: a pointer that went through the integer round trip above is
+// generic, and loads through it are flat_load + "s_waitcnt vmcnt(0) lgkmcnt(0)" -- no counted waits, so at most two or
+// three of an unrolled batch of loads are in flight.  Through this type they are global_load with counted vmcnt.
+#define ALSEP_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const ALSEP_GLOBAL T* opaque_uniform_gptr(const T* p) {
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("" : "+s"(v));
+    return (const ALSEP_GLOBAL T*)v;
+}
+
 // Asynchronous 16-byte global load into a register fragment, invisible to hipcc's waitcnt bookkeeping:
 //   dst <- *(sbase + voff + OFF)      (sbase wave-uniform SGPR pair, voff a 32-bit lane offset, 0 <= OFF < 4096)
 // A compiler-tracked load issued between LDS-DMAs inside a software-pipelined loop is waited for with

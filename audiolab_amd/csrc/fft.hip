@@ -369,6 +369,31 @@ istft_regring_kernel(const InT* __restrict__ spec, int dim_f, int T, const float
         if (t < T) {
             typename Fft<N, NT>::Regs fft;
             fft.load(tw, tid);
+            if (LAYOUT == ALSEP_LAYOUT_NHWC) {
+                // All of a thread's bins as ONE batch of loads (address clamped into the frame's row, value zeroed by a
+                // select for bins >= dim_f): a per-bin `if (k < dim_f)` around the load is an exec-masked branch plus
+                // s_waitcnt vmcnt(0) per bin, i.e. N/512 serialised memory round trips per frame.
+                constexpr int KI = N / 2 / NT;
+                static_assert(N % (2 * NT) == 0, "register ring: n_fft multiple of 512");
+                const InT* row = spec + (b * T + t) * (int64_t)dim_f * 4;
+                float v[KI][4];
+#pragma unroll
+                for (int i = 0; i < KI; ++i) load_spec4<InT>(row + (int64_t)min(tid + i * NT, dim_f - 1) * 4, v[i]);
+                float vn[4] = {0.f, 0.f, 0.f, 0.f};
+                if (tid == 0 && N / 2 < dim_f) load_spec4<InT>(row + (int64_t)(N / 2) * 4, vn);
+#pragma unroll
+                for (int i = 0; i < KI; ++i) {
+                    const int k = tid + i * NT;
+                    if (k >= dim_f) { v[i][0] = 0.f; v[i][1] = 0.f; v[i][2] = 0.f; v[i][3] = 0.f; }
+                    if (i == 0 && tid == 0) {                 // c2r ignores Im of DC
+                        buf[0] = make_float2(v[i][0], -v[i][2]);
+                    } else {
+                        buf[k] = make_float2(v[i][0] - v[i][3], -(v[i][1] + v[i][2]));
+                        buf[N - k] = make_float2(v[i][0] + v[i][3], v[i][1] - v[i][2]);
+                    }
+                }
+                if (tid == 0) buf[N / 2] = make_float2(vn[0], -vn[2]);   // ... and of Nyquist
+            } else
             for (int k = tid; k <= N / 2; k += NT) {
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
                 if (k < dim_f) {
@@ -399,6 +424,10 @@ istft_regring_kernel(const InT* __restrict__ spec, int dim_f, int T, const float
             __syncthreads();                                 // buf is rewritten by the next frame
         }
         if (t >= j0) {
+            float ev[NB];                                    // envelope values as one batch of loads, then the guarded stores
+            const int64_t p_last = (int64_t)(T - 1) * HOP + N - 1;   // the table has N + HOP (T - 1) entries
+#pragma unroll
+            for (int j = 0; j < NB; ++j) ev[j] = env[min((int64_t)t * HOP + j * NT + tid, p_last)];
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int64_t p = (int64_t)t * HOP + j * NT + tid;
@@ -406,7 +435,7 @@ istft_regring_kernel(const InT* __restrict__ spec, int dim_f, int T, const float
                 if (s >= keep_lo && s < keep_hi) {
                     const int64_t o = b * out_chunk_stride + (s - keep_lo);
                     if (o < out_limit) {
-                        const float e = 1.0f / env[p];
+                        const float e = 1.0f / ev[j];
                         out[o] = acc[j].x * e;
                         out[out_ch_stride + o] = acc[j].y * e;
                     }
@@ -635,15 +664,16 @@ static int launch_istft(alsep_ctx* ctx, const alsep_plan* p, const void* spec, i
         if (p->hop == 1024 && r16_on) {                      // production geometry: three-pass kernel
             constexpr int R2 = N / 256;
             const size_t lds_r = r16::istft_lds_bytes<R2>();
-            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)r16::istft_r16_kernel<R2, 8, InT, LAYOUT>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+            const bool full = p->dim_f >= N / 2;                // production band: every bin below Nyquist is stored
+            auto kern = full ? r16::istft_r16_kernel<R2, 8, InT, LAYOUT, true> : r16::istft_r16_kernel<R2, 8, InT, LAYOUT, false>;
+            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
             static const int run_env = [] { const char* e = getenv("ALSEP_ISTFT_RUN"); return e ? atoi(e) : 0; }();
             const int run = run_env > 0 ? run_env : istft_pick_run(j_hi - j_lo, Q, n_chunks, 3 * device_cu_count(ctx));
             const int groups_r = (j_hi - j_lo + run - 1) / run;
             for (int64_t b0 = 0; b0 < n_chunks; b0 += 32768) {
                 const int64_t nb = std::min<int64_t>(32768, n_chunks - b0);
                 const int64_t spec_off = b0 * 4 * (int64_t)p->dim_f * p->dim_t;
-                hipLaunchKernelGGL((r16::istft_r16_kernel<R2, 8, InT, LAYOUT>), dim3(groups_r, (unsigned)nb),
+                hipLaunchKernelGGL(kern, dim3(groups_r, (unsigned)nb),
                                    dim3(r16::kThreads), lds_r, ctx->stream, (const InT*)spec + spec_off, p->dim_f, p->dim_t,
                                    (const float2*)p->tw, (const float*)p->env, j_lo, j_hi, run,
                                    out + b0 * out_chunk_stride, out_ch_stride, out_chunk_stride, keep_lo, keep_hi,

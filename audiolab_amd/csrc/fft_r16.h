@@ -407,10 +407,20 @@ template <> __device__ __forceinline__ void load_bin<bf16_t>(const bf16_t* p, v2
     L = mk((float)q[0], (float)q[1]); R = mk((float)q[2], (float)q[3]);
 }
 
+template <typename InT> __device__ __forceinline__ void load_bin_g(const ALSEP_GLOBAL char* p, v2f& L, v2f& R);
+template <> __device__ __forceinline__ void load_bin_g<float>(const ALSEP_GLOBAL char* p, v2f& L, v2f& R) {
+    const f32x4 q = *reinterpret_cast<const ALSEP_GLOBAL f32x4*>(p);
+    L = mk(q[0], q[1]); R = mk(q[2], q[3]);
+}
+template <> __device__ __forceinline__ void load_bin_g<bf16_t>(const ALSEP_GLOBAL char* p, v2f& L, v2f& R) {
+    const bf16x4 q = *reinterpret_cast<const ALSEP_GLOBAL bf16x4*>(p);
+    L = mk((float)q[0], (float)q[1]); R = mk((float)q[2], (float)q[3]);
+}
+
 template <int R2> constexpr int istft_lds_bytes() { return 256 * (R2 + 1) * 8; }
 
 // grid (n_groups, n_chunks); each workgroup finishes `run` consecutive hop-blocks (as istft_regring_kernel).
-template <int R2, int NBH, typename InT, int LAYOUT>
+template <int R2, int NBH, typename InT, int LAYOUT, bool FULL>   // FULL: dim_f >= N/2 (no zero-filled bins below Nyquist)
 __global__ void __launch_bounds__(kThreads) ALSEP_WAVES_PER_EU(2)
 istft_r16_kernel(const InT* __restrict__ spec, int dim_f, int T, const float2* __restrict__ tw_,
                  const float* __restrict__ env, int j_lo, int j_hi, int run,
@@ -464,41 +474,48 @@ istft_r16_kernel(const InT* __restrict__ spec, int dim_f, int T, const float2* _
                 const InT* frame = spec + (b * T + t) * (int64_t)dim_f * 4;   // NHWC row of this frame (uniform)
                 v2f za[R2], zb[R2];
                 v2f mA[H], mB[H];
-#pragma unroll
-                for (int r = 0; r < H; ++r) {
-                    v2f L = mk(0.f, 0.f), R = mk(0.f, 0.f);
-                    const int k = ka + 256 * r;
-                    if (k < dim_f) {
-                        if (LAYOUT == ALSEP_LAYOUT_NHWC) {
-                            load_bin<InT>(reinterpret_cast<const InT*>(opaque_uniform_ptr(reinterpret_cast<const char*>(frame + 256 * r * 4)) + voffA), L, R);
+                // One bin (L_re, L_im, R_re, R_im).  GUARDED = false (dim_f >= N/2, the production band: every bin of the
+                // half spectrum is stored): plain loads, so the 2 H loads of a frame are in flight together.  Otherwise the
+                // address is clamped into the row and the value zeroed by a select -- never a branch around the load: a
+                // per-load `if (k < dim_f)` costs one exec-masked branch and one s_waitcnt vmcnt(0) per bin, i.e. 2 H
+                // serialised memory round trips per frame (that was 3/4 of this kernel's time).
+                auto fetch = [&](auto guarded, int r, int k, unsigned voff, v2f& L, v2f& R) {
+                    if (LAYOUT == ALSEP_LAYOUT_NHWC) {
+                        if (!decltype(guarded)::value) {
+                            load_bin_g<InT>(opaque_uniform_gptr(reinterpret_cast<const char*>(frame + 256 * r * 4)) + voff, L, R);
                         } else {
+                            const int kc = min(k, dim_f - 1);
+                            load_bin_g<InT>(opaque_uniform_gptr(reinterpret_cast<const char*>(frame)) + (unsigned)kc * (4u * (unsigned)sizeof(InT)), L, R);
+                            if (k >= dim_f) { L = mk(0.f, 0.f); R = mk(0.f, 0.f); }
+                        }
+                    } else {
+                        L = mk(0.f, 0.f); R = mk(0.f, 0.f);
+                        if (k < dim_f) {
                             const int64_t plane = (int64_t)dim_f * T;
                             const InT* s = spec + b * 4 * plane + (int64_t)k * T + t;
                             L = mk(to_f32(s[0]), to_f32(s[plane]));
                             R = mk(to_f32(s[2 * plane]), to_f32(s[3 * plane]));
                         }
                     }
-                    if (r == 0 && t0) { L.y = 0.f; R.y = 0.f; }          // c2r ignores Im of DC
-                    za[r] = cx_conj_add_pi(L, R);                          // conj Z[k]
-                    mA[r] = cx_add_mi(L, R);                               // conj Z[N-k]
-                }
+                };
+                auto pass_a_inputs = [&](auto guarded) {
 #pragma unroll
-                for (int r = 0; r < H; ++r) {
-                    v2f L = mk(0.f, 0.f), R = mk(0.f, 0.f);
-                    const int k = kb + 256 * r;
-                    if (k < dim_f) {
-                        if (LAYOUT == ALSEP_LAYOUT_NHWC) {
-                            load_bin<InT>(reinterpret_cast<const InT*>(opaque_uniform_ptr(reinterpret_cast<const char*>(frame + 256 * r * 4)) + voffB), L, R);
-                        } else {
-                            const int64_t plane = (int64_t)dim_f * T;
-                            const InT* s = spec + b * 4 * plane + (int64_t)k * T + t;
-                            L = mk(to_f32(s[0]), to_f32(s[plane]));
-                            R = mk(to_f32(s[2 * plane]), to_f32(s[3 * plane]));
-                        }
+                    for (int r = 0; r < H; ++r) {
+                        v2f L, R;
+                        fetch(guarded, r, ka + 256 * r, voffA, L, R);
+                        if (r == 0 && t0) { L.y = 0.f; R.y = 0.f; }      // c2r ignores Im of DC
+                        za[r] = cx_conj_add_pi(L, R);                      // conj Z[k]
+                        mA[r] = cx_add_mi(L, R);                           // conj Z[N-k]
                     }
-                    zb[r] = cx_conj_add_pi(L, R);
-                    mB[r] = cx_add_mi(L, R);
-                }
+#pragma unroll
+                    for (int r = 0; r < H; ++r) {
+                        v2f L, R;
+                        fetch(guarded, r, kb + 256 * r, voffB, L, R);
+                        zb[r] = cx_conj_add_pi(L, R);
+                        mB[r] = cx_add_mi(L, R);
+                    }
+                };
+                pass_a_inputs(std::integral_constant<bool, !FULL>{});
                 v2f nyq = mk(0.f, 0.f);
                 if (t0 && dim_f > N / 2) {                               // Nyquist bin: Im ignored
                     v2f L, R;
@@ -575,6 +592,12 @@ istft_r16_kernel(const InT* __restrict__ spec, int dim_f, int T, const float2* _
         }
         // hop-block j = t is complete
         if (t >= j0) {
+            // envelope values of the NBH finished samples first, as one batch of loads (the table has
+            // N + HOP (T - 1) entries; the clamp keeps an unguarded load inside it), then the guarded stores
+            float e[NBH];
+            const int64_t p_last = (int64_t)(T - 1) * HOP + N - 1;
+#pragma unroll
+            for (int j = 0; j < NBH; ++j) e[j] = env[min((int64_t)t * HOP + j * NT + tid, p_last)];
 #pragma unroll
             for (int j = 0; j < NBH; ++j) {
                 const int64_t p = (int64_t)t * HOP + j * NT + tid;
@@ -582,9 +605,9 @@ istft_r16_kernel(const InT* __restrict__ spec, int dim_f, int T, const float2* _
                 if (s >= keep_lo && s < keep_hi) {
                     const int64_t o = b * out_chunk_stride + (s - keep_lo);
                     if (o < out_limit) {
-                        const float e = 1.0f / env[p];
-                        out[o] = acc[j].x * e;
-                        out[out_ch_stride + o] = -acc[j].y * e;
+                        const float r = 1.0f / e[j];
+                        out[o] = acc[j].x * r;
+                        out[out_ch_stride + o] = -acc[j].y * r;
                     }
                 }
             }

@@ -1518,10 +1518,10 @@ tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const
     constexpr int PF = RESIDUAL ? RPF : 0;
     bf16x8 rr[Tc::UN][5];
     auto load_res = [&](int u) {
-        const char* rb = opaque_uniform_ptr(reinterpret_cast<const char*>(R + unit_base(u)));
+        const ALSEP_GLOBAL char* rb = opaque_uniform_gptr(reinterpret_cast<const char*>(R + unit_base(u)));   // global_load, counted vmcnt
 #pragma unroll
         for (int it = 0; it < 5; ++it)
-            if (it * 64 + lane < Tc::TR * 6) rr[u][it] = *reinterpret_cast<const bf16x8*>(rb + loff[it]);
+            if (it * 64 + lane < Tc::TR * 6) rr[u][it] = *reinterpret_cast<const ALSEP_GLOBAL bf16x8*>(rb + loff[it]);
     };
     if (RESIDUAL) {
 #pragma unroll
@@ -1531,7 +1531,7 @@ tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const
     for (int u = 0; u < Tc::UN; ++u) {
         const int cb = (int)((u0 + u) % upc) * Tc::UC;
         if (RESIDUAL && u + PF < Tc::UN) load_res(u + PF);
-        char* yb = const_cast<char*>(opaque_uniform_ptr(reinterpret_cast<const char*>(Y + unit_base(u))));
+        ALSEP_GLOBAL char* yb = const_cast<ALSEP_GLOBAL char*>(opaque_uniform_gptr(reinterpret_cast<const char*>(Y + unit_base(u))));
 #pragma unroll
         for (int ni = 0; ni < 3; ++ni) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + cb + ni * 16 + 4 * lq);
@@ -1560,7 +1560,7 @@ tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const
                 bf16x8 q;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) q[e] = (bf16_t)y[e];
-                *reinterpret_cast<bf16x8*>(yb + loff[it]) = q;
+                *reinterpret_cast<ALSEP_GLOBAL bf16x8*>(yb + loff[it]) = q;
             }
         }
         __builtin_amdgcn_wave_barrier();

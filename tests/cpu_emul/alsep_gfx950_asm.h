@@ -31,6 +31,10 @@ static inline void lds_read_tr16_wait_n() {}
 template <typename T>
 static inline const T* opaque_uniform_ptr(const T* p) { return p; }
 
+#define ALSEP_GLOBAL
+template <typename T>
+static inline const T* opaque_uniform_gptr(const T* p) { return p; }
+
 template <int OFF>
 static inline void global_load_async_bf16x8(bf16x8& dst, const void* sbase, unsigned voff) {
     dst = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sbase) + voff + OFF);
