@@ -1351,7 +1351,9 @@ struct TdfWide {
     static constexpr int GLDS = PIECES / WM;                         // per wave and tile: 6 (WM = 4) / 3 (WM = 8)
     static constexpr int WLOADS = 6;                                 // weight fragments per wave and tile
     static constexpr size_t ring_bytes = (size_t)NST * STAGE_ELEMS * sizeof(bf16_t);
-    static constexpr size_t stage_bytes = (size_t)WM * TR * UC * sizeof(float);    // epilogue: one unit per wave, fp32
+    static constexpr int SS = 52;                                     // epilogue row stride in floats: 48 + 4 makes the ds_write_b128 of the
+                                                                      // accumulator fragments conflict-free (stride 48: 4-way; SQ_LDS_BANK_CONFLICT was 44 % of the LDS cycles)
+    static constexpr size_t stage_bytes = (size_t)WM * TR * SS * sizeof(float);    // epilogue: one unit per wave, fp32
     static constexpr size_t lds_bytes = ring_bytes > stage_bytes ? ring_bytes : stage_bytes;
     static_assert(PIECES % WM == 0 && 6 % GLDS == 0, "a wave's LDS-DMA pieces stay inside one unit");
 };
@@ -1497,7 +1499,7 @@ tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const
     // accumulator fragment of a lane is 4 channels of one f' row; re-laid out it leaves as whole
     // 96-byte rows (16-byte residual loads and stores).  Arithmetic as in tdf_bf16_kernel: bias, BN,
     // ReLU and the residual add in fp32, one rounding to bf16.
-    float* stg = reinterpret_cast<float*>(alsep_smem) + (size_t)wave * (Tc::TR * Tc::UC);
+    float* stg = reinterpret_cast<float*>(alsep_smem) + (size_t)wave * (Tc::TR * Tc::SS);
     float bvv[3];
 #pragma unroll
     for (int mi = 0; mi < 3; ++mi) bvv[mi] = bias ? bias[rowblk * Tc::TR + mi * 16 + l15] : 0.f;
@@ -1541,7 +1543,7 @@ tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const
                 f32x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(acc[u][ni][mi][r] + bvv[mi], sc[r], sh[r]), 0.f);
-                *reinterpret_cast<f32x4*>(stg + (mi * 16 + l15) * Tc::UC + ni * 16 + 4 * lq) = v;
+                *reinterpret_cast<f32x4*>(stg + (mi * 16 + l15) * Tc::SS + ni * 16 + 4 * lq) = v;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1550,8 +1552,8 @@ tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const
             const int gidx = it * 64 + lane;
             const int fr = gidx / 6, cg = gidx % 6;
             if (gidx < Tc::TR * 6) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + fr * Tc::UC + cg * 8);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + fr * Tc::UC + cg * 8 + 4);
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + fr * Tc::SS + cg * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + fr * Tc::SS + cg * 8 + 4);
                 float y[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 if (RESIDUAL) {
 #pragma unroll
