@@ -107,6 +107,46 @@ def test_demix_30s_real_geometry_golden(ctx, golden_dir, tag):
     assert np.max(np.abs(out[0, :, 15 * 44100 - 64: 15 * 44100 + 64] - z[f"real_{tag}_seg"])) < tol
 
 
+@pytest.mark.parametrize("n_fft,dim_f,dim_t", [(6144, 3073, 7), (6144, 1000, 8), (4096, 2049, 6), (4096, 2048, 9), (7680, 3841, 10),
+                                               (7680, 1000, 10), (2048, 1025, 6)])
+def test_production_fft_kernels_band_variants_vs_oracle(ctx, n_fft, dim_f, dim_t):
+    """Full band (Nyquist bin stored), production band and a narrow band (zero-filled bins: the clamped-address + select
+    path of the batched spectrum loads) through the three-pass / register-ring kernels, plain and stitched stores."""
+    from audiolab_amd import _lib
+    from audiolab_amd.mdx import StftPlan
+    from oracle import mdx_oracle as mo
+    plan = StftPlan(ctx, n_fft, 1024, dim_f, dim_t)
+    g = mo.MDXGeometry(dim_f, dim_t, n_fft, 1024)
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((2, 2, plan.chunk_size)).astype(np.float32)
+    want = mo.stft(x, g)
+    xd = torch.from_numpy(x).cuda()
+    ref = plan.stft_strided(xd, plan.chunk_size, 2 * plan.chunk_size, 2, torch.float32, _lib.LAYOUT_REF)
+    assert np.max(np.abs(ref.cpu().numpy() - want)) < 3e-6 * np.max(np.abs(want))
+    spec = rng.standard_normal((2, 4, dim_f, dim_t)).astype(np.float32)
+    want_y = mo.istft(spec, g)
+    tol = 2e-5 * max(1.0, float(np.max(np.abs(want_y))))
+    sp_ref = torch.from_numpy(spec).cuda()
+    sp_nhwc = plan.convert(sp_ref, _lib.LAYOUT_REF)
+    for sp, layout in ((sp_ref, _lib.LAYOUT_REF), (sp_nhwc, _lib.LAYOUT_NHWC)):
+        out = torch.empty((2, 2, plan.chunk_size), device="cuda")
+        plan.istft_strided(sp, layout, out, plan.chunk_size, 2 * plan.chunk_size, 0, plan.chunk_size, 3 * plan.chunk_size)
+        assert np.max(np.abs(out.cpu().numpy() - want_y)) < tol
+    bf = sp_nhwc.to(torch.bfloat16)                        # the production input type
+    want_b = mo.istft(plan.convert(bf.float(), _lib.LAYOUT_NHWC).cpu().numpy(), g)
+    out = torch.empty((2, 2, plan.chunk_size), device="cuda")
+    plan.istft_strided(bf, _lib.LAYOUT_NHWC, out, plan.chunk_size, 2 * plan.chunk_size, 0, plan.chunk_size, 3 * plan.chunk_size)
+    assert np.max(np.abs(out.cpu().numpy() - want_b)) < tol
+    trim, gen = plan.trim, plan.gen_size
+    if gen > 777:
+        limit = gen + 777
+        st = torch.zeros((2, 2 * gen), device="cuda")
+        plan.istft_strided(sp_nhwc, _lib.LAYOUT_NHWC, st, 2 * gen, gen, trim, plan.chunk_size - trim, limit)
+        want_s = want_y[:, :, trim:-trim].transpose(1, 0, 2).reshape(2, -1)
+        assert np.max(np.abs(st.cpu().numpy()[:, :limit] - want_s[:, :limit])) < tol
+        assert float(st[:, limit:].abs().max()) == 0.0
+
+
 def _net_case(ctx, kw, dtype, batch, seed=7):
     from audiolab_amd.synth import synthetic_state_dict
     from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
