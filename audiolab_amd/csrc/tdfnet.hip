@@ -1577,7 +1577,18 @@ tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const
 // the MFMA B operand, and only the epilogue goes through LDS to leave as whole contiguous rows.
 // Weights are packed in fragment order [m-tile][k-step][lane][8].
 // ------------------------------------------------------------------------------------------
-struct Ds48 { static constexpr int C = 48, M = 96, K = 192, MT = 6, KS = 6; };
+// Epilogue image of the ds kernels: [64 px][MS] bf16 with MS = M + 4.  A ds_write_b64 group is 16 lanes = 16 consecutive
+// pixels; with rows of M bf16 (M/2 dwords, a multiple of 16) they fall on two bank pairs (8-way; SQ_LDS_BANK_CONFLICT was
+// 67-91 % of these kernels' LDS cycles), with M/2 + 2 dwords per row on sixteen distinct ones.  Rows are then only 8-byte
+// aligned, so the copy-out reads its 16 bytes as two ds_read_b64.
+struct Ds48 { static constexpr int C = 48, M = 96, MS = M + 4, K = 192, MT = 6, KS = 6; };
+__device__ __forceinline__ vec16 lds_read16_align8(const bf16_t* p) {
+    struct alignas(8) half16 { uint32_t w[2]; };
+    const half16 a = *reinterpret_cast<const half16*>(p), b = *reinterpret_cast<const half16*>(p + 4);
+    vec16 v;
+    v.w[0] = a.w[0]; v.w[1] = a.w[1]; v.w[2] = b.w[0]; v.w[3] = b.w[1];
+    return v;
+}
 
 __global__ void __launch_bounds__(kThreads, 1)
 ds48_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wf,
@@ -1585,7 +1596,7 @@ ds48_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const b
     typedef Ds48 D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    bf16_t* stg = reinterpret_cast<bf16_t*>(alsep_smem) + (size_t)wave * 64 * D::M;     // wave-private [64 px][96 ch]
+    bf16_t* stg = reinterpret_cast<bf16_t*>(alsep_smem) + (size_t)wave * 64 * D::MS;    // wave-private [64 px][96 ch (+4)]
     bf16x8 wf[D::MT][D::KS];
 #pragma unroll
     for (int mt = 0; mt < D::MT; ++mt)
@@ -1628,13 +1639,15 @@ ds48_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const b
                 float y[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[mt][ni][r], sc[mt][r], sh[mt][r]), 0.f);
-                store4(stg + (ni * 16 + l15) * D::M + mt * 16 + 4 * lq, y);
+                store4(stg + (ni * 16 + l15) * D::MS + mt * 16 + 4 * lq, y);
             }
         __builtin_amdgcn_wave_barrier();
         bf16_t* yrow = Y + p0 * D::M;                        // 64 pixels x 96 channels = 12 KiB contiguous
 #pragma unroll
-        for (int it = 0; it < 64 * D::M / 8 / 64; ++it)
-            *reinterpret_cast<vec16*>(yrow + ((size_t)it * 64 + lane) * 8) = *reinterpret_cast<const vec16*>(stg + ((size_t)it * 64 + lane) * 8);
+        for (int it = 0; it < 64 * D::M / 8 / 64; ++it) {
+            const int gidx = it * 64 + lane;
+            *reinterpret_cast<vec16*>(yrow + (size_t)gidx * 8) = lds_read16_align8(stg + (gidx / (D::M / 8)) * D::MS + (gidx % (D::M / 8)) * 8);
+        }
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -1645,7 +1658,7 @@ ds48_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const b
 // global memory (the re-read by the other three waves is served by L1); the epilogue goes through one LDS image of the
 // tile so that it leaves as whole contiguous rows.
 template <int C_> struct DsSplitCfg {
-    static constexpr int C = C_, M = C_ + 48, K = 4 * C_, MT = M / 16, KS = K / 32, MTW = (MT + 3) / 4;
+    static constexpr int C = C_, M = C_ + 48, MS = M + 4, K = 4 * C_, MT = M / 16, KS = K / 32, MTW = (MT + 3) / 4;
     static_assert(M % 16 == 0 && K % 32 == 0, "ds stream geometry");
 };
 template <int C_, int OCC>
@@ -1701,14 +1714,14 @@ ds_split_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, con
                     float y[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[j][ni][r], scv[r], shv[r]), 0.f);
-                    store4(stg + (ni * 16 + l15) * D::M + mt * 16 + 4 * lq, y);
+                    store4(stg + (ni * 16 + l15) * D::MS + mt * 16 + 4 * lq, y);
                 }
             }
         }
         __syncthreads();
         bf16_t* yrow = Y + p0 * D::M;                        // 64 pixels x M channels, contiguous
         for (int it = tid; it < 64 * D::M / 8; it += kThreads)
-            *reinterpret_cast<vec16*>(yrow + (size_t)it * 8) = *reinterpret_cast<const vec16*>(stg + (size_t)it * 8);
+            *reinterpret_cast<vec16*>(yrow + (size_t)it * 8) = lds_read16_align8(stg + (it / (D::M / 8)) * D::MS + (it % (D::M / 8)) * 8);
         __syncthreads();
     }
 }
@@ -1718,7 +1731,11 @@ ds_split_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, con
 // loaded).  Wave w owns tap (dy, dx) = (w >> 1, w & 1) of the 2x2 transposed kernel.
 template <int CIN, int C2_, int NI_> struct UsCfg {
     static constexpr int C = CIN, C2 = C2_, NI = NI_, PX = 16 * NI_, MT = C2_ / 16, KS = (CIN + 31) / 32;
-    static constexpr size_t lds_bytes = 2 * (size_t)(2 * PX) * C2_ * sizeof(float);   // [dy][2 PX output pixels][C2] fp32
+    // epilogue image [dy][2 PX output pixels][PS] fp32.  PS = C2 + 4: the lanes of a ds_write_b128 group hold consecutive
+    // input pixels, i.e. rows 2 PS floats apart -- with PS = C2 (a multiple of 16) all eight fall on the same four banks
+    // (8-way; SQ_LDS_BANK_CONFLICT was 83 % of this kernel's LDS cycles), with the pad it is 2-way
+    static constexpr int PS = C2_ + 4;
+    static constexpr size_t lds_bytes = 2 * (size_t)(2 * PX) * PS * sizeof(float);
     static_assert(C2_ % 16 == 0 && CIN % 8 == 0 && (2 * 2 * PX * (C2_ / 8)) % kThreads == 0, "us stream geometry");
 };
 template <int CIN, int C2_, int NI_, int OCC = 1>
@@ -1786,7 +1803,7 @@ us_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf1
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[mt][ni][r], scv[r], shv[r]), 0.f);
                 }
-                *reinterpret_cast<f32x4*>(stg + ((size_t)dy * (2 * U::PX) + 2 * (ni * 16 + l15) + dx) * U::C2 + mt * 16 + 4 * lq) = y;
+                *reinterpret_cast<f32x4*>(stg + ((size_t)dy * (2 * U::PX) + 2 * (ni * 16 + l15) + dx) * U::PS + mt * 16 + 4 * lq) = y;
             }
         __syncthreads();
         // 2 rows x 2 PX pixels x C2/8 groups of 8 channels; each output row is contiguous (2 PX x 2 C2 bytes)
@@ -1796,8 +1813,9 @@ us_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf1
             const int gidx = it * kThreads + tid;
             const int row = gidx / ROWG, rem = gidx % ROWG;
             const int64_t o = ((bb * 2 * Tp + 2 * tp + row) * (2 * (int64_t)Fp) + 2 * fp0) * U::C2 + (int64_t)rem * 8;
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + (size_t)row * (2 * U::PX) * U::C2 + (size_t)rem * 8);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + (size_t)row * (2 * U::PX) * U::C2 + (size_t)rem * 8 + 4);
+            const float* src = stg + ((size_t)row * (2 * U::PX) + rem / NG) * U::PS + (rem % NG) * 8;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 4);
             const bf16x8 sk = *reinterpret_cast<const bf16x8*>(skip + o);
             bf16x8 q;
 #pragma unroll
@@ -2313,17 +2331,17 @@ int run_pix_stream(alsep_ctx* ctx, int mode, const GemmLayer& L, const bf16_t* X
     ProfScope prof(ctx, ALSEP_PROF_PIX);
     const int64_t ntile = ncols / 64;
     if (mode == PIX_DS && L.M == Ds48::M) {
-        const size_t lds = 4 * 64 * Ds48::M * sizeof(bf16_t);
+        const size_t lds = 4 * 64 * Ds48::MS * sizeof(bf16_t);
         const int64_t gx = std::min<int64_t>(ceil_div64(ntile, 4), 256);
         hipLaunchKernelGGL(ds48_stream_kernel, dim3((unsigned)gx), dim3(kThreads), lds, ctx->stream, X, Y, (const bf16_t*)L.wfrag.p,
                            (const float*)L.scale.p, (const float*)L.shift.p, ncols, Tp, Fp);
     } else if (mode == PIX_DS && L.M == DsSplitCfg<96>::M) { // 96 -> 144
-        const size_t lds = 64 * DsSplitCfg<96>::M * sizeof(bf16_t);
+        const size_t lds = 64 * DsSplitCfg<96>::MS * sizeof(bf16_t);
         const int64_t gx = std::min<int64_t>(ntile, 512);
         hipLaunchKernelGGL((ds_split_stream_kernel<96, 2>), dim3((unsigned)gx), dim3(kThreads), lds, ctx->stream, X, Y,
                            (const bf16_t*)L.wfrag.p, (const float*)L.scale.p, (const float*)L.shift.p, ncols, Tp, Fp);
     } else if (mode == PIX_DS) {                             // 144 -> 192
-        const size_t lds = 64 * DsSplitCfg<144>::M * sizeof(bf16_t);
+        const size_t lds = 64 * DsSplitCfg<144>::MS * sizeof(bf16_t);
         const int64_t gx = std::min<int64_t>(ntile, 512);
         hipLaunchKernelGGL((ds_split_stream_kernel<144, 1>), dim3((unsigned)gx), dim3(kThreads), lds, ctx->stream, X, Y,
                            (const bf16_t*)L.wfrag.p, (const float*)L.scale.p, (const float*)L.shift.p, ncols, Tp, Fp);
