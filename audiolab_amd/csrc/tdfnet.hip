@@ -1155,10 +1155,12 @@ tdf_gemm_kernel(const T* __restrict__ X, T* __restrict__ Y, const T* __restrict_
 // ------------------------------------------------------------------------------------------
 struct TdfB16 {
     static constexpr int BM = 128, UN = 4, UC = 48, BK = 64;
+    static constexpr int SS = 52;                              // epilogue row stride (floats): conflict-free accumulator writes, as TdfWide::SS
     static constexpr int WGROUPS = BM * (BK / 8);              // 1024
     static constexpr int XGROUPS = BK * (UC / 8);              // 384 per unit
     static constexpr int STAGE_ELEMS = 8 * (WGROUPS + UN * XGROUPS);             // one stage: W tile + 4 unit tiles
-    static constexpr size_t lds_bytes = 2 * sizeof(bf16_t) * (size_t)STAGE_ELEMS;  // two stages: 80 KiB
+    static constexpr size_t lds_bytes = 2 * sizeof(bf16_t) * (size_t)STAGE_ELEMS;  // two stages: 80 KiB (the epilogue image, 4 x 64 x SS floats, aliases them)
+    static_assert(4 * 64 * SS * sizeof(float) <= lds_bytes, "epilogue image fits the ring");
 };
 
 template <bool RESIDUAL>
@@ -1270,7 +1272,7 @@ tdf_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16
     // 64 rows, so the residual add and the single bf16 rounding stay exactly as before.
     // (all waves are past the last barrier of the k loop: the stage buffers are free; the region is
     // private to the wave, so only its own LDS operations need ordering)
-    float* stg = reinterpret_cast<float*>(alsep_smem) + (size_t)wave * (64 * Tc::UC);
+    float* stg = reinterpret_cast<float*>(alsep_smem) + (size_t)wave * (64 * Tc::SS);
     float bvv[8];
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
@@ -1297,7 +1299,7 @@ tdf_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16
                 v.y = fmaxf(fmaf(acc[ni][mi][1] + bvv[mi], sc[ni][1], sh[ni][1]), 0.f);
                 v.z = fmaxf(fmaf(acc[ni][mi][2] + bvv[mi], sc[ni][2], sh[ni][2]), 0.f);
                 v.w = fmaxf(fmaf(acc[ni][mi][3] + bvv[mi], sc[ni][3], sh[ni][3]), 0.f);
-                *reinterpret_cast<float4*>(stg + (m4 * 16 + l15) * Tc::UC + ni * 16 + 4 * lq) = v;
+                *reinterpret_cast<float4*>(stg + (m4 * 16 + l15) * Tc::SS + ni * 16 + 4 * lq) = v;
             }
         __builtin_amdgcn_wave_barrier();                    // wave-private region: program order suffices on hardware
         // rows [half*64, half*64+64) x 6 groups of 8 channels = 384 16-byte output groups
@@ -1306,8 +1308,8 @@ tdf_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16
             const int gidx = it * 64 + lane;
             const int fr = gidx / 6, cg = gidx % 6;
             const int fo = row0 + half * 64 + fr;
-            const float4 lo = *reinterpret_cast<const float4*>(stg + fr * Tc::UC + cg * 8);
-            const float4 hi = *reinterpret_cast<const float4*>(stg + fr * Tc::UC + cg * 8 + 4);
+            const float4 lo = *reinterpret_cast<const float4*>(stg + fr * Tc::SS + cg * 8);
+            const float4 hi = *reinterpret_cast<const float4*>(stg + fr * Tc::SS + cg * 8 + 4);
             if (uvalid && fo < M) {
                 const int64_t o = (bt * M + fo) * (int64_t)C + cb + cg * 8;
                 float y[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};

@@ -4,7 +4,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 | tee gpurun_out/pytest_gpu.log
+timeout -k 10 900 python -u -m pytest tests -m gpu -v --timeout 420 > gpurun_out/pytest_gpu_full.log 2>&1; tail -4 gpurun_out/pytest_gpu_full.log | tee gpurun_out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.log
 timeout 900 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench_default.log
 rm -rf gpurun_out/prof

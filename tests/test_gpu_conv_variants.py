@@ -33,7 +33,7 @@ np.save(sys.argv[1], np.stack(outs))
 def run_mode(mode, path, **extra):
     regw, pipe, big = mode
     env = dict(os.environ, ALSEP_CONV_REGW=str(regw), ALSEP_CONV_PIPE=str(pipe), ALSEP_CONV_BIG=str(big), **extra)
-    r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}, path], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}, path], env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]
     return np.load(path)
 
