@@ -49,6 +49,8 @@ _SIGNATURES = {
     "alsep_last_error": (C.c_char_p, [C.c_void_p]),
     "alsep_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "alsep_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "alsep_launch_count": (C.c_int64, [C.c_void_p, C.c_char_p]),
+    "alsep_launch_counts_reset": (C.c_int, [C.c_void_p]),
     "alsep_plan_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "alsep_plan_destroy": (C.c_int, [C.c_void_p]),
     "alsep_plan_supported_nfft": (C.c_int, [C.c_int]),
@@ -166,6 +168,13 @@ class Context:
         ms, n = C.c_double(), C.c_int64()
         self.check(self.lib.alsep_profile_end(self.handle, C.byref(ms), C.byref(n)), "alsep_profile_end")
         return ms.value, n.value
+
+    def launch_count(self, kernel: str) -> int:
+        """launches of ``kernel`` (name as reported by its launch site) since creation / the last reset"""
+        return int(self.lib.alsep_launch_count(self.handle, kernel.encode()))
+
+    def launch_counts_reset(self) -> None:
+        self.check(self.lib.alsep_launch_counts_reset(self.handle), "alsep_launch_counts_reset")
 
     def synchronize(self) -> None:
         if DEVICE_TYPE == "cuda":

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -28,7 +29,14 @@ struct alsep_ctx {
     int prof_category = 0;
     std::vector<hipEvent_t> prof_events;     // start/stop pairs
     size_t prof_used = 0;
+    // launches per kernel name since alsep_create / alsep_launch_counts_reset (tests assert WHICH kernel ran)
+    std::map<std::string, int64_t> launches;
+    int cu_count = 0;                        // multiprocessors of `device`, read once per ctx
 };
+
+static inline void note_launch(alsep_ctx* ctx, const char* kernel) {
+    if (ctx) ++ctx->launches[kernel];
+}
 
 // RAII bracket: records a start/stop event pair around the launches of one kernel class when
 // that class is being profiled (alsep_profile_begin); otherwise costs one integer compare.
@@ -70,8 +78,17 @@ static inline int alsep_fail(alsep_ctx* ctx, int code, const char* fmt, ...) {
                               hipGetErrorString(e_), __FILE__, __LINE__);                 \
     } while (0)
 
+// every entry point that allocates or launches first makes the ctx's device current (a Context('cuda:1') in a process
+// whose current device is 0 must not put its tables on device 0)
+#define ALSEP_ENTER(ctx)                                                                  \
+    do {                                                                                  \
+        if ((ctx) && hipSetDevice((ctx)->device) != hipSuccess)                           \
+            return alsep_fail((ctx), ALSEP_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->device); \
+    } while (0)
+
 #define ALSEP_LAUNCH_CHECK(ctx, what)                                                     \
     do {                                                                                  \
+        note_launch((ctx), (what));                                                       \
         hipError_t e_ = hipGetLastError();                                                \
         if (e_ != hipSuccess)                                                             \
             return alsep_fail((ctx), ALSEP_ERR_HIP, "launch of %s failed: %s", (what),    \

@@ -212,9 +212,20 @@ extern "C" int alsep_profile_end(alsep_ctx* ctx, double* total_ms, int64_t* laun
     ctx->prof_used = 0;
     return ALSEP_OK;
 }
+extern "C" int64_t alsep_launch_count(const alsep_ctx* ctx, const char* kernel) {
+    if (!ctx || !kernel) return -1;
+    auto it = ctx->launches.find(kernel);
+    return it == ctx->launches.end() ? 0 : it->second;
+}
+extern "C" int alsep_launch_counts_reset(alsep_ctx* ctx) {
+    if (!ctx) return ALSEP_ERR_ARG;
+    ctx->launches.clear();
+    return ALSEP_OK;
+}
 extern "C" const char* alsep_last_error(const alsep_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
 extern "C" int alsep_axpby(alsep_ctx* ctx, float a, const float* x, float b, float* y, int64_t n) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !x || !y || n < 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_axpby: bad argument");
     if (n == 0) return ALSEP_OK;
     if (((uintptr_t)x | (uintptr_t)y) & 15) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_axpby: pointers must be 16-byte aligned");
@@ -224,6 +235,7 @@ extern "C" int alsep_axpby(alsep_ctx* ctx, float a, const float* x, float b, flo
 }
 
 extern "C" int alsep_peak_abs(alsep_ctx* ctx, const float* x, int64_t n, float* out) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !out || n < 0 || (n > 0 && !x)) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_peak_abs: bad argument");
     ALSEP_HIP(ctx, hipMemsetAsync(out, 0, sizeof(float), ctx->stream));
     if (n == 0) return ALSEP_OK;
@@ -233,6 +245,7 @@ extern "C" int alsep_peak_abs(alsep_ctx* ctx, const float* x, int64_t n, float* 
 }
 
 extern "C" int alsep_scale_by_device(alsep_ctx* ctx, float* y, int64_t n, float num, const float* den, float floor_) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !y || !den || n < 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_scale_by_device: bad argument");
     if (n == 0) return ALSEP_OK;
     hipLaunchKernelGGL(scale_by_device_kernel, dim3(grid_for(n, 4)), dim3(kThreads), 0, ctx->stream, y, n, num, den, floor_);
@@ -241,6 +254,7 @@ extern "C" int alsep_scale_by_device(alsep_ctx* ctx, float* y, int64_t n, float 
 }
 
 extern "C" int alsep_dot3(alsep_ctx* ctx, const float* a, const float* b, int64_t n, double* dots) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !a || !b || !dots || n < 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_dot3: bad argument");
     // partial sums live after the 3 results: caller provides 3 + 3*1024 doubles
     const unsigned nb = std::min<unsigned>(grid_for(n, 8), 1024u);
@@ -252,6 +266,7 @@ extern "C" int alsep_dot3(alsep_ctx* ctx, const float* a, const float* b, int64_
 }
 
 extern "C" int alsep_xcorr_window(alsep_ctx* ctx, const float* ref, const float* sig, int64_t probe, int max_shift, double* corr) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !ref || !sig || !corr || probe <= 0 || max_shift < 0 || max_shift >= probe)
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_xcorr_window: bad argument");
     hipLaunchKernelGGL(xcorr_window_kernel, dim3(2 * max_shift + 1), dim3(kThreads), 4 * sizeof(double), ctx->stream,
@@ -261,6 +276,7 @@ extern "C" int alsep_xcorr_window(alsep_ctx* ctx, const float* ref, const float*
 }
 
 extern "C" int alsep_shift_subtract(alsep_ctx* ctx, const float* ref, const float* sig, int64_t len, int lag, float alpha, float* out) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !ref || !sig || !out || len < 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_shift_subtract: bad argument");
     if (len == 0) return ALSEP_OK;
     hipLaunchKernelGGL(shift_subtract_kernel, dim3(grid_for(len, 4)), dim3(kThreads), 0, ctx->stream, ref, sig, len, lag, alpha, out);
@@ -271,6 +287,7 @@ extern "C" int alsep_shift_subtract(alsep_ctx* ctx, const float* ref, const floa
 extern "C" int alsep_ola_combine(alsep_ctx* ctx, const float* chunks, int64_t n_chunks, int64_t chunk, int64_t step,
                                  int64_t total, int use_window, float gain, float* out, int64_t out_stride, int64_t p_lo,
                                  int64_t n_out) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !chunks || !out || n_chunks <= 0 || chunk <= 0 || step <= 0 || step > chunk || total <= 0 || p_lo < 0 ||
         n_out < 0 || p_lo + n_out > total || (n_chunks - 1) * step >= total)
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_ola_combine: bad argument");
@@ -283,6 +300,7 @@ extern "C" int alsep_ola_combine(alsep_ctx* ctx, const float* chunks, int64_t n_
 
 extern "C" int alsep_zero_low_bins(alsep_ctx* ctx, void* spec, int dtype, int layout, int64_t B, int64_t dim_f, int64_t T,
                                    int nbins) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !spec || B < 0 || nbins < 0 || nbins > dim_f || (dtype != ALSEP_F32 && dtype != ALSEP_BF16))
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_zero_low_bins: bad argument");
     if (B == 0 || nbins == 0) return ALSEP_OK;

@@ -505,6 +505,7 @@ extern "C" int alsep_plan_supported_nfft(int n_fft) {
 }
 
 extern "C" int alsep_plan_create(alsep_ctx* ctx, int n_fft, int hop, int dim_f, int dim_t, alsep_plan** out) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !out) return ALSEP_ERR_ARG;
     if (!alsep_plan_supported_nfft(n_fft)) return alsep_fail(ctx, ALSEP_ERR_ARG, "n_fft=%d has no FFT kernel", n_fft);
     if (hop <= 0 || hop > n_fft || dim_t < 2 || dim_f < 1 || dim_f > n_fft / 2 + 1)
@@ -540,9 +541,12 @@ extern "C" int alsep_plan_create(alsep_ctx* ctx, int n_fft, int hop, int dim_f, 
         return alsep_fail(ctx, ALSEP_ERR_NOMEM, "plan tables: hipMalloc failed");
     }
     // blocking copies on purpose: the host vectors die at return
-    ALSEP_HIP(ctx, hipMemcpy(p->tw, tw.data(), sizeof(float2) * n_fft, hipMemcpyHostToDevice));
-    ALSEP_HIP(ctx, hipMemcpy(p->win, win.data(), sizeof(float) * n_fft, hipMemcpyHostToDevice));
-    ALSEP_HIP(ctx, hipMemcpy(p->env, env.data(), sizeof(float) * p->env_len, hipMemcpyHostToDevice));
+    if (hipMemcpy(p->tw, tw.data(), sizeof(float2) * n_fft, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->win, win.data(), sizeof(float) * n_fft, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->env, env.data(), sizeof(float) * p->env_len, hipMemcpyHostToDevice) != hipSuccess) {
+        alsep_plan_destroy(p);
+        return alsep_fail(ctx, ALSEP_ERR_HIP, "plan tables: hipMemcpy failed");
+    }
     *out = p;
     return ALSEP_OK;
 }
@@ -576,12 +580,12 @@ static int device_cu_count(alsep_ctx* ctx) {
     (void)ctx;
     return 256;
 #else
-    static const int n = [ctx] {
+    if (ctx->cu_count <= 0) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
-    return n;
+        ctx->cu_count = v;
+    }
+    return ctx->cu_count;
 #endif
 }
 
@@ -629,6 +633,7 @@ static int launch_stft(alsep_ctx* ctx, const alsep_plan* p, const float* pcm, in
 
 extern "C" int alsep_stft(alsep_ctx* ctx, const alsep_plan* plan, const float* pcm, int64_t ch_stride,
                           int64_t chunk_stride, int64_t n_chunks, void* spec, int dtype, int layout) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !plan || !pcm || !spec) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_stft: null argument");
     if (n_chunks == 0) return ALSEP_OK;
     if (n_chunks < 0 || (dtype != ALSEP_F32 && dtype != ALSEP_BF16) ||
@@ -723,6 +728,7 @@ static int launch_istft(alsep_ctx* ctx, const alsep_plan* p, const void* spec, i
 extern "C" int alsep_istft(alsep_ctx* ctx, const alsep_plan* plan, const void* spec, int dtype, int layout,
                            int64_t n_chunks, float* out, int64_t out_ch_stride, int64_t out_chunk_stride,
                            int64_t keep_lo, int64_t keep_hi, int64_t out_limit) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !plan || !spec || !out) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_istft: null argument");
     if (n_chunks == 0) return ALSEP_OK;
     if (n_chunks < 0 || keep_lo < 0 || keep_hi > plan->chunk || keep_lo >= keep_hi || out_limit <= 0 ||
@@ -745,6 +751,7 @@ extern "C" int alsep_istft(alsep_ctx* ctx, const alsep_plan* plan, const void* s
 
 extern "C" int alsep_spec_convert(alsep_ctx* ctx, const void* src, void* dst, int dtype, int src_layout,
                                   int64_t B, int64_t dim_f, int64_t T) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !src || !dst) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_spec_convert: null argument");
     if (B == 0) return ALSEP_OK;
     if (B < 0 || B > 65535 || dim_f <= 0 || T <= 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_spec_convert: bad shape");

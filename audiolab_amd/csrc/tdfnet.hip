@@ -2203,6 +2203,7 @@ int launch_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
                        dim3(kThreads), Cf::lds_bytes,
                        ctx->stream, X, Y, (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page,
                        Th, Fw, L.cin, L.cout, tiles_t, tiles_f, (int)ntiles, conv_ablate(), conv_stagger(), ny_fastest);
+    note_launch(ctx, TW == 64 ? "conv3x3_bf16_kernel<64>" : "conv3x3_bf16_kernel<small>");
     ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_kernel");
     return ALSEP_OK;
 }
@@ -2259,6 +2260,7 @@ int launch_conv_big(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     hipLaunchKernelGGL((conv3x3_bf16_big_kernel<NY>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
                        (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
                        L.cout, tiles_t, tiles_f, (int)ntiles);
+    note_launch(ctx, NY == 3 ? "conv3x3_bf16_big_kernel<3>" : "conv3x3_bf16_big_kernel<2>");
     ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_big_kernel");
     return ALSEP_OK;
 }
@@ -2363,6 +2365,7 @@ int run_pix_stream(alsep_ctx* ctx, int mode, const GemmLayer& L, const bf16_t* X
         else ALSEP_US(192, 144, 2, 1, 256)                       // 192 -> 144: 32-pixel tiles (accumulators beside 54 fragments)
 #undef ALSEP_US
     }
+    note_launch(ctx, mode == PIX_DS ? "ds_stream_kernel" : "us_stream_kernel");
     ALSEP_LAUNCH_CHECK(ctx, "pix stream kernel");
     return ALSEP_OK;
 }
@@ -2421,6 +2424,7 @@ int launch_tdf_wide(alsep_ctx* ctx, const GemmLayer& L, const bf16_t* X, bf16_t*
                            (const bf16_t*)L.wwide.p, bias, (const float*)L.scale.p, (const float*)L.shift.p, R, L.M, L.K,
                            nunits, C, nyb);
     }
+    note_launch(ctx, R ? "tdf_bf16_wide_kernel<res>" : "tdf_bf16_wide_kernel<nores>");
     ALSEP_LAUNCH_CHECK(ctx, "tdf_bf16_wide_kernel");
     return ALSEP_OK;
 }
@@ -2510,7 +2514,7 @@ WsLayout ws_layout(const alsep_net* net, int64_t B) {
     w.p0 = off; off += s0;
     w.p1 = off; off += s0;
     w.p2 = off; off += s0;
-    w.h = off;  off += align256(cfg.bn > 1 ? s0 / cfg.bn : 16);
+    w.h = off;  off += align256(cfg.bn > 0 ? s0 / cfg.bn : 16);
     int c = cfg.g;
     size_t t = cfg.dim_t, f = cfg.dim_f;
     for (int i = 0; i < net->n; ++i) {
@@ -2578,6 +2582,7 @@ int forward_impl(alsep_ctx* ctx, const alsep_net* net, const T* in, T* out, int6
 
 extern "C" int alsep_net_create(alsep_ctx* ctx, const alsep_net_config* cfg, const alsep_tensor* tensors,
                                 int64_t n_tensors, alsep_net** out) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !cfg || !tensors || !out) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_create: null argument");
     const int n = cfg->num_blocks / 2;
     if (cfg->num_blocks < 1 || cfg->l < 1 || cfg->g < 16 || cfg->g % 16 != 0 || cfg->bn < 0 ||
@@ -2626,6 +2631,7 @@ extern "C" int64_t alsep_net_workspace_bytes(const alsep_net* net, int64_t B) {
 extern "C" int alsep_net_forward(alsep_ctx* ctx, const alsep_net* net, const void* spec_in, void* spec_out,
                                  int64_t B, void* workspace, int64_t workspace_bytes, float in_scale,
                                  float out_alpha, float out_beta) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !net || !spec_in || !spec_out || !workspace) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_forward: null argument");
     if (B == 0) return ALSEP_OK;
     if (B < 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_forward: negative batch");

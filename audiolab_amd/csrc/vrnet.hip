@@ -219,6 +219,7 @@ vr_lstm_kernel(const float* __restrict__ pre, const float* __restrict__ whh, flo
 
 extern "C" int alsep_vr_lstm(alsep_ctx* ctx, const float* pre, const float* whh, float* out, int T, int N, int hidden,
                              int out_stride, int out_off, int reverse) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !pre || !whh || !out) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_lstm: null argument");
     if (T <= 0 || N <= 0 || out_off < 0 || out_off + hidden > out_stride)
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_lstm: bad shape");
@@ -240,6 +241,7 @@ extern "C" int alsep_vr_lstm(alsep_ctx* ctx, const float* pre, const float* whh,
 extern "C" int alsep_vr_conv2d(alsep_ctx* ctx, const float* x, const float* w, const float* scale, const float* shift, float* y,
                                int64_t B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,
                                int dil_h, int dil_w, int act, int y_ctotal, int y_coff) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !x || !w || !scale || !shift || !y) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_conv2d: null argument");
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad_h < 0 || pad_w < 0 ||
         dil_h <= 0 || dil_w <= 0 || act < 0 || act > 2 || y_coff < 0 || y_coff + Cout > y_ctotal)
@@ -257,6 +259,7 @@ extern "C" int alsep_vr_conv2d(alsep_ctx* ctx, const float* x, const float* w, c
 
 extern "C" int alsep_vr_depthwise(alsep_ctx* ctx, const float* x, const float* w, float* y, int64_t B, int H, int W, int C,
                                   int KH, int KW, int pad, int dil) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !x || !w || !y) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_depthwise: null argument");
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || KH <= 0 || KW <= 0 || pad < 0 || dil <= 0 || 2 * pad != dil * (KH - 1) ||
         2 * pad != dil * (KW - 1))
@@ -270,6 +273,7 @@ extern "C" int alsep_vr_depthwise(alsep_ctx* ctx, const float* x, const float* w
 
 extern "C" int alsep_vr_resize_bilinear(alsep_ctx* ctx, const float* x, float* y, int64_t B, int H, int W, int C, int Ho, int Wo,
                                         int y_ctotal, int y_coff) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !x || !y) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_resize_bilinear: null argument");
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || y_coff < 0 || y_coff + C > y_ctotal)
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_resize_bilinear: bad shape");
@@ -282,6 +286,7 @@ extern "C" int alsep_vr_resize_bilinear(alsep_ctx* ctx, const float* x, float* y
 
 extern "C" int alsep_vr_copy_slice(alsep_ctx* ctx, const float* x, float* y, int64_t BH, int Wx, int C, int w_off, int Wy,
                                    int y_ctotal, int y_coff) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !x || !y) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_copy_slice: null argument");
     if (BH <= 0 || Wx <= 0 || C <= 0 || Wy <= 0 || w_off < 0 || w_off + Wy > Wx || y_coff < 0 || y_coff + C > y_ctotal)
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_copy_slice: bad shape");
@@ -293,6 +298,7 @@ extern "C" int alsep_vr_copy_slice(alsep_ctx* ctx, const float* x, float* y, int
 }
 
 extern "C" int alsep_vr_mean_h(alsep_ctx* ctx, const float* x, float* y, int64_t B, int H, int W, int C) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !x || !y) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_mean_h: null argument");
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_mean_h: bad shape");
     const int64_t n = B * W * C;
@@ -304,6 +310,7 @@ extern "C" int alsep_vr_mean_h(alsep_ctx* ctx, const float* x, float* y, int64_t
 
 extern "C" int alsep_vr_mask(alsep_ctx* ctx, const float* logit, const float* mix, float* out, int64_t B, int Hm, int Hout, int W,
                              int C, int split_bin, float aggressiveness) {
+    ALSEP_ENTER(ctx);
     if (!ctx || !logit || !mix || !out) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_mask: null argument");
     if (B <= 0 || Hm <= 0 || Hout < Hm || W <= 0 || C <= 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_mask: bad shape");
     const int64_t n = B * Hout * W * C;

@@ -41,19 +41,36 @@ from .tdfnet import TDFNet, TDFNetConfig
 
 logger = logging.getLogger(__name__)
 
-# name -> (primary stem label, secondary stem label or None, TDFNetConfig)
-_VOC = TDFNetConfig(dim_f=3072, dim_t=256, n_fft=7680, g=48)
-_K6144 = TDFNetConfig(dim_f=3072, dim_t=256, n_fft=6144, g=48)
+# name -> (primary stem label, secondary stem label or None, TDFNetConfig[, {"compensate": c}])
+#
+# PROVENANCE of the geometry below: the model files are downloaded at run time by the reference
+# (stem_separator.py:109-124) and are not in /root/reference; n_fft / dim_f / dim_t / compensate per file are the
+# values of the public UVR ``model_data.json`` / KUIELab mdx-net-submission tables as recalled by the builder
+# (upstream, uncited -- PARITY UNPINNED).  What a real ``.onnx`` file itself fixes (dim_f, dim_t, L, g, l, bn) is
+# read from its graph and OVERRIDES this table (onnx_reader.py); only n_fft / hop / compensate / the stem labels
+# cannot be recovered from the file and come from here (or from the caller: ``load_model(..., n_fft=)``,
+# ``patched_load_model`` passes MDXSeparator's own ``n_fft`` / ``hop_length``).
+def _cfg(n_fft: int, dim_f: int, dim_t: int) -> TDFNetConfig:
+    return TDFNetConfig(dim_f=dim_f, dim_t=dim_t, n_fft=n_fft, g=48)
+
+
 MODEL_ROSTER: Dict[str, tuple] = {
-    "UVR-MDX-NET-Voc_FT.onnx": ("Vocals", "Instrumental", _VOC),
-    "Kim_Vocal_2.onnx": ("Vocals", "Instrumental", _VOC),
-    "Kim_Vocal_1.onnx": ("Vocals", "Instrumental", _VOC),
-    "UVR-MDX-NET_Crowd_HQ_1.onnx": ("No Crowd", "Crowd", _K6144),
-    "kuielab_a_vocals.onnx": ("Vocals", "Instrumental", _K6144),
-    "kuielab_a_drums.onnx": ("Drums", "No Drums", _K6144),
-    "kuielab_a_bass.onnx": ("Bass", "No Bass", _K6144),
-    "kuielab_a_other.onnx": ("Other", "No Other", _K6144),
+    # UVR MDX-Net vocal models (ensemble slots 5-7, stem_separator.py:384-386): n_fft 7680, dim_f 3072, dim_t 2**8
+    "UVR-MDX-NET-Voc_FT.onnx": ("Vocals", "Instrumental", _cfg(7680, 3072, 256), {"compensate": 1.021}),
+    "Kim_Vocal_2.onnx": ("Vocals", "Instrumental", _cfg(7680, 3072, 256), {"compensate": 1.009}),
+    "Kim_Vocal_1.onnx": ("Vocals", "Instrumental", _cfg(7680, 3072, 256), {"compensate": 1.043}),
+    # crowd removal (wrappers/separate.py:131-137, stem_separator.py:798): n_fft 5120, dim_f 2560
+    "UVR-MDX-NET_Crowd_HQ_1.onnx": ("No Crowd", "Crowd", _cfg(5120, 2560, 256), {"compensate": 1.035}),
+    # KUIELab MDX-Net "a" set (stem_separator.py:512 uses the bass one): dim_f 2048 everywhere, n_fft per target
+    "kuielab_a_vocals.onnx": ("Vocals", "Instrumental", _cfg(6144, 2048, 256), {"compensate": 1.035}),
+    "kuielab_a_drums.onnx": ("Drums", "No Drums", _cfg(4096, 2048, 128), {"compensate": 1.035}),
+    "kuielab_a_bass.onnx": ("Bass", "No Bass", _cfg(16384, 2048, 512), {"compensate": 1.035}),
+    "kuielab_a_other.onnx": ("Other", "No Other", _cfg(8192, 2048, 512), {"compensate": 1.035}),
 }
+# BASELINE configs[1] "MDX-Net UVR 4-stem": four single-target networks of the in-tree geometry (mdxnet.py:247-251:
+# dim_f 3072, n_fft 6144) -- the bench workload; never reached by a file name of the reference
+_BENCH = _cfg(6144, 3072, 256)
+BENCH_ROSTER: Dict[str, tuple] = {f"bench_4stem_{t.lower()}.onnx": (t, f"No {t}", _BENCH) for t in ("Vocals", "Drums", "Bass", "Other")}
 FOUR_STEM_SET = ("kuielab_a_vocals.onnx", "kuielab_a_drums.onnx", "kuielab_a_bass.onnx", "kuielab_a_other.onnx")
 
 
@@ -76,7 +93,10 @@ class Separator:
                  invert_using_spec: bool = True, use_autocast: bool = True, ctx: Optional[Context] = None,
                  dtype: Optional[torch.dtype] = None, sample_rate: int = 44100, chunks: int = 0, margin: int = 44100,
                  denoise: bool = False, max_batch: int = 8, sharded: bool = False, roster: Optional[Dict[str, tuple]] = None,
-                 chunker: str = "margin", overlap: float = 0.25, compensate: float = 1.0, **_ignored):
+                 chunker: str = "margin", overlap: float = 0.25, compensate: Optional[float] = None,
+                 allow_synthetic: bool = False, **_ignored):
+        """``allow_synthetic=True`` (bench, tests): a roster name without a weight file gets seeded random-init weights.
+        The default refuses to: a missing model file is an error, never plausible-looking noise."""
         self.log_level = log_level
         self.model_file_dir = model_file_dir
         self.output_dir = output_dir
@@ -93,6 +113,7 @@ class Separator:
         if chunker not in ("margin", "ola"):
             raise AlsepError("chunker must be 'margin' (in-tree runner, pinned) or 'ola' (audio-separator style, unpinned)")
         self.chunker, self.overlap, self.compensate = chunker, overlap, compensate
+        self.allow_synthetic = bool(allow_synthetic)
         self.model_instance: Optional[_ModelInstance] = None
         self._cache: Dict[str, _ModelInstance] = {}
 
@@ -106,9 +127,14 @@ class Separator:
         p = os.path.join(self.model_file_dir, model_filename)
         return p if model_filename.lower().endswith(".onnx") and os.path.isfile(p) else None
 
-    def load_model(self, model_filename: str) -> None:
+    def weights_provenance(self) -> str:
+        """"real" / "synthetic" for the loaded model (goes into the Separate cache key)."""
+        return getattr(self.model_instance, "weights", "none") if self.model_instance else "none"
+
+    def load_model(self, model_filename: str, n_fft: Optional[int] = None, hop: Optional[int] = None) -> None:
         """Weights stay resident per model name: the reference reloads per ensemble member
-        (stem_separator.py:394); here a second load_model of the same name is a dictionary hit."""
+        (stem_separator.py:394); here a second load_model of the same name is a dictionary hit.
+        ``n_fft`` / ``hop`` override the roster's values (they are not in an .onnx file)."""
         if model_filename in self._cache:
             self.model_instance = self._cache[model_filename]
             self.model_instance.output_dir = self.output_dir
@@ -119,6 +145,9 @@ class Separator:
         if model_filename not in self.roster:
             raise AlsepError(f"model '{model_filename}' is not available in this build (MDX-Net roster: {sorted(self.roster)})")
         entry = self.roster[model_filename]
+        meta = entry[3] if len(entry) > 3 and entry[0] != "multi" else {}
+        entry = entry[:3]
+        provenance = []
         if entry[0] == "multi":                                 # ("multi", [(label, cfg), ...]): one network per stem
             stems = [(label, None, cfg) for label, cfg in entry[1]]
         else:
@@ -128,25 +157,34 @@ class Separator:
             pt = os.path.join(self.model_file_dir, tag + ".pt")
             if onnx_path and tag == model_filename:
                 from .onnx_reader import load_mdx_onnx
-                m = load_mdx_onnx(onnx_path, n_fft=cfg.n_fft if cfg else None, hop=cfg.hop if cfg else 1024)
+                m = load_mdx_onnx(onnx_path, n_fft=n_fft or (cfg.n_fft if cfg else None), hop=hop or (cfg.hop if cfg else 1024))
                 if cfg is not None and (m.config.dim_f, m.config.dim_t) != (cfg.dim_f, cfg.dim_t):
                     logger.warning("%s: the file holds dim_f=%d dim_t=%d, the roster says %d / %d; using the file's", model_filename,
                                    m.config.dim_f, m.config.dim_t, cfg.dim_f, cfg.dim_t)
                 cfg, sd = m.config, m.state_dict
+                provenance.append("real")
             elif cfg is None:
                 raise AlsepError(f"model '{model_filename}': no geometry in the roster and no model file")
             elif os.path.exists(pt):
-                sd = torch.load(pt, map_location="cpu")
-            else:
+                sd = torch.load(pt, map_location="cpu", weights_only=True)
+                provenance.append("real")
+            elif self.allow_synthetic:
                 seed = int.from_bytes(hashlib.sha256(tag.encode()).digest()[:4], "little")
                 sd = synthetic_state_dict(cfg, seed=seed)
+                logger.warning("%s: no weight file under %s -- SYNTHETIC random-init weights (allow_synthetic=True)", tag,
+                               self.model_file_dir)
+                provenance.append("synthetic")
+            else:
+                raise AlsepError(f"model '{model_filename}': no weight file ({os.path.join(self.model_file_dir, model_filename)} "
+                                 f"or {pt}); random-init weights are only used with Separator(allow_synthetic=True)")
             net = TDFNet(cfg, sd, ctx=self.ctx, dtype=self.dtype, max_batch=self.max_batch)
             dim_t_arg = int(cfg.dim_t).bit_length() - 1
             args = types.SimpleNamespace(margin=self.margin, chunks=self.chunks, denoise=self.denoise, dim_f=cfg.dim_f,
                                          dim_t=dim_t_arg, n_fft=cfg.n_fft)
             if self.chunker == "ola":
                 from .mdx import OlaRunner
-                pred = OlaRunner(net, ctx=self.ctx, overlap=self.overlap, compensate=self.compensate, denoise=self.denoise,
+                comp = self.compensate if self.compensate is not None else float(meta.get("compensate", 1.0))
+                pred = OlaRunner(net, ctx=self.ctx, overlap=self.overlap, compensate=comp, denoise=self.denoise,
                                  max_batch=self.max_batch)
             else:
                 pred = Predictor(args, net, ctx=self.ctx, hop=cfg.hop, sharded=self.sharded)
@@ -159,6 +197,7 @@ class Separator:
             net_i, pred_i = build(f"{model_filename}#{label}", cfg_i)
             inst.extra.append((label, net_i, pred_i))
         inst.output_dir = self.output_dir
+        inst.weights = "synthetic" if "synthetic" in provenance else "real"
         self._cache[model_filename] = inst
         self.model_instance = inst
 

@@ -207,7 +207,7 @@ class TDFNet:
     def run(self, _names, feed):
         """ORT-session surface (mdxnet.py:170-176, patch_separate.py:52): reference layout in/out."""
         from .mdx import StftPlan
-        spek = feed["input"]
+        spek = torch.as_tensor(feed["input"]).to(self.ctx.device)    # ORT sessions are fed host arrays (mdxnet.py:170-176)
         plan = self._plan()
         x = plan.convert(spek.contiguous().to(self.dtype), _lib.LAYOUT_REF)
         y = self.forward_nhwc(x)

@@ -27,7 +27,11 @@ def read_wav(path: str) -> Tuple[np.ndarray, int]:
         cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
         body = data[pos + 8:pos + 8 + size]
         if cid == b"fmt ":
+            if len(body) < 16:
+                raise ValueError(f"{path}: fmt chunk of {len(body)} bytes (need 16)")
             tag, ch, sr, _, _, bits = struct.unpack("<HHIIHH", body[:16])
+            if ch == 0 or sr == 0:
+                raise ValueError(f"{path}: fmt chunk declares {ch} channels at {sr} Hz")
             if tag == WAVE_FORMAT_EXTENSIBLE and len(body) >= 26:
                 tag = struct.unpack("<H", body[24:26])[0]
             fmt = (tag, ch, sr, bits)

@@ -102,6 +102,11 @@ class Separate(BaseWrapper):
                 "crowd_removal_model": g("crowd_removal_model", "UVR-MDX-NET_Crowd_HQ_1.onnx"),
                 "store_reverb_ir": g("store_reverb_ir", True),
             }
+            eng = self.engine_options.get("separator")
+            if eng is not None and getattr(eng, "allow_synthetic", False):
+                # stems made from random-init weights (bench / tests) must never satisfy a later run with real models;
+                # with real weights the key is exactly the reference's (:274-291)
+                current_config["weights"] = "synthetic-allowed"
             valid_cache = False
             if os.path.exists(cache_file):                                                        # :293-313
                 try:

@@ -71,6 +71,11 @@ enum {
 };
 int alsep_profile_begin(alsep_ctx* ctx, int category);
 int alsep_profile_end(alsep_ctx* ctx, double* total_ms, int64_t* launches);
+/* Launches of one kernel since alsep_create / alsep_launch_counts_reset, by the name the launch site reports
+ * ("conv3x3_bf16_big_kernel<2>", "conv3x3_bf16_regw_kernel", "tdf_bf16_wide_kernel<res>", "us_stream_kernel",
+ * "istft_r16_kernel" ...): lets a parity test prove WHICH kernel produced the result it checked.  -1 on a null argument. */
+int64_t alsep_launch_count(const alsep_ctx* ctx, const char* kernel);
+int alsep_launch_counts_reset(alsep_ctx* ctx);
 
 /* STFT plan: geometry of ConvTDFNetTrim.__init__ (modules/rvc/infer/modules/uvr5/mdxnet.py:15-39).
  * dim_t is the frame count (2**dim_t_arg).  chunk = hop*(dim_t-1). */

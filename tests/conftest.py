@@ -58,3 +58,38 @@ def emul(emul_lib_path, monkeypatch):
     ctx = _lib.Context("cpu")
     yield ctx
     ctx.close()
+
+
+# ------------------------------------------------------------------------------------------
+# ``dev``: the same test body on the CPU emulation (-m "not gpu") and on the real GPU (-m gpu).
+# The pinned comparisons (golden vectors of the reference, oracle compositions) are therefore
+# executed by the HIP kernels themselves on the GPU box, not only by their host emulation.
+# ------------------------------------------------------------------------------------------
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    import torch
+    from audiolab_amd import _lib
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return _lib.Context("cuda:0")
+
+
+@pytest.fixture(params=["emul", pytest.param("gpu", marks=pytest.mark.gpu)])
+def dev(request):
+    """A Context: the emulated kernels on CPU tensors, or libalsep.so on cuda:0."""
+    if request.param == "emul":
+        return request.getfixturevalue("emul")
+    return request.getfixturevalue("gpu_ctx")
+
+
+def on(ctx, a):
+    """numpy array / tensor -> tensor on the context's device."""
+    import numpy as np
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+    return t.to(ctx.device)
+
+
+def host(t):
+    """device tensor -> numpy"""
+    return t.detach().cpu().numpy()

@@ -1,4 +1,4 @@
-"""CPU (-m "not gpu"): the whole Separate path end to end -- Separate.process_audio -> separate_music ->
+"""Emulated kernels (-m "not gpu") and GPU (-m gpu), same bodies: the whole Separate path end to end -- Separate.process_audio -> separate_music ->
 ensemble of MDX models -> blend -> de-bleed -> multistem -> alt bass -> float32 WAV stems -- with
 tiny networks on the emulated kernels, against the same pipeline composed from the oracle pieces."""
 import os
@@ -11,6 +11,7 @@ from oracle import ensemble_oracle as eo
 from oracle import mdx_oracle as mo
 from oracle import tdfnet_oracle
 from oracle.toy import synth_mix
+from tests.conftest import host, on
 
 
 def tiny_roster():
@@ -35,7 +36,7 @@ def oracle_model(name, roster, mix):
     return mo.demix(mix, g, run, chunks=0, margin=44100, dtype=np.float32)[0]
 
 
-def test_separate_end_to_end_vs_oracle(emul, tmp_path, monkeypatch):
+def test_separate_end_to_end_vs_oracle(dev, tmp_path, monkeypatch):
     from audiolab_amd import wavio
     from audiolab_amd.engine import Separator
     from audiolab_amd.handlers import config
@@ -48,7 +49,7 @@ def test_separate_end_to_end_vs_oracle(emul, tmp_path, monkeypatch):
     mix = synth_mix(n, seed=21)
     src = tmp_path / "song.wav"
     wavio.write_wav(str(src), mix, 44100)
-    eng = Separator(ctx=emul, use_autocast=False, roster=roster, max_batch=2)
+    eng = Separator(ctx=dev, use_autocast=False, allow_synthetic=True, roster=roster, max_batch=2)
     wrapper = Separate()
     monkeypatch.setattr(Separate, "engine_options", {"separator": eng, "ensemble_strength": 2})
     ticks = []
@@ -73,9 +74,18 @@ def test_separate_end_to_end_vs_oracle(emul, tmp_path, monkeypatch):
         assert stems[k].shape == (2, n)
         err = float(np.max(np.abs(stems[k] - want[k])))
         assert err < 1e-4, f"{k}: {err:.3e}"
+    # second call, same options: served from stems/separation_info.json (wrappers/separate.py:293-313), no model runs
+    calls = []
+    real = eng.separate_array
+    monkeypatch.setattr(eng, "separate_array", lambda m: calls.append(1) or real(m))
+    again = wrapper.process_audio([ProjectFiles(str(src))], vocals_only=False, alt_bass_model=True, separate_bg_vocals=False)
+    assert not calls and sorted(again[0].last_outputs) == sorted(out[0].last_outputs)
+    # a changed option misses the cache
+    wrapper.process_audio([ProjectFiles(str(src))], vocals_only=True, separate_bg_vocals=False)
+    assert calls
 
 
-def test_multichannel_ola_075_vs_oracle(emul):
+def test_multichannel_ola_075_vs_oracle(dev):
     """BASELINE configs[4] in miniature: multichannel input as stereo pairs (3 channels: one pair and an odd last channel), Hann overlap-add
     chunker at overlap 0.75, against the oracle run on every pair."""
     from audiolab_amd.engine import Separator
@@ -90,7 +100,7 @@ def test_multichannel_ola_075_vs_oracle(emul):
 
     def run(spek):
         return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)), cfg.num_blocks, cfg.l, cfg.bn).numpy()
-    eng = Separator(ctx=emul, use_autocast=False, roster=roster, max_batch=3, chunker="ola", overlap=0.75, compensate=1.02)
+    eng = Separator(ctx=dev, use_autocast=False, allow_synthetic=True, roster=roster, max_batch=3, chunker="ola", overlap=0.75, compensate=1.02)
     eng.load_model(name)
     n = 3000
     for channels in (3,):
@@ -101,5 +111,5 @@ def test_multichannel_ola_075_vs_oracle(emul):
             pair = mix[c0:c0 + 2] if c0 + 2 <= channels else np.concatenate([mix[c0:c0 + 1]] * 2)
             want = mo.demix_ola(pair, g, run, overlap=0.75, denoise=False, zero_low_bins=3, compensate=1.02)
             k = min(2, channels - c0)
-            assert np.max(np.abs(out["Drums"][c0:c0 + k].numpy() - want[:k])) < 1e-4
-            assert np.max(np.abs(out["No Drums"][c0:c0 + k].numpy() - (pair - want)[:k])) < 1e-4
+            assert np.max(np.abs(host(out["Drums"][c0:c0 + k]) - want[:k])) < 1e-4
+            assert np.max(np.abs(host(out["No Drums"][c0:c0 + k]) - (pair - want)[:k])) < 1e-4

@@ -200,38 +200,100 @@ def test_net_from_onnx_file_vs_torch_reference(ctx, tmp_path):
 
 
 def test_net_bf16_vs_torch_reference(ctx):
-    for nb, tol in ((1, 2e-2), (3, 6e-2), (7, 0.5)):
+    """bf16 storage + fp32 accumulation against the fp32 oracle on the SAME bf16-rounded input: the error is the rounding of the
+    stored activations (2^-9 relative each) accumulated over the layers -- measured 0.7 % (1 block) ... 2.1 % (7 blocks)."""
+    for nb, tol in ((1, 1.5e-2), (3, 3e-2), (7, 5e-2)):
         got, want, *_ = _net_case(ctx, dict(dim_f=256, dim_t=32, n_fft=512, hop=128, num_blocks=nb, g=48), torch.bfloat16, 2)
         rel = float((got - want).norm() / want.norm())
         print(f"bf16 num_blocks={nb}: rel L2 {rel:.3e}")
         assert rel < tol
 
 
-def test_full_size_mdx_f32_vs_oracle(ctx):
-    """The bench architecture (L=11, g=48, dim_f 3072, dim_t 256, n_fft 6144) in fp32 on ~9 s of
-    audio (2 model windows) against the CPU oracle end to end: |delta| < 1e-4 PCM (north_star)."""
-    from audiolab_amd.mdx import Predictor
-    from audiolab_amd.synth import synth_mix, synthetic_state_dict
-    from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
-    from oracle import mdx_oracle, tdfnet_oracle
-    cfg = TDFNetConfig()
-    sd = synthetic_state_dict(cfg, seed=0)
-    net = TDFNet(cfg, sd, ctx=ctx, dtype=torch.float32, max_batch=2)
-    n = 400000
-    mix = synth_mix(n)
-    args = types.SimpleNamespace(margin=44100, chunks=0, denoise=False, dim_f=cfg.dim_f, dim_t=8, n_fft=cfg.n_fft)
-    got = Predictor(args, net, ctx=ctx).demix(torch.from_numpy(mix).cuda()).cpu().numpy()
+@pytest.mark.parametrize("g,kernel", [(96, "conv3x3_bf16_big_kernel<2>"), (144, "conv3x3_bf16_big_kernel<3>"),
+                                      (48, "conv3x3_bf16_regw_kernel")])
+def test_big_tile_conv_kernels_vs_oracle(ctx, g, kernel):
+    """Per-kernel oracle check of the production 3x3 kernels at shapes that DISPATCH them (not variant-vs-variant): a
+    one-block network (first 1x1 conv, three c -> c 3x3 convs, TDF, final 1x1) with c = 96 / 144 / 48 channels, so
+    every 3x3 launch is the 8-wave big-tile kernel (NY = 2 / 3) resp. the persistent register-weight kernel -- asserted
+    through alsep_launch_count -- against the torch fp32 oracle on the same bf16-rounded input."""
+    kw = dict(dim_f=512, dim_t=64, n_fft=1024, hop=256, num_blocks=1, g=g)
+    ctx.launch_counts_reset()
+    got, want, *_ = _net_case(ctx, kw, torch.bfloat16, 2)      # one forward of B = 2: 128 8x64 tiles (>= 96: the big-tile dispatch rule)
+    assert ctx.launch_count(kernel) == 3, {k: ctx.launch_count(k) for k in (kernel, "conv3x3_bf16_kernel<64>")}
+    assert ctx.launch_count("conv3x3_bf16_kernel<64>") == 0 and ctx.launch_count("conv3x3_bf16_kernel<small>") == 0
+    rel = float((got - want).norm() / want.norm())
+    err = float((got - want).abs().max() / want.abs().max())
+    print(f"{kernel} g={g}: rel L2 {rel:.3e}, max rel {err:.3e}")
+    assert rel < 1.5e-2 and err < 6e-2
 
-    def model_run(spek):
-        with torch.no_grad():
-            return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)),
-                                         cfg.num_blocks, cfg.l, cfg.bn).numpy()
-    g = mdx_oracle.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
-    want = mdx_oracle.demix(mix, g, model_run, chunks=0, margin=44100, dtype=np.float32)
+
+_FULL = {}
+
+
+def _full_size_case():
+    """bench architecture (L=11, g=48, dim_f 3072, dim_t 256, n_fft 6144) on ~9 s of audio (2 model windows): the oracle's
+    stems, computed once for the fp32 and the bf16 test"""
+    if not _FULL:
+        from audiolab_amd.synth import synth_mix, synthetic_state_dict
+        from audiolab_amd.tdfnet import TDFNetConfig
+        from oracle import mdx_oracle, tdfnet_oracle
+        cfg = TDFNetConfig()
+        sd = synthetic_state_dict(cfg, seed=0)
+        mix = synth_mix(400000)
+
+        def model_run(spek):
+            with torch.no_grad():
+                return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)),
+                                             cfg.num_blocks, cfg.l, cfg.bn).numpy()
+        g = mdx_oracle.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
+        _FULL.update(cfg=cfg, sd=sd, mix=mix, want=mdx_oracle.demix(mix, g, model_run, chunks=0, margin=44100, dtype=np.float32))
+    return _FULL
+
+
+def test_full_size_mdx_f32_vs_oracle(ctx):
+    """The bench architecture in fp32 against the CPU oracle end to end: |delta| < 1e-4 PCM (north_star)."""
+    from audiolab_amd.mdx import Predictor
+    from audiolab_amd.tdfnet import TDFNet
+    c = _full_size_case()
+    cfg, want = c["cfg"], c["want"]
+    net = TDFNet(cfg, c["sd"], ctx=ctx, dtype=torch.float32, max_batch=2)
+    args = types.SimpleNamespace(margin=44100, chunks=0, denoise=False, dim_f=cfg.dim_f, dim_t=8, n_fft=cfg.n_fft)
+    got = Predictor(args, net, ctx=ctx).demix(torch.from_numpy(c["mix"]).cuda()).cpu().numpy()
     err = float(np.max(np.abs(got - want)))
     print(f"full-size fp32: max|delta| = {err:.3e}, peak = {np.max(np.abs(want)):.3f}, rms = {np.sqrt(np.mean(want ** 2)):.3f}")
     assert np.max(np.abs(want)) > 1e-2
     assert err < 1e-4
+
+
+def test_full_size_mdx_bf16_vs_oracle(ctx):
+    """The BENCH dtype at the BENCH geometry (configs[1]: L=11, g=48, 3072 x 256, n_fft 6144, bf16 storage + bf16 MFMA,
+    windows batched as bench.py does) against the fp32 CPU oracle, end to end in PCM.  bf16 cannot meet the 1e-4 fp32
+    gate (gate parity in fp32, report bf16 with its measured error); the bound asserted here is the measured
+    error with head-room: relative L2 <= 5e-2 (SDR >= 26 dB).  The kernels that produced the checked stems are asserted
+    by launch count: every production kernel of the bench step must have run."""
+    from audiolab_amd.mdx import Predictor
+    from audiolab_amd.tdfnet import TDFNet
+    c = _full_size_case()
+    cfg, want = c["cfg"], c["want"]
+    net = TDFNet(cfg, c["sd"], ctx=ctx, dtype=torch.bfloat16, max_batch=8)
+    args = types.SimpleNamespace(margin=44100, chunks=0, denoise=False, dim_f=cfg.dim_f, dim_t=8, n_fft=cfg.n_fft)
+    ctx.launch_counts_reset()
+    got = Predictor(args, net, ctx=ctx).demix(torch.from_numpy(c["mix"]).cuda()).cpu().numpy()
+    counts = {k: ctx.launch_count(k) for k in ("stft_r16_kernel", "istft_r16_kernel", "conv3x3_bf16_regw_kernel",
+                                               "conv3x3_bf16_big_kernel<2>", "conv3x3_bf16_big_kernel<3>", "conv3x3_bf16_kernel<64>",
+                                               "tdf_bf16_wide_kernel<nores>", "tdf_bf16_wide_kernel<res>", "tdf_bf16_kernel",
+                                               "ds_stream_kernel", "us_stream_kernel", "pix_gemm_kernel")}
+    print("launches:", counts)
+    assert counts["stft_r16_kernel"] == 1 and counts["istft_r16_kernel"] == 1
+    assert counts["conv3x3_bf16_regw_kernel"] == 6 and counts["conv3x3_bf16_big_kernel<2>"] == 6      # levels 0 / 1: 2 blocks x 3
+    assert counts["conv3x3_bf16_big_kernel<3>"] == 6 and counts["conv3x3_bf16_kernel<64>"] >= 6       # level 2; levels 3, 4
+    assert counts["tdf_bf16_wide_kernel<nores>"] == 4 and counts["tdf_bf16_wide_kernel<res>"] == 4     # levels 0-1, both linears
+    assert counts["ds_stream_kernel"] == 3 and counts["us_stream_kernel"] == 3                        # levels 0<->1<->2<->3
+    d = (got - want).astype(np.float64)
+    rel = float(np.sqrt((d ** 2).sum() / (want.astype(np.float64) ** 2).sum()))
+    sdr = -20.0 * np.log10(rel)
+    print(f"full-size bf16: rel L2 = {rel:.3e} (SDR {sdr:.1f} dB), max|delta| = {np.max(np.abs(d)):.3e}, peak = {np.max(np.abs(want)):.3f}")
+    assert rel < 5e-2
 
 
 def test_properties_at_baseline_size(ctx):

@@ -52,7 +52,7 @@ def test_reader_recovers_config_and_function(tmp_path, kw, style, as_inputs):
     assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
 
 
-def test_loaded_weights_run_on_the_kernels(emul, tmp_path):
+def test_loaded_weights_run_on_the_kernels(dev, tmp_path):
     from audiolab_amd.onnx_reader import load_mdx_onnx
     from audiolab_amd.tdfnet import TDFNet
     cfg = _cfg(n_fft=256, hop=64)
@@ -61,10 +61,10 @@ def test_loaded_weights_run_on_the_kernels(emul, tmp_path):
     write_mdx_onnx(path, sd, cfg)
     m = load_mdx_onnx(path, n_fft=cfg.n_fft, hop=cfg.hop)
     assert m.config == cfg
-    net = TDFNet(m.config, m.state_dict, ctx=emul, dtype=torch.float32)
+    net = TDFNet(m.config, m.state_dict, ctx=dev, dtype=torch.float32)
     x = torch.randn(1, 4, cfg.dim_f, cfg.dim_t, generator=torch.Generator().manual_seed(5))
     want = tdfnet_oracle.forward(sd, x, cfg.num_blocks, cfg.l, cfg.bn)
-    got = net(x)
+    got = net(x.to(dev.device)).cpu()
     assert float((got - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
 
 
@@ -101,7 +101,7 @@ def test_foreign_graphs_are_refused(tmp_path):
         load_mdx_onnx(path)
 
 
-def test_engine_prefers_the_model_file(emul, tmp_path):
+def test_engine_prefers_the_model_file(dev, tmp_path):
     """Separator.load_model (stem_separator.py:394 call site): an .onnx present in model_file_dir supplies weights and
     hyper-parameters; the roster only contributes n_fft and the stem labels."""
     from audiolab_amd.engine import Separator
@@ -110,15 +110,15 @@ def test_engine_prefers_the_model_file(emul, tmp_path):
     sd = _randomised(cfg, 23)
     write_mdx_onnx(os.path.join(tmp_path, "toy_vocals.onnx"), sd, cfg)
     roster = {"toy_vocals.onnx": ("Vocals", "Instrumental", TDFNetConfig(dim_f=64, dim_t=16, n_fft=256, hop=64, g=48))}
-    sep = Separator(model_file_dir=str(tmp_path), ctx=emul, dtype=torch.float32, roster=roster)
+    sep = Separator(model_file_dir=str(tmp_path), ctx=dev, dtype=torch.float32, roster=roster)
     sep.load_model("toy_vocals.onnx")
     assert sep.model_instance.net.cfg == cfg                  # L, l, g, bn from the graph, not from the roster
     mix = torch.randn(2, 3000, generator=torch.Generator().manual_seed(2)) * 0.1
     got = sep.separate_array(mix)
-    ref = Separator(model_file_dir=str(tmp_path / "none"), ctx=emul, dtype=torch.float32,
+    ref = Separator(model_file_dir=str(tmp_path / "none"), ctx=dev, dtype=torch.float32, allow_synthetic=True,
                     roster={"toy_vocals.onnx": ("Vocals", "Instrumental", cfg)})
     ref.load_model("toy_vocals.onnx")                         # synthetic weights: a different network
-    direct = TDFNet(cfg, sd, ctx=emul, dtype=torch.float32)
+    direct = TDFNet(cfg, sd, ctx=dev, dtype=torch.float32)
     ref.model_instance.predictor.model = direct               # ... swapped for the original weights
     want = ref.separate_array(mix)
     assert float((got["Vocals"] - want["Vocals"]).abs().max()) < 1e-5
@@ -127,3 +127,9 @@ def test_engine_prefers_the_model_file(emul, tmp_path):
     from audiolab_amd._lib import AlsepError
     with pytest.raises(AlsepError):
         sep.load_model("missing.onnx")
+    # in the roster but without a weight file: refused unless synthetic weights were asked for explicitly
+    bare = Separator(model_file_dir=str(tmp_path / "none"), ctx=dev, dtype=torch.float32,
+                     roster={"toy_vocals.onnx": ("Vocals", "Instrumental", cfg)})
+    with pytest.raises(AlsepError, match="allow_synthetic"):
+        bare.load_model("toy_vocals.onnx")
+    assert sep.weights_provenance() == "real" and ref.weights_provenance() == "synthetic"

@@ -1,4 +1,4 @@
-"""CPU (-m "not gpu"): orchestration stages a12 / a13 of SURVEY.md section 8 -- transform chain, BG-vocal split, drum-kit
+"""Emulated kernels (-m "not gpu") and GPU (-m gpu), same bodies: orchestration stages a12 / a13 of SURVEY.md section 8 -- transform chain, BG-vocal split, drum-kit
 split, woodwinds (audiolab_amd/separator/stem_separator.py) -- against golden vectors produced by the REFERENCE's own
 methods (oracle/make_golden_orchestration.py: modules/separator/stem_separator.py:534-623, 680-840 run with a fake separator
 of deterministic toy models).  Both sides use the same toy models (oracle/toy.py TOY_MODELS), so what is compared is the
@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from oracle.toy import TOY_MODELS, synth_mix
+from tests.conftest import host, on
 
 
 class ToyEngine:
@@ -39,9 +40,9 @@ def golden(golden_dir):
     return z, meta
 
 
-def make_model(emul, **opts):
+def make_model(dev, **opts):
     from audiolab_amd.separator.stem_separator import EnsembleDemucsMDXMusicSeparationModel
-    eng = ToyEngine(emul)
+    eng = ToyEngine(dev)
     model = EnsembleDemucsMDXMusicSeparationModel(dict(opts), separator=eng)
     return model, eng
 
@@ -66,7 +67,7 @@ def test_string_logic_matches_reference(golden):
         assert E._rename_file(base, path) == want, (base, path)
 
 
-def test_transform_chain_matches_reference(emul, golden):
+def test_transform_chain_matches_reference(dev, golden):
     z, meta = golden
     x, sr = inputs(meta)
     arrays = {"vocals": x["vocals"], "instrumental": x["inst"], "bg_vocals": x["vocals"]}
@@ -74,29 +75,29 @@ def test_transform_chain_matches_reference(emul, golden):
         info = meta[key]
         label = "bg_vocals" if "_bg_vocals_" in key else ("instrumental" if "_instrumental_" in key else "vocals")
         skip = ["No Reverb"] if key.endswith("_skip") else None
-        model, eng = make_model(emul, **info["opts"])
-        got = model._apply_transform_chain(torch.from_numpy(arrays[label].copy()), "song", label, skip_transforms=skip)
+        model, eng = make_model(dev, **info["opts"])
+        got = model._apply_transform_chain(on(dev, arrays[label].copy()), "song", label, skip_transforms=skip)
         assert eng.calls == info["calls"], key                  # which models ran, in which order
         assert model.global_step == info["steps"], key
         close(got, z[key])
 
 
-def test_bg_vocal_split_matches_reference(emul, golden):
+def test_bg_vocal_split_matches_reference(dev, golden):
     z, meta = golden
     x, sr = inputs(meta)
-    model, eng = make_model(emul)
-    main_v, bg_v = model._apply_bg_vocal_splitting(torch.from_numpy(x["vocals"].copy()), "song")
+    model, eng = make_model(dev)
+    main_v, bg_v = model._apply_bg_vocal_splitting(on(dev, x["vocals"].copy()), "song")
     close(main_v, z["bg_main"])
     close(bg_v, z["bg_bg"])
-    main_v, bg_v = model._apply_bg_vocal_splitting(torch.zeros((2, 4000)), "song")      # silent background: keep the input
+    main_v, bg_v = model._apply_bg_vocal_splitting(on(dev, torch.zeros((2, 4000))), "song")      # silent background: keep the input
     assert bg_v is None and float(main_v.abs().max()) == 0.0 and meta["bg_silent_fallback"]
 
 
-def test_drum_kit_and_woodwinds_match_reference(emul, golden):
+def test_drum_kit_and_woodwinds_match_reference(dev, golden):
     z, meta = golden
     x, sr = inputs(meta)
-    model, eng = make_model(emul)
-    t = lambda a: torch.from_numpy(a.copy())
+    model, eng = make_model(dev)
+    t = lambda a: on(dev, a.copy())
     results = {"song": {"sr": sr, "instrumental": t(x["inst"]), "drums": t(x["drums"]), "other": t(x["other"]), "bass": None,
                         "output_folder": "/mem"}}
     model._advanced_drum_separation_all(results)
@@ -109,18 +110,18 @@ def test_drum_kit_and_woodwinds_match_reference(emul, golden):
     assert model.global_step == meta["drum_ww_steps"]
 
 
-def test_six_stem_label_mapping_matches_reference(emul, golden):
+def test_six_stem_label_mapping_matches_reference(dev, golden):
     z, meta = golden
     x, sr = inputs(meta)
-    model, eng = make_model(emul)
-    mix = torch.from_numpy((x["vocals"] + x["inst"]).astype(np.float32))
-    results = {"song": {"sr": sr, "mix": mix, "instrumental": torch.from_numpy(x["inst"].copy()), "output_folder": "/mem"}}
+    model, eng = make_model(dev)
+    mix = on(dev, (x["vocals"] + x["inst"]).astype(np.float32))
+    results = {"song": {"sr": sr, "mix": mix, "instrumental": on(dev, x["inst"].copy()), "output_folder": "/mem"}}
     model._multistem_separation_all(results)
     for k in ("drums", "bass", "guitar", "piano", "other"):
         close(results["song"][k], z[f"multi_{k}"])
 
 
-def test_stages_are_skipped_without_their_models(emul, tmp_path):
+def test_stages_are_skipped_without_their_models(dev, tmp_path):
     """Default roster (MDX-Net files only): the stages whose model architectures have no kernels yet are skipped with a
     log line, the job still completes and the progress reaches 1."""
     from audiolab_amd import wavio
@@ -132,7 +133,7 @@ def test_stages_are_skipped_without_their_models(emul, tmp_path):
     mix = synth_mix(6000, seed=5)
     src = tmp_path / "song.wav"
     wavio.write_wav(str(src), mix, 44100)
-    eng = Separator(ctx=emul, use_autocast=False, roster=roster, max_batch=2)
+    eng = Separator(ctx=dev, use_autocast=False, allow_synthetic=True, roster=roster, max_batch=2)
     ticks = []
     os.makedirs(tmp_path / "stems")
     out = separate_music({str(tmp_path / "stems"): [str(src)]}, callback=lambda f, d, t: ticks.append(f), separator=eng,
@@ -144,7 +145,7 @@ def test_stages_are_skipped_without_their_models(emul, tmp_path):
     assert ticks[-1] >= 1.0 - 1e-9 and all(b >= a for a, b in zip(ticks, ticks[1:]))
 
 
-def test_multi_stem_roster_entry(emul):
+def test_multi_stem_roster_entry(dev):
     """("multi", [(label, cfg), ...]): one network per stem, all fed the same input (the drum-kit splitter's shape)."""
     import hashlib
     from audiolab_amd.engine import Separator
@@ -154,7 +155,7 @@ def test_multi_stem_roster_entry(emul):
     from oracle import tdfnet_oracle
     cfg = TDFNetConfig(dim_f=64, dim_t=32, n_fft=256, hop=64, num_blocks=3, g=16)
     name = "MDX23C-DrumSep-aufr33-jarredou.ckpt"
-    eng = Separator(ctx=emul, use_autocast=False, roster={name: ("multi", [("Kick", cfg), ("Snare", cfg)])}, max_batch=2)
+    eng = Separator(ctx=dev, use_autocast=False, allow_synthetic=True, roster={name: ("multi", [("Kick", cfg), ("Snare", cfg)])}, max_batch=2)
     eng.load_model(name)
     mix = synth_mix(5000, seed=9)
     out = eng.separate_array(mix)
@@ -167,4 +168,4 @@ def test_multi_stem_roster_entry(emul):
         def run(spek):
             return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)), cfg.num_blocks, cfg.l, cfg.bn).numpy()
         want = mo.demix(mix, g, run, chunks=0, margin=44100, dtype=np.float32)[0]
-        assert np.max(np.abs(out[label].numpy() - want)) < 1e-4
+        assert np.max(np.abs(host(out[label]) - want)) < 1e-4

@@ -35,6 +35,38 @@ def test_wav_roundtrip(tmp_path):
     with pytest.raises(ValueError):
         (tmp_path / "c.wav").write_bytes(b"not a wav")
         wavio.read_wav(str(tmp_path / "c.wav"))
+    import struct
+    short_fmt = b"RIFF" + struct.pack("<I", 24) + b"WAVE" + b"fmt " + struct.pack("<I", 8) + b"\x01\x00\x02\x00\x44\xac\x00\x00"
+    zero_ch = (b"RIFF" + struct.pack("<I", 36) + b"WAVE" + b"fmt " + struct.pack("<I", 16) +
+               struct.pack("<HHIIHH", 1, 0, 44100, 0, 0, 16) + b"data" + struct.pack("<I", 0))
+    for blob in (short_fmt, zero_ch):                                             # malformed headers: ValueError, not struct.error
+        (tmp_path / "d.wav").write_bytes(blob)
+        with pytest.raises(ValueError):
+            wavio.read_wav(str(tmp_path / "d.wav"))
+
+
+def test_project_files_contract(sandbox):
+    """util/data_classes.py:10-67: directory layout, hash tag, dict bookkeeping, all_outputs filter."""
+    import xxhash
+    from audiolab_amd.util.data_classes import ProjectFiles
+    src = sandbox / "my song.wav"
+    make_wav(src)
+    p = ProjectFiles(str(src))
+    tag = xxhash.xxh64(src.read_bytes()).hexdigest()[:8]
+    assert p.file_hash == tag
+    assert p.project_dir == os.path.join(str(sandbox / "outputs"), "process", f"my song_{tag}")
+    assert p.src_file == os.path.join(p.project_dir, "source", "my song.wav") and os.path.isfile(p.src_file)
+    assert p.last_outputs == [] and p.video_sources == {} and p.output_dict == {}
+    assert p.file_dict["source"][0] == p.src_file
+    a, b = os.path.join(p.project_dir, "stems", "a.wav"), os.path.join(p.project_dir, "stems", "gone.wav")
+    os.makedirs(os.path.dirname(a))
+    open(a, "wb").close()
+    p.add_output("stems", [a, b])
+    p.add_output("merge", a)
+    assert p.last_outputs == [a] and p.output_dict == {"stems": [a, b], "merge": [a]} and p.file_dict["stems"] == [a, b]
+    assert p.all_outputs() == [a]                                                 # existing, non-terminal, no repeats
+    again = ProjectFiles(str(src))                                                # files of earlier runs are indexed by folder
+    assert again.project_dir == p.project_dir and a in again.file_dict["stems"] and again.output_dict == {}
 
 
 def test_allowed_kwargs_match_reference_table():
