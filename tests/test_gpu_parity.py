@@ -158,6 +158,7 @@ def _net_case(ctx, kw, dtype, batch, seed=7):
     x = (torch.randn((batch, 4, cfg.dim_f, cfg.dim_t), generator=g) * 4.0).to(dtype).float()
     want = tdfnet_oracle.forward(sd, x, cfg.num_blocks, cfg.l, cfg.bn)
     got = net.forward_nhwc(x.permute(0, 3, 2, 1).contiguous().to(dtype).cuda()).float().cpu().permute(0, 3, 2, 1)
+    _net_case.last, _net_case.last_x = (got, want, net, sd, cfg), x
     return got, want, net, sd, cfg
 
 
@@ -223,8 +224,13 @@ def test_big_tile_conv_kernels_vs_oracle(ctx, g, kernel):
     assert ctx.launch_count("conv3x3_bf16_kernel<64>") == 0 and ctx.launch_count("conv3x3_bf16_kernel<small>") == 0
     rel = float((got - want).norm() / want.norm())
     err = float((got - want).abs().max() / want.abs().max())
-    print(f"{kernel} g={g}: rel L2 {rel:.3e}, max rel {err:.3e}")
+    _, _, _, sd, cfg = _net_case.last
+    from oracle import tdfnet_oracle
+    want_st = tdfnet_oracle.forward(sd, _net_case.last_x, cfg.num_blocks, cfg.l, cfg.bn, storage=torch.bfloat16)
+    rel_st = float((got - want_st).norm() / want_st.norm())
+    print(f"{kernel} g={g}: vs fp32 oracle rel L2 {rel:.3e}, max rel {err:.3e}; vs bf16-storage oracle rel L2 {rel_st:.3e}")
     assert rel < 1.5e-2 and err < 6e-2
+    assert rel_st < 4e-3                 # one block: the only disagreement left is flipped roundings (measured 1-2e-3)
 
 
 _FULL = {}
@@ -267,15 +273,20 @@ def test_full_size_mdx_f32_vs_oracle(ctx):
 
 def test_full_size_mdx_bf16_vs_oracle(ctx):
     """The BENCH dtype at the BENCH geometry (configs[1]: L=11, g=48, 3072 x 256, n_fft 6144, bf16 storage + bf16 MFMA,
-    windows batched as bench.py does) against the fp32 CPU oracle, end to end in PCM.  bf16 cannot meet the 1e-4 fp32
-    gate (gate parity in fp32, report bf16 with its measured error); the bound asserted here is the measured
-    error with head-room: relative L2 <= 5e-2 (SDR >= 26 dB).  The kernels that produced the checked stems are asserted
-    by launch count: every production kernel of the bench step must have run."""
+    windows batched as bench.py does), end to end in PCM, against TWO oracles:
+      (a) the oracle in its half-precision STORAGE mode (oracle/tdfnet_oracle.forward(storage=bfloat16): the same fp32
+          arithmetic with every stored activation / weight matrix rounded to bf16 where the kernels round) -- what the
+          kernels must reproduce up to accumulation order (bound: see the yardstick note at the asserts);
+      (b) the fp32 oracle -- the price of bf16 storage itself on this random-init network, reported (the 1e-4
+          gate is an fp32 gate; bf16 is reported with its measured error) and bounded.
+    The kernels that produced the checked stems are asserted by launch count: every production kernel of the bench
+    step must have run."""
     from audiolab_amd.mdx import Predictor
     from audiolab_amd.tdfnet import TDFNet
+    from oracle import mdx_oracle, tdfnet_oracle
     c = _full_size_case()
-    cfg, want = c["cfg"], c["want"]
-    net = TDFNet(cfg, c["sd"], ctx=ctx, dtype=torch.bfloat16, max_batch=8)
+    cfg, want, sd = c["cfg"], c["want"], c["sd"]
+    net = TDFNet(cfg, sd, ctx=ctx, dtype=torch.bfloat16, max_batch=8)
     args = types.SimpleNamespace(margin=44100, chunks=0, denoise=False, dim_f=cfg.dim_f, dim_t=8, n_fft=cfg.n_fft)
     ctx.launch_counts_reset()
     got = Predictor(args, net, ctx=ctx).demix(torch.from_numpy(c["mix"]).cuda()).cpu().numpy()
@@ -289,11 +300,30 @@ def test_full_size_mdx_bf16_vs_oracle(ctx):
     assert counts["conv3x3_bf16_big_kernel<3>"] == 6 and counts["conv3x3_bf16_kernel<64>"] >= 6       # level 2; levels 3, 4
     assert counts["tdf_bf16_wide_kernel<nores>"] == 4 and counts["tdf_bf16_wide_kernel<res>"] == 4     # levels 0-1, both linears
     assert counts["ds_stream_kernel"] == 3 and counts["us_stream_kernel"] == 3                        # levels 0<->1<->2<->3
-    d = (got - want).astype(np.float64)
-    rel = float(np.sqrt((d ** 2).sum() / (want.astype(np.float64) ** 2).sum()))
-    sdr = -20.0 * np.log10(rel)
-    print(f"full-size bf16: rel L2 = {rel:.3e} (SDR {sdr:.1f} dB), max|delta| = {np.max(np.abs(d)):.3e}, peak = {np.max(np.abs(want)):.3f}")
-    assert rel < 5e-2
+
+    def model_run_bf16(spek):
+        with torch.no_grad():
+            return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)),
+                                         cfg.num_blocks, cfg.l, cfg.bn, storage=torch.bfloat16).numpy()
+    g = mdx_oracle.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
+    want_st = mdx_oracle.demix(c["mix"], g, model_run_bf16, chunks=0, margin=44100, dtype=np.float32)
+
+    def rel(a, b):
+        d = (a - b).astype(np.float64)
+        return float(np.sqrt((d ** 2).sum() / (b.astype(np.float64) ** 2).sum()))
+    r_st, r_32, r_oo = rel(got, want_st), rel(got, want), rel(want_st, want)
+    print(f"full-size bf16: vs bf16-storage oracle rel L2 = {r_st:.3e} (SDR {-20 * np.log10(r_st):.1f} dB); vs fp32 oracle "
+          f"{r_32:.3e} (SDR {-20 * np.log10(r_32):.1f} dB); bf16-storage oracle vs fp32 oracle {r_oo:.3e}; "
+          f"max|delta| vs storage oracle = {np.max(np.abs(got - want_st)):.3e}, peak = {np.max(np.abs(want)):.3f}")
+    # Yardstick: two FAITHFUL bf16-storage evaluations of this random-init network (same rounding points, different fp32
+    # summation order -- e.g. this oracle in fp32 and in fp64) already differ by ~0.6 x their distance to the fp32 result,
+    # because a flipped bf16 rounding is a 2^-9 perturbation that the 40-layer network amplifies (measured on the emulated
+    # kernels: 0.47 % vs 0.82 % at 3 blocks, 1.7 % vs 2.8 % at 5).  A kernel that computed anything else than the
+    # restated arithmetic would sit at >= 1.0 x (independent errors add).  So: distance to the storage oracle at most
+    # 0.8 x the cost of the storage type, total error at most 1.25 x that cost, and a hard cap.
+    assert r_st < 0.8 * r_oo, (r_st, r_oo)
+    assert r_32 < 1.25 * r_oo, (r_32, r_oo)
+    assert r_32 < 0.3
 
 
 def test_properties_at_baseline_size(ctx):
