@@ -793,7 +793,7 @@ struct ConvBig {
     static_assert(lds_bytes <= 160 * 1024, "ConvBig: LDS budget");
 };
 
-template <int NY>
+template <int NY, bool SWP = true>                           // SWP: software-pipelined k-loop (fragments of k-step s+1 requested before the MFMAs of s)
 __global__ void __launch_bounds__(kBigThreads, 2)
 conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
                         const float* __restrict__ scale, const float* __restrict__ shift,
@@ -822,6 +822,17 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
         const int tap = gc / Cf::CG, cg = gc % Cf::CG;
         return ((tap / 3) * Cf::PW + (tap % 3)) * Cf::KC + cg * 8;
     };
+    // SWP: per-lane LDS element offsets, computed once.  Patch: pixel (row = wave, col = l15) + k-group 4 st + lq.  Weights:
+    // (4 st + lq) ^ wswz = 4 (st ^ b) + c with b = wswz >> 2, c = lq ^ (wswz & 3): an even / odd k-step differs by +-32 elements
+    int pk[SWP ? Cf::NS : 1];
+    int wl_e = 0, wl_o = 0;
+    if constexpr (SWP) {
+#pragma unroll
+        for (int st = 0; st < Cf::NS; ++st) pk[st] = pbase[0] + koff_of(st);
+        const int b32 = (wswz >> 2) * 32, c8 = (lq ^ (wswz & 3)) * 8;
+        wl_e = l15 * Cf::WGRP * 8 + c8 + b32;
+        wl_o = l15 * Cf::WGRP * 8 + c8 - b32;
+    }
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nstage = my_tiles * NY * nq;
 
@@ -899,6 +910,39 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
 #pragma unroll
                             for (int ni = 0; ni < 4; ++ni) acc[yy][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
+                    if constexpr (SWP) {
+                        // Fully unrolled; every LDS address is a per-lane base (pk[st]: patch, k-group 4 st + lq; wl_e / wl_o: weight row
+                        // l15, swizzled group of an even / odd k-step) plus an instruction immediate, so a k-step costs no VALU
+                        // (the rolled loop recomputed tap / group divisions per step: ~30 VALU instructions beside 12 MFMAs), and
+                        // the 7 fragment reads of k-step st + 1 are in flight while the 12 MFMAs of st run (counted lgkmcnt).
+                        const bf16_t* we = wts + wl_e;
+                        const bf16_t* wo = wts + wl_o;
+                        bf16x8 xa[4], wa[3], xb[4], wb[3];
+                        auto load = [&](int st, bf16x8 (&xf)[4], bf16x8 (&wf)[3]) {
+                            const bf16_t* pl = patch + pk[st];
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni) xf[ni] = lds_frag<bf16_t>(pl + ni * 16 * Cf::KC);
+                            const bf16_t* wl = (st & 1) ? wo : we;
+#pragma unroll
+                            for (int mi = 0; mi < 3; ++mi) wf[mi] = lds_frag<bf16_t>(wl + mi * 16 * Cf::WGRP * 8 + st * 32);
+                        };
+                        load(0, xa, wa);
+#pragma unroll
+                        for (int st = 0; st < Cf::NS; st += 2) {
+                            load(st + 1, xb, wb);
+#pragma unroll
+                            for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+                                for (int ni = 0; ni < 4; ++ni) mma_step(acc[yy][mi][ni], wa[mi], xa[ni]);
+                            if (st < 6 && !last) weights_one(st);
+                            if (st + 2 < Cf::NS) load(st + 2, xa, wa);
+#pragma unroll
+                            for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+                                for (int ni = 0; ni < 4; ++ni) mma_step(acc[yy][mi][ni], wb[mi], xb[ni]);
+                            if (st + 1 < 6 && !last) weights_one(st + 1);
+                        }
+                    } else {
 #pragma unroll 2
                     for (int st = 0; st < Cf::NS; ++st) {
                         const int ko = koff_of(st);
@@ -912,6 +956,7 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
 #pragma unroll
                             for (int ni = 0; ni < 4; ++ni) mma_step(acc[yy][mi][ni], wf[mi], xf[ni]);
                         if (st < 6 && !last) weights_one(st);
+                    }
                     }
                 }
             }
@@ -2253,13 +2298,22 @@ int launch_conv_big(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     const int tiles_t = Th / Cf::TH, tiles_f = Fw / Cf::TW;
     const int64_t ntiles = B * tiles_t * tiles_f;
     if (ntiles > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "conv3x3: too many tiles");
-    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_big_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_big_kernel<NY, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)Cf::lds_bytes));
     const int gx = ntiles < 256 ? (int)ntiles : 256;
+    static const int swp = [] { const char* e = getenv("ALSEP_CONV_BIG_SWP"); return e ? atoi(e) : 1; }();
     ProfScope prof(ctx, NY == 3 ? ALSEP_PROF_CONV3X3_BIG3 : ALSEP_PROF_CONV3X3_BIG);
-    hipLaunchKernelGGL((conv3x3_bf16_big_kernel<NY>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
-                       (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
-                       L.cout, tiles_t, tiles_f, (int)ntiles);
+    if (swp) {
+        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_big_kernel<NY, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)Cf::lds_bytes));
+        hipLaunchKernelGGL((conv3x3_bf16_big_kernel<NY, true>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                           (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
+                           L.cout, tiles_t, tiles_f, (int)ntiles);
+    } else {
+        hipLaunchKernelGGL((conv3x3_bf16_big_kernel<NY, false>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                           (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
+                           L.cout, tiles_t, tiles_f, (int)ntiles);
+    }
     note_launch(ctx, NY == 3 ? "conv3x3_bf16_big_kernel<3>" : "conv3x3_bf16_big_kernel<2>");
     ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_big_kernel");
     return ALSEP_OK;
