@@ -78,6 +78,29 @@ __device__ __forceinline__ void global_load_async_bf16x8(bf16x8& dst, const void
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
 
+// Asynchronous 16-byte LDS read into a register fragment, invisible to hipcc's waitcnt bookkeeping (as the global form above):
+//   dst <- *(lds_ptr + OFF bytes), OFF in the instruction's 16-bit immediate.
+// Why: in a software-pipelined k-loop (fragments of step s+1 requested before the MFMAs of step s) ROCm 7.2 waits
+// "s_waitcnt lgkmcnt(0)" at the first use of step s's fragments although the counter is in order and lgkmcnt(7) would do --
+// every second step then waits for the reads it has just issued.  As asm the wait is ours (lds_wait_n<N>): dst must not be read
+// before it, and the compiler must have no reason to touch dst in between (scripts/check_async_regs.py).
+template <int OFF>
+__device__ __forceinline__ void lds_read_async_b128(bf16x8& dst, const bf16_t* lds_ptr) {
+    static_assert(OFF >= 0 && OFF < 65536 && OFF % 16 == 0, "ds offset field");
+    const unsigned addr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)lds_ptr;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+// wait until at most N of this wave's LDS operations are outstanding (they complete in order); pins the instruction order
+template <int N>
+__device__ __forceinline__ void lds_wait_n() {
+    static_assert(N >= 0 && N < 16, "lgkmcnt is a 4-bit counter");
+    __builtin_amdgcn_s_waitcnt((63 & 15) | ((63 >> 4) << 14) | (7 << 4) | (N << 8));
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// no instruction may be scheduled across this point
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
 // Extends the live range of a register value to this point (no code).
 template <typename T>
 __device__ __forceinline__ void keep_vgprs_live(const T& v) {

@@ -789,9 +789,56 @@ struct ConvBig {
     static constexpr int PINST = (PGROUPS + 63) / 64;       // 62
     static constexpr int WINST = WGROUPS / 64;              // 42: waves 0,1 issue 6, waves 2..7 issue 5
     static constexpr size_t ring_bytes = 16 * (size_t)(PGROUPS + 2 * WGROUPS);
-    static constexpr size_t lds_bytes = ring_bytes + 2 * NY * BN * sizeof(float);
+    static constexpr size_t lds_bytes = ring_bytes + 2 * NY * BN * sizeof(float) + 1024;   // + 1 KiB scratch (surplus DMA pieces)
     static_assert(lds_bytes <= 160 * 1024, "ConvBig: LDS budget");
 };
+
+// ---- software-pipelined k-loop of the big-tile kernel (SWP) ------------------------------------------------------------
+// One k-step's fragments: 4 patch reads (pixel blocks ni at +ni*16*KC elements) and 3 weight reads (row blocks mi at
+// +mi*16*WGRP*8, k-step ST at +32*ST elements from the even / odd lane base), all with immediate offsets.
+template <typename Cf, int ST>
+__device__ __forceinline__ void big_issue_reads(bf16x8 (&xf)[4], bf16x8 (&wf)[3], const bf16_t* patch, const int (&pk)[Cf::NS],
+                                                const bf16_t* we, const bf16_t* wo) {
+    const bf16_t* pl = patch + pk[ST];
+    lds_read_async_b128<0 * 16 * Cf::KC * 2>(xf[0], pl);
+    lds_read_async_b128<1 * 16 * Cf::KC * 2>(xf[1], pl);
+    lds_read_async_b128<2 * 16 * Cf::KC * 2>(xf[2], pl);
+    lds_read_async_b128<3 * 16 * Cf::KC * 2>(xf[3], pl);
+    const bf16_t* wl = (ST & 1) ? wo : we;
+    lds_read_async_b128<(0 * 16 * Cf::WGRP * 8 + ST * 32) * 2>(wf[0], wl);
+    lds_read_async_b128<(1 * 16 * Cf::WGRP * 8 + ST * 32) * 2>(wf[1], wl);
+    lds_read_async_b128<(2 * 16 * Cf::WGRP * 8 + ST * 32) * 2>(wf[2], wl);
+}
+__device__ __forceinline__ void big_mma12(f32x4 (&acc)[3][4], const bf16x8 (&wf)[3], const bf16x8 (&xf)[4]) {
+#pragma unroll
+    for (int mi = 0; mi < 3; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) mma_step(acc[mi][ni], wf[mi], xf[ni]);
+}
+// steps ST (fragments in a) and ST + 1 (in b); on entry nothing of step ST has been requested when ST == 0, else a is in flight
+template <typename Cf, int ST, typename Dma>
+__device__ __forceinline__ void big_swp_steps(f32x4 (&acc)[3][4], bf16x8 (&xa)[4], bf16x8 (&wa)[3], bf16x8 (&xb)[4], bf16x8 (&wb)[3],
+                                              const bf16_t* patch, const int (&pk)[Cf::NS], const bf16_t* we, const bf16_t* wo,
+                                              Dma dma) {
+    if constexpr (ST < Cf::NS) {
+        if constexpr (ST == 0) big_issue_reads<Cf, 0>(xa, wa, patch, pk, we, wo);
+        big_issue_reads<Cf, ST + 1>(xb, wb, patch, pk, we, wo);
+        lds_wait_n<7>();                                     // a (the older 7 reads) has landed, b is in flight
+        big_mma12(acc, wa, xa);
+        if constexpr (ST < 6) dma(ST);
+        sched_fence();
+        if constexpr (ST + 2 < Cf::NS) {
+            big_issue_reads<Cf, ST + 2>(xa, wa, patch, pk, we, wo);
+            lds_wait_n<7>();
+        } else {
+            lds_wait_n<0>();
+        }
+        big_mma12(acc, wb, xb);
+        if constexpr (ST + 1 < 6) dma(ST + 1);
+        sched_fence();
+        big_swp_steps<Cf, ST + 2>(acc, xa, wa, xb, wb, patch, pk, we, wo, dma);
+    }
+}
 
 template <int NY, bool SWP = true>                           // SWP: software-pipelined k-loop (fragments of k-step s+1 requested before the MFMAs of s)
 __global__ void __launch_bounds__(kBigThreads, 2)
@@ -871,9 +918,17 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
         wsrc_next = Wp + ((int64_t)ny * nq + q) * (Cf::WGROUPS * 8);
         wdst_next = wring + (size_t)(s & 1) * Cf::WGROUPS * 8;
     };
+    bf16_t* const scratch = reinterpret_cast<bf16_t*>(alsep_smem + Cf::lds_bytes - 1024);   // SWP: landing place of the surplus DMAs
     auto weights_one = [&](int j) {
         const int i = wave + 8 * j;
-        if (i < Cf::WINST) glds16(wsrc_next + ((size_t)i * 64 + lane) * 8, wdst_next + (size_t)i * 64 * 8);
+        if constexpr (SWP) {
+            // branch-free (a wave-uniform branch here splits the unrolled k-loop into basic blocks, and hipcc then waits
+            // lgkmcnt(0) at every join): waves 2..7 have no sixth piece and copy piece 0 into a 1 KiB scratch instead
+            const bool real = i < Cf::WINST;
+            glds16(wsrc_next + ((size_t)(real ? i : 0) * 64 + lane) * 8, real ? wdst_next + (size_t)i * 64 * 8 : scratch);
+        } else {
+            if (i < Cf::WINST) glds16(wsrc_next + ((size_t)i * 64 + lane) * 8, wdst_next + (size_t)i * 64 * 8);
+        }
     };
 
     // Stage s: ny = s % NY, patch ps = s / NY (tile ps / nq, input chunk q = ps % nq).  In-order vmcnt bookkeeping:
@@ -898,7 +953,7 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
         if (after_epilogue) wait_vmcnt<ST>();
         else wait_vmcnt<0>();
         barrier_nodrain();
-        if (!last) weights_prep(s + 1);
+        if (SWP || !last) weights_prep(s + 1);                   // SWP: the (branch-free) DMA of the last stage refills the free slot once more
         {
             const bf16_t* wts = wring + (size_t)(s & 1) * Cf::WGROUPS * 8;
 #pragma unroll
@@ -911,37 +966,16 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
                             for (int ni = 0; ni < 4; ++ni) acc[yy][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                     if constexpr (SWP) {
-                        // Fully unrolled; every LDS address is a per-lane base (pk[st]: patch, k-group 4 st + lq; wl_e / wl_o: weight row
-                        // l15, swizzled group of an even / odd k-step) plus an instruction immediate, so a k-step costs no VALU
-                        // (the rolled loop recomputed tap / group divisions per step: ~30 VALU instructions beside 12 MFMAs), and
-                        // the 7 fragment reads of k-step st + 1 are in flight while the 12 MFMAs of st run (counted lgkmcnt).
+                        // Fully unrolled, software-pipelined: the 7 fragment reads of k-step st + 1 are in flight while the 12 MFMAs
+                        // of st run.  Every LDS address is a per-lane base (pk[st]: patch, k-group 4 st + lq; we / wo: weight row l15,
+                        // swizzled group of an even / odd k-step) plus an instruction immediate, so a k-step costs no VALU (the rolled
+                        // loop recomputed the tap / group divisions per step: ~30 VALU instructions beside 12 MFMAs).  The reads are
+                        // asm (lds_read_async_b128) with our own counted waits: hipcc waits lgkmcnt(0) -- i.e. also for the reads it
+                        // has just issued -- at every second step of the same loop written with plain loads.
                         const bf16_t* we = wts + wl_e;
                         const bf16_t* wo = wts + wl_o;
                         bf16x8 xa[4], wa[3], xb[4], wb[3];
-                        auto load = [&](int st, bf16x8 (&xf)[4], bf16x8 (&wf)[3]) {
-                            const bf16_t* pl = patch + pk[st];
-#pragma unroll
-                            for (int ni = 0; ni < 4; ++ni) xf[ni] = lds_frag<bf16_t>(pl + ni * 16 * Cf::KC);
-                            const bf16_t* wl = (st & 1) ? wo : we;
-#pragma unroll
-                            for (int mi = 0; mi < 3; ++mi) wf[mi] = lds_frag<bf16_t>(wl + mi * 16 * Cf::WGRP * 8 + st * 32);
-                        };
-                        load(0, xa, wa);
-#pragma unroll
-                        for (int st = 0; st < Cf::NS; st += 2) {
-                            load(st + 1, xb, wb);
-#pragma unroll
-                            for (int mi = 0; mi < 3; ++mi)
-#pragma unroll
-                                for (int ni = 0; ni < 4; ++ni) mma_step(acc[yy][mi][ni], wa[mi], xa[ni]);
-                            if (st < 6 && !last) weights_one(st);
-                            if (st + 2 < Cf::NS) load(st + 2, xa, wa);
-#pragma unroll
-                            for (int mi = 0; mi < 3; ++mi)
-#pragma unroll
-                                for (int ni = 0; ni < 4; ++ni) mma_step(acc[yy][mi][ni], wb[mi], xb[ni]);
-                            if (st + 1 < 6 && !last) weights_one(st + 1);
-                        }
+                        big_swp_steps<Cf, 0>(acc[yy], xa, wa, xb, wb, patch, pk, we, wo, [&](int j) { weights_one(j); });
                     } else {
 #pragma unroll 2
                     for (int st = 0; st < Cf::NS; ++st) {
@@ -985,6 +1019,7 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
             }
         }
     }
+    if constexpr (SWP) wait_vmcnt<0>();                      // the surplus LDS-DMA of the last stage lands before the wave ends
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2301,9 +2336,14 @@ int launch_conv_big(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_big_kernel<NY, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)Cf::lds_bytes));
     const int gx = ntiles < 256 ? (int)ntiles : 256;
-    static const int swp = [] { const char* e = getenv("ALSEP_CONV_BIG_SWP"); return e ? atoi(e) : 1; }();
+    // ALSEP_CONV_BIG_SWP: 0 (default) rolled k-loop; 1 software-pipelined k-loop at NY = 2; 2 also at NY = 3 (spills).  Same-box A/B
+    // (profiles/r02_conv_big_swp_ab.txt): the pipelined loop takes 3-7 % off this kernel (310 -> 301 / 287 us) but the whole step gets
+    // SLOWER (233.5 -> 238.4 ms): every other kernel -- the untouched NY = 3 conv, the plain conv, even the stand-alone STFT loop that
+    // runs after the steps -- loses 5-9 % in the same process.  The chip gives the saved stall cycles back as a lower clock
+    // (MI355X_MICROARCH.md, DVFS give-back), and keeps it lower for the kernels that follow.
+    static const int swp = [] { const char* e = getenv("ALSEP_CONV_BIG_SWP"); return e ? atoi(e) : 0; }();
     ProfScope prof(ctx, NY == 3 ? ALSEP_PROF_CONV3X3_BIG3 : ALSEP_PROF_CONV3X3_BIG);
-    if (swp) {
+    if (swp >= (NY == 2 ? 1 : 2)) {                          // NY = 3: the second fragment set does not fit 256 registers (76 spilled): opt-in only
         ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_big_kernel<NY, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)Cf::lds_bytes));
         hipLaunchKernelGGL((conv3x3_bf16_big_kernel<NY, true>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,

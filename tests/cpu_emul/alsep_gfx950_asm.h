@@ -40,6 +40,14 @@ static inline void global_load_async_bf16x8(bf16x8& dst, const void* sbase, unsi
     dst = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sbase) + voff + OFF);
 }
 
+template <int OFF>
+static inline void lds_read_async_b128(bf16x8& dst, const bf16_t* lds_ptr) {
+    std::memcpy(&dst, reinterpret_cast<const char*>(lds_ptr) + OFF, 16);
+}
+template <int N>
+static inline void lds_wait_n() {}
+static inline void sched_fence() {}
+
 template <typename T>
 static inline void keep_vgprs_live(const T&) {}
 

@@ -62,6 +62,7 @@ def test_dispatch_orders_and_prefetch_bit_identical(tmp_path):
     base = run_mode((1, 0, 1), str(tmp_path / "d0.npy"))
     assert np.isfinite(base).all() and np.abs(base).max() > 1e-3
     for extra in (dict(ALSEP_CONV_NYFAST="0"), dict(ALSEP_TDF_YFAST="0"), dict(ALSEP_CONV_BIG3="0"), dict(ALSEP_TDF_RPF="0"),
+                  dict(ALSEP_CONV_BIG_SWP="0"), dict(ALSEP_CONV_BIG_SWP="2"),   # rolled k-loop / software-pipelined also at NY = 3
                   dict(ALSEP_CONV_NYFAST="0", ALSEP_TDF_YFAST="0", ALSEP_CONV_BIG3="0", ALSEP_TDF_RPF="0")):
         got = run_mode((1, 0, 1), str(tmp_path / "d1.npy"), **extra)
         assert np.array_equal(base, got), f"{extra}: max diff {np.abs(base - got).max()}"
