@@ -84,6 +84,27 @@ _SIGNATURES = {
     "alsep_vr_copy_slice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 6),
     "alsep_vr_mean_h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "alsep_vr_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 5 + [C.c_float]),
+    "alsep_nn_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 15),
+    "alsep_nn_bgemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 +
+                       [C.POINTER(C.c_int64)] * 3 + [C.c_float]),
+    "alsep_nn_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+    "alsep_nn_stats_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
+    "alsep_nn_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_float,
+                                C.c_int, C.c_void_p]),
+    "alsep_nn_meanstd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "alsep_nn_affine_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_int]),
+    "alsep_nn_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
+    "alsep_nn_scale_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+    "alsep_nn_add_bcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int64, C.c_int, C.c_int]),
+    "alsep_nn_vec_fma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "alsep_nn_vec_div": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
+    "alsep_nn_swap_last2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
+    "alsep_nn_reflect_pad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "alsep_nn_tconv_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 7),
+    "alsep_demucs_spec_in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
+    "alsep_demucs_spec_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_float]),
+    "alsep_demucs_mix_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64]),
 }
 
 EXPORTS: Tuple[str, ...] = tuple(_SIGNATURES)

@@ -1,0 +1,515 @@
+// Generic channels-last fp32 building blocks for the Demucs (HTDemucs) family: what `audio_separator`'s DemucsSeparator runs for
+// `htdemucs_6s.yaml` (reference call site modules/separator/stem_separator.py:459-503; the network source lives in the un-vendored
+// `demucs>=4.0.1`, requirements.txt:19 -- PARITY UNPINNED, restated in oracle/htdemucs_oracle.py).
+//
+// First HIP path for this family (correct and generic, fp32 storage, exact-f32 MFMA for the contractions; not yet tuned):
+//   bgemm        : strided batched GEMM on v_mfma_f32_16x16x4_f32 (attention scores Q K^T and P V straight from the packed
+//                  in-projection [B,T,3C], no head transposes)
+//   softmax_rows : row softmax in place (one workgroup per row, row cached in registers)
+//   norm         : GroupNorm(1 group) / LayerNorm / MyGroupNorm over groups of R rows x C channels, statistics in fp64 by a
+//                  two-stage reduction, per-channel affine, fused GELU or GLU
+//   act, scale_add, add_bcast, vec_fma, vec_div, reflect_pad : element-wise
+//   tconv_fold   : the overlap-add half of ConvTranspose([K,1], [S,1]) (K = 2 S) after its 1x1-conv half
+//   meanstd / affine_stats : Demucs' whole-sample normalisation (unbiased std) and its inverse
+//   demucs_spec_in / spec_out / mix_out : layout glue between the STFT kernels' [B,4,F,T] and the network's [B,F,T,C]
+#include "alsep_common.h"
+#include "mma.h"
+
+namespace {
+
+constexpr int kNnThreads = 256;
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    // wave reduction, then across the 4 waves through LDS
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s = fmaxf(s, red[w]);
+    return s;
+}
+
+// C[b1,b2][m][n] = alpha * sum_k A[b1,b2][m][k] * B[b1,b2][n][k], every operand addressed by element strides.
+// One wave = 64 rows (m) x 32 columns (n); a workgroup = 4 waves side by side along n.
+struct GemmStrides { int64_t b1, b2, r, k; };
+__global__ void __launch_bounds__(kNnThreads)
+nn_bgemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int nb2, int M, int N, int K,
+                GemmStrides sa, GemmStrides sb, GemmStrides sc, float alpha) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int b1 = blockIdx.z / nb2, b2 = blockIdx.z % nb2;
+    const float* a = A + b1 * sa.b1 + b2 * sa.b2;
+    const float* b = B + b1 * sb.b1 + b2 * sb.b2;
+    float* c = C + b1 * sc.b1 + b2 * sc.b2;
+    const int m0 = blockIdx.y * 64, n0 = (blockIdx.x * 4 + wave) * 32;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int64_t arow[4], brow[2];
+    bool av_[4], bv_[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { const int r = m0 + m * 16 + l15; av_[m] = r < M; arow[m] = (int64_t)(av_[m] ? r : 0) * sa.r; }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) { const int r = n0 + n * 16 + l15; bv_[n] = r < N; brow[n] = (int64_t)(bv_[n] ? r : 0) * sb.r; }
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + lq;
+        const bool kv = k < K;
+        float af[4], bf[2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) af[m] = (kv && av_[m]) ? a[arow[m] + (int64_t)k * sa.k] : 0.f;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bf[n] = (kv && bv_[n]) ? b[brow[n] + (int64_t)k * sb.k] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[n], acc[m][n], 0, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int col = n0 + n * 16 + l15;
+        if (col >= N) continue;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + m * 16 + 4 * lq + r;
+                if (row < M) c[(int64_t)row * sc.r + (int64_t)col * sc.k] = alpha * acc[m][n][r];
+            }
+    }
+}
+
+// softmax over the last dimension, in place; one workgroup per row
+__global__ void __launch_bounds__(kNnThreads)
+nn_softmax_rows_kernel(float* __restrict__ x, int n) {
+    float* red = reinterpret_cast<float*>(alsep_smem);
+    double* redd = reinterpret_cast<double*>(alsep_smem + 64);
+    float* row = x + (int64_t)blockIdx.x * n;
+    float mx = -3.4e38f;
+    for (int i = threadIdx.x; i < n; i += kNnThreads) mx = fmaxf(mx, row[i]);
+    mx = block_max(mx, red);
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += kNnThreads) {
+        const float e = expf(row[i] - mx);
+        row[i] = e;
+        s += (double)e;
+    }
+    s = block_sum(s, redd);
+    const float inv = (float)(1.0 / s);
+    for (int i = threadIdx.x; i < n; i += kNnThreads) row[i] *= inv;
+}
+
+// partial sums of a group: grid (NB, G); part[(g * NB + blk) * 2 + {0,1}] = sum, sum of squares (fp64)
+__global__ void __launch_bounds__(kNnThreads)
+nn_stats_partial_kernel(const float* __restrict__ x, int64_t per_group, int nb, double* __restrict__ part) {
+    double* red = reinterpret_cast<double*>(alsep_smem);
+    const int g = blockIdx.y, blk = blockIdx.x;
+    const float* xg = x + (int64_t)g * per_group;
+    const int64_t chunk = (per_group + nb - 1) / nb;
+    const int64_t lo = (int64_t)blk * chunk, hi = lo + chunk < per_group ? lo + chunk : per_group;
+    double s = 0.0, q = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kNnThreads) {
+        const double v = (double)xg[i];
+        s += v;
+        q += v * v;
+    }
+    s = block_sum(s, red);
+    q = block_sum(q, red);
+    if (threadIdx.x == 0) {
+        part[((int64_t)g * nb + blk) * 2] = s;
+        part[((int64_t)g * nb + blk) * 2 + 1] = q;
+    }
+}
+// stats[g] = (mean, rstd or std): mode 0 -> rstd = 1/sqrt(var_biased + eps) (normalisation layers); mode 1 -> unbiased std
+__global__ void nn_stats_final_kernel(const double* __restrict__ part, int nb, int64_t per_group, int G, float eps, int mode,
+                                      float* __restrict__ stats) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nb; ++b) {
+        s += part[((int64_t)g * nb + b) * 2];
+        q += part[((int64_t)g * nb + b) * 2 + 1];
+    }
+    const double n = (double)per_group, mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * g] = (float)mean;
+    if (mode == 0) stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    else stats[2 * g + 1] = (float)sqrt(per_group > 1 ? var * n / (n - 1.0) : 0.0);
+}
+// y = act(((x - mean_g) * rstd_g) * gamma[c] + beta[c]); act 0 none, 3 GELU, 4 GLU (C -> C/2 output channels)
+__global__ void __launch_bounds__(kNnThreads)
+nn_norm_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ gamma,
+                     const float* __restrict__ beta, const float* __restrict__ stats, int64_t n_out, int64_t rows_per_group, int C,
+                     int act) {
+    const int Co = act == 4 ? C / 2 : C;
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * kNnThreads) {
+        const int c = (int)(i % Co);
+        const int64_t row = i / Co;
+        const int64_t g = row / rows_per_group;
+        const float mean = stats[2 * g], rstd = stats[2 * g + 1];
+        const float* xr = x + row * C;
+        float v = (xr[c] - mean) * rstd;
+        if (gamma) v = fmaf(v, gamma[c], beta[c]);
+        if (act == 3) v = gelu_erf(v);
+        else if (act == 4) {
+            float u = (xr[c + Co] - mean) * rstd;
+            if (gamma) u = fmaf(u, gamma[c + Co], beta[c + Co]);
+            v *= sigmoidf_(u);
+        }
+        y[i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(kNnThreads)
+nn_act_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n_out, int C, int act) {
+    const int Co = act == 4 ? C / 2 : C;
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * kNnThreads) {
+        const int c = (int)(i % Co);
+        const int64_t row = i / Co;
+        const float v = x[row * C + c];
+        float r = v;
+        if (act == 1) r = fmaxf(v, 0.f);
+        else if (act == 3) r = gelu_erf(v);
+        else if (act == 4) r = v * sigmoidf_(x[row * C + c + Co]);
+        y[i] = r;
+    }
+}
+
+// y = a + scale[c] * b   (scale == nullptr: 1)
+__global__ void __launch_bounds__(kNnThreads)
+nn_scale_add_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ scale, float* __restrict__ y,
+                    int64_t n, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads)
+        y[i] = scale ? fmaf(scale[i % C], b[i], a[i]) : a[i] + b[i];
+}
+// y[i] += s * e[((i / inner) % period) * C + i % C]
+__global__ void __launch_bounds__(kNnThreads)
+nn_add_bcast_kernel(float* __restrict__ y, const float* __restrict__ e, float s, int64_t n, int64_t inner, int period, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads)
+        y[i] = fmaf(s, e[((i / inner) % period) * C + i % C], y[i]);
+}
+// y[r * ys + i] += w[i] * x[r * xs + i]
+__global__ void __launch_bounds__(kNnThreads)
+nn_vec_fma_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ w, int64_t rows, int64_t n,
+                  int64_t ys, int64_t xs) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < rows * n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int64_t r = i / n, j = i % n;
+        y[r * ys + j] = fmaf(w[j], x[r * xs + j], y[r * ys + j]);
+    }
+}
+__global__ void __launch_bounds__(kNnThreads)
+nn_vec_div_kernel(float* __restrict__ y, const float* __restrict__ w, int64_t rows, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < rows * n; i += (int64_t)gridDim.x * kNnThreads)
+        y[i] = y[i] / w[i % n];
+}
+// torch F.pad(mode="reflect") along the last axis: y[r][i] = x[r][reflect(i - left)], length n -> n + left + right
+__global__ void __launch_bounds__(kNnThreads)
+nn_reflect_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int64_t n, int64_t left, int64_t right) {
+    const int64_t m = n + left + right;
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < rows * m; i += (int64_t)gridDim.x * kNnThreads) {
+        const int64_t r = i / m;
+        int64_t j = i % m - left;
+        if (j < 0) j = -j;
+        if (j >= n) j = 2 * (n - 1) - j;
+        y[i] = x[r * n + j];
+    }
+}
+
+// ConvTranspose([K,1], stride [S,1]) with K = 2 S, second half: g [B, I, J, K * Cout] holds G[i][k][co] = sum_ci x[i][ci] W[ci][co][k];
+// y[b, o, j, co] = act(G[i][r] + G[i - 1][r + S] + bias[co]), o_full = o + pad = i S + r; y is [B, Lout, J, Cout]
+__global__ void __launch_bounds__(kNnThreads)
+nn_tconv_fold_kernel(const float* __restrict__ g, const float* __restrict__ bias, float* __restrict__ y, int64_t n, int I, int J,
+                     int Cout, int S, int pad, int Lout, int act) {
+    const int K = 2 * S;
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int co = (int)(i % Cout);
+        const int64_t p = i / Cout;
+        const int j = (int)(p % J);
+        const int o = (int)((p / J) % Lout);
+        const int64_t b = p / ((int64_t)J * Lout);
+        const int of = o + pad, ii = of / S, r = of % S;
+        float v = bias ? bias[co] : 0.f;
+        if (ii < I) v += g[(((b * I + ii) * J + j) * (int64_t)K + r) * Cout + co];
+        if (ii >= 1 && ii - 1 < I) v += g[(((b * I + ii - 1) * J + j) * (int64_t)K + r + S) * Cout + co];
+        y[i] = act == 3 ? gelu_erf(v) : v;
+    }
+}
+
+// inverse == 0: y = (x - mean) / (eps + std); inverse == 1: y = x * std + mean; stats[2 s] = mean, [2 s + 1] = std of sample s
+__global__ void __launch_bounds__(kNnThreads)
+nn_affine_stats_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ stats, int64_t n,
+                       int64_t per_sample, float eps, int inverse) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int64_t s = i / per_sample;
+        const float mean = stats[2 * s], sd = stats[2 * s + 1];
+        y[i] = inverse ? fmaf(x[i], sd, mean) : (x[i] - mean) / (eps + sd);
+    }
+}
+
+// HTDemucs._spec / _magnitude: spec [B, 4 = (L_re, L_im, R_re, R_im), F, Tt] (alsep_stft, reference layout) ->
+// y [B, F, T, 4] = scale * spec[..., t_off : t_off + T]
+__global__ void __launch_bounds__(kNnThreads)
+demucs_spec_in_kernel(const float* __restrict__ spec, float* __restrict__ y, int64_t n, int F, int Tt, int T, int t_off, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int c = (int)(i & 3);
+        const int64_t p = i >> 2;
+        const int t = (int)(p % T), f = (int)((p / T) % F);
+        const int64_t b = p / ((int64_t)T * F);
+        y[i] = scale * spec[((b * 4 + c) * F + f) * (int64_t)Tt + t_off + t];
+    }
+}
+// HTDemucs._mask (cac) + the frame padding of _ispec: x [B, F, T, S * 4] (normalised network output), stats of the input
+// spectrogram -> spec [B * S, 4, F, Tt]; frames [t_off, t_off + T) = scale * (x * std + mean), the others zero
+__global__ void __launch_bounds__(kNnThreads)
+demucs_spec_out_kernel(const float* __restrict__ x, const float* __restrict__ stats, float* __restrict__ spec, int64_t n, int S, int F,
+                       int Tt, int T, int t_off, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int tt = (int)(i % Tt);
+        const int f = (int)((i / Tt) % F);
+        const int c = (int)((i / ((int64_t)Tt * F)) & 3);
+        const int64_t bs = i / ((int64_t)Tt * F * 4);
+        const int64_t b = bs / S;
+        const int s = (int)(bs % S);
+        const int t = tt - t_off;
+        float v = 0.f;
+        if (t >= 0 && t < T) v = scale * fmaf(x[((b * F + f) * (int64_t)T + t) * (S * 4) + s * 4 + c], stats[2 * b + 1], stats[2 * b]);
+        spec[i] = v;
+    }
+}
+// out [B, S, 2, L] = (xt [B, L, S * 2] * stdt + meant) + xs [B * S, 2, L]
+__global__ void __launch_bounds__(kNnThreads)
+demucs_mix_out_kernel(const float* __restrict__ xt, const float* __restrict__ statst, const float* __restrict__ xs,
+                      float* __restrict__ out, int64_t n, int S, int64_t L) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int64_t l = i % L;
+        const int ch = (int)((i / L) & 1);
+        const int64_t bs = i / (2 * L);
+        const int64_t b = bs / S;
+        const int s = (int)(bs % S);
+        out[i] = fmaf(xt[(b * L + l) * (S * 2) + s * 2 + ch], statst[2 * b + 1], statst[2 * b]) + xs[i];
+    }
+}
+
+// y [B, L, C] = x [B, C, L]  (and back with the roles of L and C swapped)
+__global__ void __launch_bounds__(kNnThreads)
+nn_swap_last2_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int64_t C, int64_t L) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int64_t c = i % C, l = (i / C) % L, b = i / (C * L);
+        y[i] = x[(b * C + c) * L + l];
+    }
+}
+
+unsigned ew_grid(int64_t n) {
+    int64_t b = ceil_div64(n, kNnThreads);
+    if (b < 1) b = 1;
+    return (unsigned)(b > 65536 ? 65536 : b);
+}
+}  // namespace
+
+#define NN_ARG(cond, what) \
+    if (!(cond)) return alsep_fail(ctx, ALSEP_ERR_ARG, what ": bad argument")
+
+extern "C" int alsep_nn_bgemm(alsep_ctx* ctx, const float* A, const float* B, float* C, int nb1, int nb2, int M, int N, int K,
+                              const int64_t* sa, const int64_t* sb, const int64_t* sc, float alpha) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && A && B && C && sa && sb && sc && nb1 > 0 && nb2 > 0 && M > 0 && N > 0 && K > 0 && (int64_t)nb1 * nb2 <= 65535,
+           "alsep_nn_bgemm");
+    GemmStrides a{sa[0], sa[1], sa[2], sa[3]}, b{sb[0], sb[1], sb[2], sb[3]}, c{sc[0], sc[1], sc[2], sc[3]};
+    hipLaunchKernelGGL(nn_bgemm_kernel, dim3((unsigned)ceil_div64(N, 128), (unsigned)ceil_div64(M, 64), (unsigned)(nb1 * nb2)),
+                       dim3(kNnThreads), 0, ctx->stream, A, B, C, nb2, M, N, K, a, b, c, alpha);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_bgemm_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_softmax_rows(alsep_ctx* ctx, float* x, int64_t rows, int n) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && x && rows > 0 && rows <= 0x7fffffff && n > 0, "alsep_nn_softmax_rows");
+    hipLaunchKernelGGL(nn_softmax_rows_kernel, dim3((unsigned)rows), dim3(kNnThreads), 128, ctx->stream, x, n);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_softmax_rows_kernel");
+    return ALSEP_OK;
+}
+
+static int stats_nb(int64_t per_group, int64_t G) {
+    int64_t nb = ceil_div64(per_group, 32768);
+    if (nb < 1) nb = 1;
+    const int64_t cap = G >= 256 ? 1 : 512 / G;               // enough workgroups for the chip, few partials per group
+    if (nb > cap) nb = cap;
+    return (int)(nb < 1 ? 1 : nb);
+}
+extern "C" int64_t alsep_nn_stats_workspace_bytes(int64_t G, int64_t per_group) {
+    if (G <= 0 || per_group <= 0) return -1;
+    return (int64_t)sizeof(double) * 2 * G * stats_nb(per_group, G) + (int64_t)sizeof(float) * 2 * G + 64;
+}
+
+static int run_stats(alsep_ctx* ctx, const float* x, int64_t G, int64_t per_group, float eps, int mode, void* workspace,
+                     float** stats_out) {
+    const int nb = stats_nb(per_group, G);
+    double* part = reinterpret_cast<double*>(workspace);
+    float* stats = reinterpret_cast<float*>(part + 2 * G * nb);
+    hipLaunchKernelGGL(nn_stats_partial_kernel, dim3((unsigned)nb, (unsigned)G), dim3(kNnThreads), 64, ctx->stream, x, per_group, nb,
+                       part);
+    hipLaunchKernelGGL(nn_stats_final_kernel, dim3((unsigned)ceil_div64(G, 64)), dim3(64), 0, ctx->stream, (const double*)part, nb,
+                       per_group, (int)G, eps, mode, stats);
+    *stats_out = stats;
+    ALSEP_LAUNCH_CHECK(ctx, "nn_stats kernels");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_norm(alsep_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta, int64_t G, int64_t R,
+                             int C, float eps, int act, void* workspace) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && x && y && workspace && G > 0 && G <= 65535 && R > 0 && C > 0 && (act == 0 || act == 3 || (act == 4 && C % 2 == 0)) &&
+               ((gamma == nullptr) == (beta == nullptr)) && ((uintptr_t)workspace & 7) == 0,
+           "alsep_nn_norm");
+    float* stats = nullptr;
+    int rc = run_stats(ctx, x, G, R * C, eps, 0, workspace, &stats);
+    if (rc) return rc;
+    const int64_t n_out = G * R * (act == 4 ? C / 2 : C);
+    hipLaunchKernelGGL(nn_norm_apply_kernel, dim3(ew_grid(n_out)), dim3(kNnThreads), 0, ctx->stream, x, y, gamma, beta,
+                       (const float*)stats, n_out, R, C, act);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_norm_apply_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_meanstd(alsep_ctx* ctx, const float* x, int64_t nsamples, int64_t per_sample, float* stats, void* workspace) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && x && stats && workspace && nsamples > 0 && nsamples <= 65535 && per_sample > 0 && ((uintptr_t)workspace & 7) == 0,
+           "alsep_nn_meanstd");
+    float* st = nullptr;
+    int rc = run_stats(ctx, x, nsamples, per_sample, 0.f, 1, workspace, &st);
+    if (rc) return rc;
+    ALSEP_HIP(ctx, hipMemcpyAsync(stats, st, sizeof(float) * 2 * nsamples, hipMemcpyDeviceToDevice, ctx->stream));
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_affine_stats(alsep_ctx* ctx, const float* x, float* y, const float* stats, int64_t nsamples,
+                                     int64_t per_sample, float eps, int inverse) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && x && y && stats && nsamples > 0 && per_sample > 0, "alsep_nn_affine_stats");
+    const int64_t n = nsamples * per_sample;
+    hipLaunchKernelGGL(nn_affine_stats_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, x, y, stats, n, per_sample, eps,
+                       inverse);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_affine_stats_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_act(alsep_ctx* ctx, const float* x, float* y, int64_t rows, int C, int act) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && x && y && rows > 0 && C > 0 && (act == 1 || act == 3 || (act == 4 && C % 2 == 0)), "alsep_nn_act");
+    const int64_t n_out = rows * (act == 4 ? C / 2 : C);
+    hipLaunchKernelGGL(nn_act_kernel, dim3(ew_grid(n_out)), dim3(kNnThreads), 0, ctx->stream, x, y, n_out, C, act);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_act_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_scale_add(alsep_ctx* ctx, const float* a, const float* b, const float* scale, float* y, int64_t rows, int C) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && a && b && y && rows > 0 && C > 0, "alsep_nn_scale_add");
+    hipLaunchKernelGGL(nn_scale_add_kernel, dim3(ew_grid(rows * C)), dim3(kNnThreads), 0, ctx->stream, a, b, scale, y, rows * C, C);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_scale_add_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_add_bcast(alsep_ctx* ctx, float* y, const float* e, float s, int64_t n, int64_t inner, int period, int C) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && y && e && n > 0 && inner > 0 && period > 0 && C > 0, "alsep_nn_add_bcast");
+    hipLaunchKernelGGL(nn_add_bcast_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, y, e, s, n, inner, period, C);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_add_bcast_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_vec_fma(alsep_ctx* ctx, float* y, const float* x, const float* w, int64_t rows, int64_t n, int64_t y_stride,
+                                int64_t x_stride) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && y && x && w && rows > 0 && n > 0 && y_stride >= n && x_stride >= n, "alsep_nn_vec_fma");
+    hipLaunchKernelGGL(nn_vec_fma_kernel, dim3(ew_grid(rows * n)), dim3(kNnThreads), 0, ctx->stream, y, x, w, rows, n, y_stride,
+                       x_stride);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_vec_fma_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_vec_div(alsep_ctx* ctx, float* y, const float* w, int64_t rows, int64_t n) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && y && w && rows > 0 && n > 0, "alsep_nn_vec_div");
+    hipLaunchKernelGGL(nn_vec_div_kernel, dim3(ew_grid(rows * n)), dim3(kNnThreads), 0, ctx->stream, y, w, rows, n);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_vec_div_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_reflect_pad(alsep_ctx* ctx, const float* x, float* y, int64_t rows, int64_t n, int64_t left, int64_t right) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && x && y && rows > 0 && n > 1 && left >= 0 && right >= 0 && left < n && right < n, "alsep_nn_reflect_pad");
+    hipLaunchKernelGGL(nn_reflect_pad_kernel, dim3(ew_grid(rows * (n + left + right))), dim3(kNnThreads), 0, ctx->stream, x, y, rows, n,
+                       left, right);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_reflect_pad_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_tconv_fold(alsep_ctx* ctx, const float* g, const float* bias, float* y, int64_t B, int I, int J, int Cout,
+                                   int S, int pad, int Lout, int act) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && g && y && B > 0 && I > 0 && J > 0 && Cout > 0 && S > 0 && pad >= 0 && Lout > 0 && Lout + pad <= (I + 1) * S &&
+               (act == 0 || act == 3),
+           "alsep_nn_tconv_fold");
+    const int64_t n = B * Lout * J * Cout;
+    hipLaunchKernelGGL(nn_tconv_fold_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, g, bias, y, n, I, J, Cout, S, pad,
+                       Lout, act);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_tconv_fold_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_demucs_spec_in(alsep_ctx* ctx, const float* spec, float* y, int64_t B, int F, int Tt, int T, int t_off,
+                                    float scale) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && spec && y && B > 0 && F > 0 && T > 0 && t_off >= 0 && t_off + T <= Tt, "alsep_demucs_spec_in");
+    const int64_t n = B * F * T * 4;
+    hipLaunchKernelGGL(demucs_spec_in_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, spec, y, n, F, Tt, T, t_off, scale);
+    ALSEP_LAUNCH_CHECK(ctx, "demucs_spec_in_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_demucs_spec_out(alsep_ctx* ctx, const float* x, const float* stats, float* spec, int64_t B, int S, int F, int Tt,
+                                     int T, int t_off, float scale) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && x && stats && spec && B > 0 && S > 0 && F > 0 && T > 0 && t_off >= 0 && t_off + T <= Tt, "alsep_demucs_spec_out");
+    const int64_t n = B * S * 4 * F * Tt;
+    hipLaunchKernelGGL(demucs_spec_out_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, x, stats, spec, n, S, F, Tt, T, t_off,
+                       scale);
+    ALSEP_LAUNCH_CHECK(ctx, "demucs_spec_out_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_demucs_mix_out(alsep_ctx* ctx, const float* xt, const float* statst, const float* xs, float* out, int64_t B, int S,
+                                    int64_t L) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && xt && statst && xs && out && B > 0 && S > 0 && L > 0, "alsep_demucs_mix_out");
+    const int64_t n = B * S * 2 * L;
+    hipLaunchKernelGGL(demucs_mix_out_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, xt, statst, xs, out, n, S, L);
+    ALSEP_LAUNCH_CHECK(ctx, "demucs_mix_out_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_swap_last2(alsep_ctx* ctx, const float* x, float* y, int64_t B, int64_t C, int64_t L) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && x && y && B > 0 && C > 0 && L > 0, "alsep_nn_swap_last2");
+    hipLaunchKernelGGL(nn_swap_last2_kernel, dim3(ew_grid(B * C * L)), dim3(kNnThreads), 0, ctx->stream, x, y, B * C * L, C, L);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_swap_last2_kernel");
+    return ALSEP_OK;
+}

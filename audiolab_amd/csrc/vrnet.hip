@@ -22,6 +22,7 @@ constexpr int kVrThreads = 256;
 __device__ __forceinline__ float vr_act(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
     if (act == 2) return v > 0.f ? v : 0.01f * v;            // nn.LeakyReLU default slope
+    if (act == 3) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));   // nn.GELU (exact, erf)
     return v;
 }
 
@@ -31,8 +32,8 @@ __device__ __forceinline__ float vr_act(float v, int act) {
 __global__ void __launch_bounds__(kVrThreads)
 vr_conv2d_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                  const float* __restrict__ shift, float* __restrict__ y, int64_t npix, int H, int W, int Cin, int Cout,
-                 int Ho, int Wo, int KH, int KW, int stride, int pad_h, int pad_w, int dil_h, int dil_w, int act, int y_ct,
-                 int y_c0) {
+                 int Ho, int Wo, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int act,
+                 int y_ct, int y_c0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int co0 = blockIdx.y * 64;
@@ -60,7 +61,7 @@ vr_conv2d_kernel(const float* __restrict__ x, const float* __restrict__ w, const
         bool inb[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            const int iy = oy[n] * stride - pad_h + (tap / KW) * dil_h, ix = ox[n] * stride - pad_w + (tap % KW) * dil_w;
+            const int iy = oy[n] * stride_h - pad_h + (tap / KW) * dil_h, ix = ox[n] * stride_w - pad_w + (tap % KW) * dil_w;
             inb[n] = pv[n] && iy >= 0 && iy < H && ix >= 0 && ix < W;
             xp[n] = xb[n] + ((int64_t)(inb[n] ? iy : 0) * W + (inb[n] ? ix : 0)) * Cin;
         }
@@ -252,8 +253,30 @@ extern "C" int alsep_vr_conv2d(alsep_ctx* ctx, const float* x, const float* w, c
     const int64_t gx = ceil_div64(npix, 128);
     if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_vr_conv2d: too many pixels");
     hipLaunchKernelGGL(vr_conv2d_kernel, dim3((unsigned)gx, (unsigned)((Cout + 63) / 64)), dim3(kVrThreads), 0, ctx->stream, x, w,
-                       scale, shift, y, npix, H, W, Cin, Cout, Ho, Wo, KH, KW, stride, pad_h, pad_w, dil_h, dil_w, act, y_ctotal, y_coff);
+                       scale, shift, y, npix, H, W, Cin, Cout, Ho, Wo, KH, KW, stride, stride, pad_h, pad_w, dil_h, dil_w, act, y_ctotal, y_coff);
     ALSEP_LAUNCH_CHECK(ctx, "vr_conv2d_kernel");
+    return ALSEP_OK;
+}
+
+// The same kernel with a stride per axis and GELU among the activations: Conv1d / Conv2d([K,1], [S,1]) / 1x1 / 3x3 layers of the
+// Demucs family (a Conv1d over [B, L, C] is the W = 1 case; a Linear is the 1x1 case with the rows as pixels).
+extern "C" int alsep_nn_conv2d(alsep_ctx* ctx, const float* x, const float* w, const float* scale, const float* shift, float* y,
+                               int64_t B, int H, int W, int Cin, int Cout, int KH, int KW, int stride_h, int stride_w, int pad_h,
+                               int pad_w, int dil_h, int dil_w, int act, int y_ctotal, int y_coff) {
+    ALSEP_ENTER(ctx);
+    if (!ctx || !x || !w || !scale || !shift || !y) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d: null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride_h <= 0 || stride_w <= 0 || pad_h < 0 ||
+        pad_w < 0 || dil_h <= 0 || dil_w <= 0 || act < 0 || act > 3 || y_coff < 0 || y_coff + Cout > y_ctotal)
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d: bad shape");
+    const int Ho = (H + 2 * pad_h - dil_h * (KH - 1) - 1) / stride_h + 1, Wo = (W + 2 * pad_w - dil_w * (KW - 1) - 1) / stride_w + 1;
+    if (Ho <= 0 || Wo <= 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d: empty output");
+    const int64_t npix = B * Ho * Wo;
+    const int64_t gx = ceil_div64(npix, 128);
+    if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d: too many pixels");
+    hipLaunchKernelGGL(vr_conv2d_kernel, dim3((unsigned)gx, (unsigned)((Cout + 63) / 64)), dim3(kVrThreads), 0, ctx->stream, x, w,
+                       scale, shift, y, npix, H, W, Cin, Cout, Ho, Wo, KH, KW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, act,
+                       y_ctotal, y_coff);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_conv2d_kernel");
     return ALSEP_OK;
 }
 

@@ -64,3 +64,11 @@ def all_gather_segments(local: torch.Tensor, n_win: int, gen: int, n_sample: int
         work = dist.all_gather(list(recv.unbind(0)), send.contiguous(), group=group, async_op=async_op)
     pending = PendingGather(work if async_op else None, recv, ranges, lead, n_sample)
     return pending if async_op else pending.result()
+
+
+def all_reduce_partial(acc: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """Sum of the ranks' weighted partial overlap-add accumulators (Demucs segments with triangular weights, Hann-windowed
+    MDX chunks): every rank holds the units of a contiguous range, so only the seam regions carry more than one non-zero
+    contribution; one collective (ncclAllReduce on RCCL, gloo in tests)."""
+    dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    return acc

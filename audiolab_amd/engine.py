@@ -37,6 +37,7 @@ from . import _lib, wavio
 from ._lib import AlsepError, Context
 from .mdx import Predictor
 from .synth import synthetic_state_dict
+from .htdemucs import DemucsRunner, HTDemucs, HTDemucsConfig
 from .tdfnet import TDFNet, TDFNetConfig
 
 logger = logging.getLogger(__name__)
@@ -66,6 +67,8 @@ MODEL_ROSTER: Dict[str, tuple] = {
     "kuielab_a_drums.onnx": ("Drums", "No Drums", _cfg(4096, 2048, 128), {"compensate": 1.035}),
     "kuielab_a_bass.onnx": ("Bass", "No Bass", _cfg(16384, 2048, 512), {"compensate": 1.035}),
     "kuielab_a_other.onnx": ("Other", "No Other", _cfg(8192, 2048, 512), {"compensate": 1.035}),
+    # the multi-stem stage (stem_separator.py:466): HTDemucs 6 sources on the full mix; DemucsSeparator defaults shifts 2, overlap 0.25
+    "htdemucs_6s.yaml": ("demucs", HTDemucsConfig(), {"shifts": 2, "overlap": 0.25}),
 }
 # BASELINE configs[1] "MDX-Net UVR 4-stem": four single-target networks of the in-tree geometry (mdxnet.py:247-251:
 # dim_f 3072, n_fft 6144) -- the bench workload; never reached by a file name of the reference
@@ -86,6 +89,7 @@ class _ModelInstance:
         self.output_dir = None
         self.model_run = net                                  # callable(spek) -> pred, the patch_separate seam
         self.extra: List[tuple] = []                          # multi-stem models: further (label, net, predictor)
+        self.demucs: Optional[DemucsRunner] = None            # Demucs-family model: one network, all sources at once
 
 
 class Separator:
@@ -145,6 +149,9 @@ class Separator:
         if model_filename not in self.roster:
             raise AlsepError(f"model '{model_filename}' is not available in this build (MDX-Net roster: {sorted(self.roster)})")
         entry = self.roster[model_filename]
+        if entry[0] == "demucs":
+            self._load_demucs(model_filename, entry)
+            return
         meta = entry[3] if len(entry) > 3 and entry[0] != "multi" else {}
         entry = entry[:3]
         provenance = []
@@ -201,6 +208,31 @@ class Separator:
         self._cache[model_filename] = inst
         self.model_instance = inst
 
+    def _load_demucs(self, model_filename: str, entry: tuple) -> None:
+        """("demucs", HTDemucsConfig, {shifts, overlap}): weights from ``<model_file_dir>/<name>.pt`` (a state_dict with demucs'
+        parameter names) or, with allow_synthetic, seeded random-init ones.  float32 (the kernels of this family are fp32)."""
+        cfg = entry[1]
+        opts = entry[2] if len(entry) > 2 else {}
+        pt = os.path.join(self.model_file_dir, model_filename + ".pt")
+        if os.path.exists(pt):
+            sd, weights = torch.load(pt, map_location="cpu", weights_only=True), "real"
+        elif self.allow_synthetic:
+            from .htdemucs import synthetic_state_dict as demucs_synth
+            seed = int.from_bytes(hashlib.sha256(model_filename.encode()).digest()[:4], "little")
+            sd, weights = demucs_synth(cfg, seed=seed), "synthetic"
+            logger.warning("%s: no weight file under %s -- SYNTHETIC random-init weights (allow_synthetic=True)", model_filename,
+                           self.model_file_dir)
+        else:
+            raise AlsepError(f"model '{model_filename}': no weight file ({pt}); random-init weights are only used with "
+                             f"Separator(allow_synthetic=True)")
+        net = HTDemucs(cfg, sd, ctx=self.ctx)
+        inst = _ModelInstance(model_filename, net, None, cfg.sources[0].capitalize(), None)
+        inst.demucs = DemucsRunner(net, shifts=int(opts.get("shifts", 2)), overlap=float(opts.get("overlap", 0.25)), sharded=self.sharded)
+        inst.output_dir = self.output_dir
+        inst.weights = weights
+        self._cache[model_filename] = inst
+        self.model_instance = inst
+
     # -- inference --------------------------------------------------------------------------------
     def separate_array(self, mix) -> Dict[str, torch.Tensor]:
         """mix [C,N] (numpy or tensor) -> {stem label: [C,N] device tensor}.  Mono is duplicated to stereo (and comes
@@ -228,6 +260,8 @@ class Separator:
     def _separate_pair(self, m: torch.Tensor) -> Dict[str, torch.Tensor]:
         m = m.to(self.ctx.device).contiguous()
         inst = self.model_instance
+        if inst.demucs is not None:                             # all sources from one pass; labels as DemucsSeparator names its files
+            return {name.capitalize(): t for name, t in inst.demucs.separate(m).items()}
         primary = inst.predictor.demix(m)
         if primary.dim() == 3:                                  # Predictor returns [1,2,N] like the reference
             primary = primary[0]

@@ -203,6 +203,59 @@ int alsep_vr_mean_h(alsep_ctx* ctx, const float* x, float* y, int64_t B, int H, 
 int alsep_vr_mask(alsep_ctx* ctx, const float* logit, const float* mix, float* out, int64_t B, int Hm, int Hout, int W, int C,
                   int split_bin, float aggressiveness);
 
+/* ---- Demucs family (HTDemucs: what audio_separator's DemucsSeparator runs for htdemucs_6s.yaml, loaded at
+ * modules/separator/stem_separator.py:466 and run at :479; network source in the un-vendored demucs>=4.0.1, requirements.txt:19 --
+ * PARITY UNPINNED).  Generic channels-last float32 building blocks; activations: 0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 GELU (erf),
+ * 4 GLU over the channel axis (C -> C/2; norm / act only). ---- */
+/* alsep_vr_conv2d with a stride per axis and GELU: Conv1d over [B,L,C] is the W = 1 case, a Linear the 1x1 case */
+int alsep_nn_conv2d(alsep_ctx* ctx, const float* x, const float* w, const float* scale, const float* shift, float* y, int64_t B, int H,
+                    int W, int Cin, int Cout, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                    int act, int y_ctotal, int y_coff);
+/* C[b1,b2][m][n] = alpha * sum_k A[b1,b2][m][k] B[b1,b2][n][k]; sa / sb / sc = element strides {b1, b2, row, k-or-column} (the
+ * attention products of nn.MultiheadAttention straight from the packed in-projection, no head transposes) */
+int alsep_nn_bgemm(alsep_ctx* ctx, const float* A, const float* B, float* C, int nb1, int nb2, int M, int N, int K, const int64_t* sa,
+                   const int64_t* sb, const int64_t* sc, float alpha);
+/* softmax over the last dimension of x [rows, n], in place */
+int alsep_nn_softmax_rows(alsep_ctx* ctx, float* x, int64_t rows, int n);
+/* bytes of device scratch (8-byte aligned) for alsep_nn_norm / alsep_nn_meanstd over G groups of per_group elements */
+int64_t alsep_nn_stats_workspace_bytes(int64_t G, int64_t per_group);
+/* x [G, R, C]: normalise every group of R rows x C channels to zero mean / unit (biased) variance, y = act(n * gamma[c] + beta[c]):
+ * nn.GroupNorm(1, C) (R = positions of one sample), nn.LayerNorm(C) (R = 1), demucs MyGroupNorm (R = tokens).  gamma / beta may
+ * both be NULL.  act 0, 3 or 4. */
+int alsep_nn_norm(alsep_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta, int64_t G, int64_t R, int C, float eps,
+                  int act, void* workspace);
+/* stats[2 s] = mean, stats[2 s + 1] = UNBIASED std of sample s (HTDemucs.forward: mean / std of the whole spectrogram / waveform) */
+int alsep_nn_meanstd(alsep_ctx* ctx, const float* x, int64_t nsamples, int64_t per_sample, float* stats, void* workspace);
+/* inverse 0: y = (x - mean) / (eps + std); inverse 1: y = x * std + mean */
+int alsep_nn_affine_stats(alsep_ctx* ctx, const float* x, float* y, const float* stats, int64_t nsamples, int64_t per_sample, float eps,
+                          int inverse);
+/* y = act(x) over x [rows, C]; act 1, 3 or 4 */
+int alsep_nn_act(alsep_ctx* ctx, const float* x, float* y, int64_t rows, int C, int act);
+/* y = a + scale[c] * b (LayerScale residual; scale NULL: plain add) */
+int alsep_nn_scale_add(alsep_ctx* ctx, const float* a, const float* b, const float* scale, float* y, int64_t rows, int C);
+/* y[i] += s * e[((i / inner) % period) * C + i % C]: frequency embedding over [B,F,T,C] (inner = T*C, period = F), positional
+ * embedding over [B,N,C] (inner = C, period = N) */
+int alsep_nn_add_bcast(alsep_ctx* ctx, float* y, const float* e, float s, int64_t n, int64_t inner, int period, int C);
+/* y[r * y_stride + i] += w[i] * x[r * x_stride + i], i < n (triangular overlap-add of demucs.apply.apply_model);  y[r][i] /= w[i] */
+int alsep_nn_vec_fma(alsep_ctx* ctx, float* y, const float* x, const float* w, int64_t rows, int64_t n, int64_t y_stride, int64_t x_stride);
+int alsep_nn_vec_div(alsep_ctx* ctx, float* y, const float* w, int64_t rows, int64_t n);
+/* y [B, L, C] = x [B, C, L] (waveform [B,2,L] <-> channels-last [B,L,2]) */
+int alsep_nn_swap_last2(alsep_ctx* ctx, const float* x, float* y, int64_t B, int64_t C, int64_t L);
+/* F.pad(mode="reflect") along the last axis: [rows, n] -> [rows, left + n + right] */
+int alsep_nn_reflect_pad(alsep_ctx* ctx, const float* x, float* y, int64_t rows, int64_t n, int64_t left, int64_t right);
+/* second half of ConvTranspose([K,1], stride [S,1]), K = 2 S: g [B, I, J, K*Cout] = 1x1 conv of the input with the weights packed
+ * [Cin][k*Cout + co]; y [B, Lout, J, Cout] = act(g[i][r] + g[i-1][r+S] + bias), o + pad = i S + r (the crop of HDecLayer.forward) */
+int alsep_nn_tconv_fold(alsep_ctx* ctx, const float* g, const float* bias, float* y, int64_t B, int I, int J, int Cout, int S, int pad,
+                        int Lout, int act);
+/* spec [B,4,F,Tt] (alsep_stft, reference layout) -> y [B,F,T,4] = scale * spec[..., t_off : t_off + T]   (HTDemucs._spec/_magnitude) */
+int alsep_demucs_spec_in(alsep_ctx* ctx, const float* spec, float* y, int64_t B, int F, int Tt, int T, int t_off, float scale);
+/* x [B,F,T,S*4] (normalised output), stats of the input spectrogram -> spec [B*S,4,F,Tt]: frames [t_off, t_off+T) =
+ * scale * (x * std + mean), the rest zero   (HTDemucs._mask with cac + the frame padding of _ispec) */
+int alsep_demucs_spec_out(alsep_ctx* ctx, const float* x, const float* stats, float* spec, int64_t B, int S, int F, int Tt, int T,
+                          int t_off, float scale);
+/* out [B,S,2,L] = (xt [B,L,S*2] * stdt + meant) + xs [B*S,2,L]   (the last lines of HTDemucs.forward) */
+int alsep_demucs_mix_out(alsep_ctx* ctx, const float* xt, const float* statst, const float* xs, float* out, int64_t B, int S, int64_t L);
+
 #ifdef __cplusplus
 }
 #endif
