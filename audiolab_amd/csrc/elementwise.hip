@@ -147,6 +147,48 @@ ola_combine_kernel(const float* __restrict__ chunks, int64_t n_chunks, int64_t c
     }
 }
 
+// Sharded form of ola_combine: `chunks` holds only the chunks [b0, b1) of this rank; part [3][n_out] receives the RAW weighted sums
+// of both channels and the summed weights over those chunks (zero where none of them covers).  The ranks' parts are summed by one
+// collective and divided afterwards: at a shard seam the chunks of two ranks overlap.
+__global__ void __launch_bounds__(kThreads)
+ola_partial_kernel(const float* __restrict__ chunks, int64_t b0, int64_t b1, int64_t chunk, int64_t step, int64_t total,
+                   int use_window, float* __restrict__ part, int64_t p_lo, int64_t n_out) {
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_out; i += stride) {
+        const int64_t p = p_lo + i;
+        int64_t b_hi = p / step;
+        if (b_hi > b1 - 1) b_hi = b1 - 1;
+        int64_t b_lo = (p - chunk + step) / step;
+        if (p - chunk + 1 <= 0) b_lo = 0;
+        if (b_lo < b0) b_lo = b0;
+        float accl = 0.f, accr = 0.f, div = 0.f;
+        for (int64_t b = b_lo; b <= b_hi; ++b) {
+            const int64_t start = b * step, j = p - start;
+            int64_t n_act = total - start;
+            if (n_act > chunk) n_act = chunk;
+            if (j < 0 || j >= n_act) continue;
+            float w = 1.f;
+            if (use_window) w = n_act > 1 ? 0.5f - 0.5f * cosf(6.28318530717958647692f * (float)j / (float)(n_act - 1)) : 1.f;
+            accl += w * chunks[((b - b0) * 2 + 0) * chunk + j];
+            accr += w * chunks[((b - b0) * 2 + 1) * chunk + j];
+            div += w;
+        }
+        part[i] = accl;
+        part[n_out + i] = accr;
+        part[2 * n_out + i] = div;
+    }
+}
+// out[c][i] = gain * part[c][i] / part[2][i]
+__global__ void __launch_bounds__(kThreads)
+ola_finish_kernel(const float* __restrict__ part, float gain, float* __restrict__ out, int64_t out_stride, int64_t n_out) {
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_out; i += stride) {
+        const float d = part[2 * n_out + i];
+        out[i] = gain * (part[i] / d);
+        out[out_stride + i] = gain * (part[n_out + i] / d);
+    }
+}
+
 // zero the lowest `nbins` frequency bins of a spectrogram (MDXSeparator.run_model: spek[:, :, :3, :] *= 0)
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
@@ -295,6 +337,27 @@ extern "C" int alsep_ola_combine(alsep_ctx* ctx, const float* chunks, int64_t n_
     hipLaunchKernelGGL(ola_combine_kernel, dim3(grid_for(n_out, 2)), dim3(kThreads), 0, ctx->stream, chunks, n_chunks, chunk,
                        step, total, use_window, gain, out, out_stride, p_lo, n_out);
     ALSEP_LAUNCH_CHECK(ctx, "ola_combine_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_ola_partial(alsep_ctx* ctx, const float* chunks, int64_t b0, int64_t b1, int64_t chunk, int64_t step,
+                                 int64_t total, int use_window, float* part, int64_t p_lo, int64_t n_out) {
+    ALSEP_ENTER(ctx);
+    if (!ctx || !part || b0 < 0 || b1 < b0 || (b1 > b0 && !chunks) || chunk <= 0 || step <= 0 || step > chunk || total <= 0 ||
+        p_lo < 0 || n_out < 0 || p_lo + n_out > total)
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_ola_partial: bad argument");
+    if (n_out == 0) return ALSEP_OK;
+    hipLaunchKernelGGL(ola_partial_kernel, dim3(grid_for(n_out, 2)), dim3(kThreads), 0, ctx->stream, chunks, b0, b1, chunk, step,
+                       total, use_window, part, p_lo, n_out);
+    ALSEP_LAUNCH_CHECK(ctx, "ola_partial_kernel");
+    return ALSEP_OK;
+}
+extern "C" int alsep_ola_finish(alsep_ctx* ctx, const float* part, float gain, float* out, int64_t out_stride, int64_t n_out) {
+    ALSEP_ENTER(ctx);
+    if (!ctx || !part || !out || n_out < 0 || out_stride < n_out) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_ola_finish: bad argument");
+    if (n_out == 0) return ALSEP_OK;
+    hipLaunchKernelGGL(ola_finish_kernel, dim3(grid_for(n_out, 2)), dim3(kThreads), 0, ctx->stream, part, gain, out, out_stride, n_out);
+    ALSEP_LAUNCH_CHECK(ctx, "ola_finish_kernel");
     return ALSEP_OK;
 }
 

@@ -192,7 +192,7 @@ class Separator:
                 from .mdx import OlaRunner
                 comp = self.compensate if self.compensate is not None else float(meta.get("compensate", 1.0))
                 pred = OlaRunner(net, ctx=self.ctx, overlap=self.overlap, compensate=comp, denoise=self.denoise,
-                                 max_batch=self.max_batch)
+                                 max_batch=self.max_batch, sharded=self.sharded)
             else:
                 pred = Predictor(args, net, ctx=self.ctx, hop=cfg.hop, sharded=self.sharded)
             return net, pred

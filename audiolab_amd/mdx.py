@@ -278,7 +278,11 @@ class OlaRunner:
     weighted by np.hanning, summed, divided by the summed weights, and scaled by ``compensate``."""
 
     def __init__(self, net, ctx: Optional[Context] = None, overlap: float = 0.25, zero_low_bins: int = 3,
-                 compensate: float = 1.0, denoise: bool = False, max_batch: int = 8):
+                 compensate: float = 1.0, denoise: bool = False, max_batch: int = 8, sharded: bool = False, group=None):
+        """``sharded=True``: the chunks are split into contiguous ranges over the ranks of ``group`` (torch.distributed); every
+        rank accumulates the weighted sums of its chunks, ONE all-reduce adds the parts (chunks of neighbouring ranks overlap at
+        the shard seams), the division by the summed window weights happens afterwards on every rank."""
+        self.sharded, self.group = sharded, group
         self.net = net
         self.ctx = ctx if ctx is not None else net.ctx
         cfg = net.cfg
@@ -299,19 +303,32 @@ class OlaRunner:
         buf_len = (n_chunks - 1) * step + chunk              # chunks cut by the end see zeros
         mixture = ctx.zeros((2, buf_len), torch.float32)
         mixture[:, trim:trim + n] = mix
-        waves = ctx.empty((n_chunks, 2, chunk), torch.float32)
-        bstep = self.max_batch if self.max_batch > 0 else n_chunks
-        for b0 in range(0, n_chunks, bstep):
-            nb = min(bstep, n_chunks - b0)
+        c_lo, c_hi = 0, n_chunks
+        if self.sharded:
+            import torch.distributed as tdist
+            from . import dist as adist
+            c_lo, c_hi = adist.window_range(n_chunks, tdist.get_world_size(self.group), tdist.get_rank(self.group))
+        n_local = c_hi - c_lo
+        waves = ctx.empty((max(n_local, 1), 2, chunk), torch.float32)
+        bstep = self.max_batch if self.max_batch > 0 else max(n_local, 1)
+        for b0 in range(c_lo, c_hi, bstep):
+            nb = min(bstep, c_hi - b0)
             spek = plan.stft_strided(mixture, buf_len, step, nb, self.net.dtype, _lib.LAYOUT_NHWC, pcm_offset=b0 * step)
             if self.zero_low_bins:
                 ctx.check(ctx.lib.alsep_zero_low_bins(ctx.handle, _lib.ptr(spek), _lib.dtype_code(spek.dtype), _lib.LAYOUT_NHWC,
                                                       nb, plan.dim_f, plan.dim_t, self.zero_low_bins), "alsep_zero_low_bins")
             pred = self.net.forward_nhwc(spek, denoise=self.denoise)
             plan.istft_strided(pred, _lib.LAYOUT_NHWC, waves, chunk, 2 * chunk, 0, chunk, (nb - 1) * 2 * chunk + chunk,
-                               out_offset=b0 * 2 * chunk)
+                               out_offset=(b0 - c_lo) * 2 * chunk)
         out = ctx.empty((2, n), torch.float32)
-        ctx.check(ctx.lib.alsep_ola_combine(ctx.handle, _lib.ptr(waves), n_chunks, chunk, step, total,
-                                            1 if self.overlap != 0 else 0, float(self.compensate), _lib.ptr(out), n, trim, n),
-                  "alsep_ola_combine")
+        use_window = 1 if self.overlap != 0 else 0
+        if not self.sharded:
+            ctx.check(ctx.lib.alsep_ola_combine(ctx.handle, _lib.ptr(waves), n_chunks, chunk, step, total, use_window,
+                                                float(self.compensate), _lib.ptr(out), n, trim, n), "alsep_ola_combine")
+            return out
+        part = ctx.empty((3, n), torch.float32)
+        ctx.check(ctx.lib.alsep_ola_partial(ctx.handle, _lib.ptr(waves), c_lo, c_hi, chunk, step, total, use_window, _lib.ptr(part),
+                                            trim, n), "alsep_ola_partial")
+        part = adist.all_reduce_partial(part, self.group)
+        ctx.check(ctx.lib.alsep_ola_finish(ctx.handle, _lib.ptr(part), float(self.compensate), _lib.ptr(out), n, n), "alsep_ola_finish")
         return out

@@ -109,6 +109,12 @@ int alsep_istft(alsep_ctx* ctx, const alsep_plan* plan, const void* spec, int dt
 int alsep_ola_combine(alsep_ctx* ctx, const float* chunks, int64_t n_chunks, int64_t chunk, int64_t step,
                       int64_t total, int use_window, float gain, float* out, int64_t out_stride, int64_t p_lo,
                       int64_t n_out);
+/* The same overlap-add split over the ranks of a job: `chunks` holds only the chunks [b0, b1) of this rank; part [3][n_out] =
+ * raw weighted sums of the two channels and the summed weights over those chunks.  The ranks' parts are SUMMED by one collective (at a
+ * shard seam chunks of two ranks overlap), then alsep_ola_finish divides: out[c][i] = gain * part[c][i] / part[2][i]. */
+int alsep_ola_partial(alsep_ctx* ctx, const float* chunks, int64_t b0, int64_t b1, int64_t chunk, int64_t step, int64_t total,
+                      int use_window, float* part, int64_t p_lo, int64_t n_out);
+int alsep_ola_finish(alsep_ctx* ctx, const float* part, float gain, float* out, int64_t out_stride, int64_t n_out);
 /* zero the lowest nbins bins of a spectrogram in place (MDXSeparator.run_model zeroes bins 0..2). */
 int alsep_zero_low_bins(alsep_ctx* ctx, void* spec, int dtype, int layout, int64_t B, int64_t dim_f, int64_t T,
                         int nbins);

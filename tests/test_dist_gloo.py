@@ -69,3 +69,60 @@ def test_sharded_demix_world2_gloo(emul_lib_path, tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), emul_lib_path, out_path), nprocs=2, join=True)
     err = float(np.load(out_path)[0])
     assert err < 1e-5
+
+
+def _worker_ola_demucs(rank, world, port, emul_so, out_path):
+    """world-2 over gloo: (1) Hann overlap-add MDX runner at overlap 0.75 with the chunks sharded and the seam sums exchanged;
+    (2) the HTDemucs runner with its (shift, segment) units sharded.  Both against the single-process oracle."""
+    import dataclasses
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from audiolab_amd import _lib
+    _lib._LIB = _lib.bind(emul_so)
+    _lib.DEVICE_TYPE = "cpu"
+    ctx = _lib.Context("cpu")
+    from audiolab_amd.htdemucs import DemucsRunner, HTDemucs, HTDemucsConfig
+    from audiolab_amd.mdx import OlaRunner
+    from audiolab_amd.synth import synthetic_state_dict
+    from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
+    from oracle import htdemucs_oracle as ho
+    from oracle import mdx_oracle as mo
+    from oracle import tdfnet_oracle
+    from oracle.toy import synth_mix
+    errs = []
+    cfg = TDFNetConfig(dim_f=64, dim_t=32, n_fft=256, hop=64, num_blocks=3, g=16)
+    sd = synthetic_state_dict(cfg, seed=3)
+    net = TDFNet(cfg, sd, ctx=ctx, dtype=torch.float32, max_batch=2)
+    mix = synth_mix(4000, seed=31)
+    got = OlaRunner(net, ctx=ctx, overlap=0.75, compensate=1.02, max_batch=2, sharded=True).demix(torch.from_numpy(mix)).numpy()
+    g = mo.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
+
+    def run(spek):
+        return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)), cfg.num_blocks, cfg.l, cfg.bn).numpy()
+    want = mo.demix_ola(mix, g, run, overlap=0.75, denoise=False, zero_low_bins=3, compensate=1.02)
+    errs.append(float(np.max(np.abs(got - want))))
+    ocfg = ho.HTDemucsConfig(sources=("drums", "bass"), channels=16, nfft=256, depth=2, dconv_comp=4, bottom_channels=32, t_layers=2,
+                             t_heads=4, segment_samples=2560, samplerate=4000)
+    hsd = ho.synthetic_state_dict(ocfg, 5)
+    hnet = HTDemucs(HTDemucsConfig(**dataclasses.asdict(ocfg)), hsd, ctx=ctx)
+    hm = torch.randn(2, 5000, generator=torch.Generator().manual_seed(8)) * 0.2
+    out = DemucsRunner(hnet, shifts=1, overlap=0.25, seed=0, sharded=True).separate(hm)
+    hw = ho.separate(ocfg, hsd, hm, shifts=1, overlap=0.25, seed=0).numpy()
+    errs.append(float(max(np.max(np.abs(out[k].numpy() - hw[i])) for i, k in enumerate(ocfg.sources))))
+    res = torch.tensor(errs)
+    dist.all_reduce(res, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        np.save(out_path, res.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_ola_and_demucs_world2_gloo(emul_lib_path, tmp_path):
+    out_path = str(tmp_path / "err2.npy")
+    mp.spawn(_worker_ola_demucs, args=(2, _free_port(), emul_lib_path, out_path), nprocs=2, join=True)
+    errs = np.load(out_path)
+    assert errs[0] < 1e-4, f"sharded Hann overlap-add: {errs[0]:.3e}"
+    assert errs[1] < 1e-4, f"sharded Demucs runner: {errs[1]:.3e}"
