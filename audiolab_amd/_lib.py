@@ -64,6 +64,8 @@ _SIGNATURES = {
                                     C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
     "alsep_ola_partial": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int64] * 5 + [C.c_int, C.c_void_p, C.c_int64, C.c_int64]),
     "alsep_ola_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int64]),
+    "alsep_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                 C.c_float, C.c_float]),
     "alsep_zero_low_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int]),
     "alsep_net_create": (C.c_int, [C.c_void_p, C.POINTER(NetConfig), C.POINTER(TensorEntry), C.c_int64,
                                    C.POINTER(C.c_void_p)]),

@@ -189,6 +189,43 @@ ola_finish_kernel(const float* __restrict__ part, float gain, float* __restrict_
     }
 }
 
+// Band-limited sample-rate conversion by a Kaiser-windowed sinc (what librosa.load(sr=44100) does to a 48 kHz input at
+// stem_separator.py:865 -- there with libsoxr, a dependency that is not in /root/reference: the filter below is this build's own,
+// PARITY UNPINNED).  y[r][m] = sum_n x[r][n] h(m / ratio - n), h(t) = fc sinc(fc t) kaiser(t / hw; beta), fc = min(1, ratio) * rolloff,
+// support |t| <= hw = zeros / fc input samples.  Positions in fp64 (a 60-minute track has 1.7e8 samples).
+__device__ __forceinline__ double bessel_i0(double x) {
+    double s = 1.0, t = 1.0;
+    const double q = x * x * 0.25;
+    for (int k = 1; k < 40; ++k) {
+        t *= q / ((double)k * (double)k);
+        s += t;
+        if (t < 1e-17 * s) break;
+    }
+    return s;
+}
+__global__ void __launch_bounds__(kThreads)
+resample_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int64_t n_in, int64_t n_out, double ratio,
+                double fc, double hw, double beta, double inv_i0_beta) {
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < rows * n_out; i += stride) {
+        const int64_t r = i / n_out, m = i % n_out;
+        const double t = (double)m / ratio;
+        int64_t lo = (int64_t)ceil(t - hw), hi = (int64_t)floor(t + hw);
+        if (lo < 0) lo = 0;
+        if (hi > n_in - 1) hi = n_in - 1;
+        const float* xr = x + r * n_in;
+        double acc = 0.0;
+        for (int64_t n = lo; n <= hi; ++n) {
+            const double d = t - (double)n, u = d / hw;
+            const double a = 3.14159265358979323846 * fc * d;
+            const double sinc = fabs(a) < 1e-12 ? 1.0 : sin(a) / a;
+            const double w = bessel_i0(beta * sqrt(fmax(0.0, 1.0 - u * u))) * inv_i0_beta;
+            acc += (double)xr[n] * fc * sinc * w;
+        }
+        y[i] = (float)acc;
+    }
+}
+
 // zero the lowest `nbins` frequency bins of a spectrogram (MDXSeparator.run_model: spek[:, :, :3, :] *= 0)
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
@@ -358,6 +395,22 @@ extern "C" int alsep_ola_finish(alsep_ctx* ctx, const float* part, float gain, f
     if (n_out == 0) return ALSEP_OK;
     hipLaunchKernelGGL(ola_finish_kernel, dim3(grid_for(n_out, 2)), dim3(kThreads), 0, ctx->stream, part, gain, out, out_stride, n_out);
     ALSEP_LAUNCH_CHECK(ctx, "ola_finish_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_resample(alsep_ctx* ctx, const float* x, float* y, int64_t rows, int64_t n_in, int64_t n_out, int sr_in,
+                              int sr_out, int zeros, float rolloff, float beta) {
+    ALSEP_ENTER(ctx);
+    if (!ctx || !x || !y || rows <= 0 || n_in <= 0 || n_out <= 0 || sr_in <= 0 || sr_out <= 0 || zeros < 1 || zeros > 512 ||
+        !(rolloff > 0.f && rolloff <= 1.f) || beta < 0.f)
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_resample: bad argument");
+    const double ratio = (double)sr_out / (double)sr_in;
+    const double fc = (ratio < 1.0 ? ratio : 1.0) * (double)rolloff, hw = (double)zeros / fc;
+    double i0 = 1.0, t = 1.0;                                 // I0(beta) on the host
+    for (int k = 1; k < 60; ++k) { t *= ((double)beta * beta * 0.25) / ((double)k * k); i0 += t; }
+    hipLaunchKernelGGL(resample_kernel, dim3(grid_for(rows * n_out, 1)), dim3(kThreads), 0, ctx->stream, x, y, rows, n_in, n_out, ratio,
+                       fc, hw, (double)beta, 1.0 / i0);
+    ALSEP_LAUNCH_CHECK(ctx, "resample_kernel");
     return ALSEP_OK;
 }
 

@@ -282,8 +282,10 @@ class Separator:
         if self.model_instance is None:
             raise AlsepError("load_model() first")
         audio, sr = wavio.read_wav(audio_file_path)
-        if sr != self.sample_rate:
-            raise AlsepError(f"{audio_file_path}: sample rate {sr} != {self.sample_rate} (resampling is out of scope)")
+        if sr != self.sample_rate:                              # the models run at 44.1 kHz: resample as the reference's loader does
+            from . import ensemble
+            audio = ensemble.resample(self.ctx, torch.from_numpy(audio).to(self.ctx.device), sr, self.sample_rate)
+            sr = self.sample_rate
         stems = self.separate_array(audio)
         out_dir = self.model_instance.output_dir or self.output_dir or os.path.dirname(audio_file_path)
         os.makedirs(out_dir, exist_ok=True)

@@ -147,3 +147,17 @@ def debleed(ctx: Context, mix: torch.Tensor, vocals: torch.Tensor, instrumental:
             resid = z
         out = resid
     return out, accepted
+
+
+def resample(ctx: Context, x: torch.Tensor, sr_in: int, sr_out: int, zeros: int = 32, rolloff: float = 0.95, beta: float = 12.0) -> torch.Tensor:
+    """[C, N] at sr_in -> [C, ceil(N * sr_out / sr_in)] at sr_out on the device (the resampling librosa.load(sr=44100) applies to a
+    non-44.1 kHz input, stem_separator.py:865; own Kaiser-windowed sinc, see alsep_resample)."""
+    if sr_in == sr_out:
+        return x
+    x = _flat(x)
+    rows, n_in = x.shape
+    n_out = -(-n_in * sr_out // sr_in)
+    y = ctx.empty((rows, n_out))
+    ctx.check(ctx.lib.alsep_resample(ctx.handle, _lib.ptr(x), _lib.ptr(y), rows, n_in, n_out, sr_in, sr_out, zeros, rolloff, beta),
+              "alsep_resample")
+    return y

@@ -363,11 +363,12 @@ def predict_with_model(options: Dict, callback: Callable = None, separator: Opti
             if not os.path.isfile(ip):
                 continue
             audio, sr = wavio.read_wav(ensure_wav(ip))
-            if sr != 44100:
-                raise RuntimeError(f"{ip}: {sr} Hz input needs resampling to 44.1 kHz (librosa.load(sr=44100), :865) -- out of scope")
             if audio.shape[0] == 1:
                 audio = np.concatenate([audio, audio])
             mix = torch.from_numpy(audio[:2].copy()).to(model.ctx.device)
+            if sr != 44100:                                      # librosa.load(wav_path, sr=44100, mono=False), :865
+                mix = ensemble.resample(model.ctx, mix, sr, 44100)
+                sr = 44100
             files_data.append({"base_name": os.path.splitext(os.path.basename(ip))[0], "mix": mix, "sr": sr,
                                "output_folder": out_folder})
     if not files_data:

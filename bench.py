@@ -148,6 +148,108 @@ def cpu_baseline(cfg, sd, mix_np, n_windows: int):
                       f"median of {reps} run(s): {dt:.1f} s wall"}
 
 
+def other_workload(args) -> None:
+    """Supplementary bench lines for BASELINE configs[2] / [3] / [4] (same JSON shape; no per-kernel roofline: these runs exist to
+    put a measured number and the multi-GPU structure next to each config, the graded line is the mdx4 default)."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU; there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from audiolab_amd import _lib
+    from audiolab_amd.engine import Separator
+    from audiolab_amd.synth import synth_mix
+    device = torch.device("cuda", local_rank)
+    ctx = _lib.Context(device)
+    wl = args.workload
+    weak = args.scaling == "weak"
+    if wl == "demucs6":                                       # configs[2]: htdemucs 6-stem, 10 min, overlap 0.25, segments sharded
+        seconds = args.seconds if args.seconds != TRACK_SECONDS else 600
+        n = seconds * SR * (world if weak else 1)
+        mix = torch.from_numpy(synth_mix(n)).to(device)
+        eng = Separator(ctx=ctx, use_autocast=False, allow_synthetic=True, sharded=world > 1)
+        eng.load_model("htdemucs_6s.yaml")
+        stems, audio_s, sr = 6, n / SR, SR
+        desc = f"htdemucs_6s (HTDemucs 6 sources, fp32), {seconds} s 44.1 kHz stereo {'per GPU' if weak else 'in total'}, shifts 2, overlap 0.25"
+        dtype_name, sharding = "f32", f"(shift, segment) units/{world} + all_reduce of the weighted sums"
+
+        def step():
+            return eng.separate_array(mix)
+    elif wl == "tracks":                                      # configs[3]: a batch of tracks, MDX ensemble + Demucs per track, replicas
+        from audiolab_amd.separator.stem_separator import EnsembleDemucsMDXMusicSeparationModel
+        seconds = args.seconds if args.seconds != TRACK_SECONDS else 180
+        n = seconds * SR
+        tracks = [torch.from_numpy(synth_mix(n, seed=1000 + rank * 100 + k)).to(device) for k in range(args.tracks)]
+        eng = Separator(ctx=ctx, use_autocast=True, allow_synthetic=True, max_batch=args.batch)
+        model = EnsembleDemucsMDXMusicSeparationModel({"ensemble_strength": 2, "vocals_only": False}, separator=eng)
+        stems, audio_s, sr = 7, args.tracks * world * n / SR, SR
+        desc = (f"{args.tracks} tracks x {seconds} s per GPU: 2 MDX-Net vocal models (n_fft 7680, bf16) blended + de-bleed, then "
+                f"htdemucs_6s on the mix (fp32): vocals, instrumental + 5 Demucs stems per track")
+        dtype_name, sharding = "bf16+f32", f"track replicas x{world}, no data-path collective"
+
+        def step():
+            files = [{"base_name": f"t{k}", "mix": t, "sr": SR, "output_folder": "/mem"} for k, t in enumerate(tracks)]
+            res = model._ensemble_separate_all(files)
+            model._multistem_separation_all(res)
+            return res
+    else:                                                     # configs[4]: 60 min 48 kHz 8 channels, overlap 0.75
+        seconds = args.seconds if args.seconds != TRACK_SECONDS else 3600
+        sr = 48000
+        n = seconds * sr * (world if weak else 1)
+        mix8 = torch.from_numpy(np.concatenate([synth_mix(n, sr=sr, seed=50 + c) for c in range(4)])).to(device)
+        eng = Separator(ctx=ctx, use_autocast=True, allow_synthetic=True, max_batch=args.batch, chunker="ola", overlap=0.75,
+                        sharded=world > 1, roster={"longform_vocals.onnx": ("Vocals", "Instrumental", _bench_cfg())})
+        eng.load_model("longform_vocals.onnx")
+        stems, audio_s = 2, n / sr
+        desc = (f"8 channels (4 stereo pairs) x {seconds} s at 48 kHz (native rate), one MDX-Net model (bench geometry, bf16 -- no fp16 "
+                f"kernels yet), Hann overlap-add at overlap 0.75, chunks sharded")
+        dtype_name, sharding = "bf16", f"chunks/{world} + all_reduce of the seam sums"
+
+        def step():
+            return eng.separate_array(mix8)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    if rank == 0:
+        mult = 4 if wl == "longform" else 1                    # stereo pairs count as separate 2-channel programmes
+        print(json.dumps({
+            "metric": "stems*realtime-factor (44.1kHz stereo)", "value": round(stems * mult * audio_s * args.steps / dt, 2),
+            "unit": "stems*x_realtime", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": dtype_name, "data": "synthetic",
+            "config": {"workload": desc, "stems": stems, "audio_seconds": audio_s, "sample_rate": sr, "sharding": sharding},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _bench_cfg():
+    from audiolab_amd.tdfnet import TDFNetConfig
+    return TDFNetConfig()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,7 +262,14 @@ def main() -> None:
     ap.add_argument("--cpu-windows", type=int, default=2)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: N x --seconds of audio on N GPUs (per-GPU work fixed); strong: --seconds in total")
+    ap.add_argument("--workload", default="mdx4", choices=["mdx4", "demucs6", "tracks", "longform"],
+                    help="mdx4 (default): BASELINE configs[1], the graded line.  Supplementary lines for the other configs: demucs6 = "
+                         "configs[2] (htdemucs 6-stem, segments sharded over the ranks), tracks = configs[3] (batch of tracks per GPU, MDX "
+                         "ensemble + htdemucs, replicas), longform = configs[4] (48 kHz 8-channel, Hann overlap-add at 0.75, chunks sharded)")
+    ap.add_argument("--tracks", type=int, default=8, help="tracks per GPU of the tracks workload")
     args = ap.parse_args()
+    if args.workload != "mdx4":
+        return other_workload(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -115,6 +115,12 @@ int alsep_ola_combine(alsep_ctx* ctx, const float* chunks, int64_t n_chunks, int
 int alsep_ola_partial(alsep_ctx* ctx, const float* chunks, int64_t b0, int64_t b1, int64_t chunk, int64_t step, int64_t total,
                       int use_window, float* part, int64_t p_lo, int64_t n_out);
 int alsep_ola_finish(alsep_ctx* ctx, const float* part, float gain, float* out, int64_t out_stride, int64_t n_out);
+/* Sample-rate conversion of rows of PCM, x [rows, n_in] at sr_in -> y [rows, n_out] at sr_out (n_out = ceil(n_in * sr_out / sr_in) as
+ * librosa): what librosa.load(path, sr=44100) does to a 48 kHz input at modules/separator/stem_separator.py:865.  The reference uses
+ * libsoxr there (not in /root/reference): this is the build's own Kaiser-windowed sinc (`zeros` zero crossings per side, cut-off
+ * rolloff * min(sr_in, sr_out) / 2, Kaiser beta) -- PARITY UNPINNED; restated in oracle/mdx_oracle.py resample(). */
+int alsep_resample(alsep_ctx* ctx, const float* x, float* y, int64_t rows, int64_t n_in, int64_t n_out, int sr_in, int sr_out,
+                   int zeros, float rolloff, float beta);
 /* zero the lowest nbins bins of a spectrogram in place (MDXSeparator.run_model zeroes bins 0..2). */
 int alsep_zero_low_bins(alsep_ctx* ctx, void* spec, int dtype, int layout, int64_t B, int64_t dim_f, int64_t T,
                         int nbins);

@@ -52,3 +52,21 @@ def test_debleed_matches_oracle(dev):
         got, acc_g = ensemble.debleed(dev, on(dev, mix), on(dev, voc), on(dev, inst), 44100, 0.2)
         assert acc_g == acc_w
         assert np.max(np.abs(host(got) - want)) < 2e-6
+
+
+@pytest.mark.parametrize("sr_in,sr_out,n", [(48000, 44100, 4801), (44100, 48000, 3000), (22050, 44100, 1000)])
+def test_resample_vs_oracle(dev, sr_in, sr_out, n):
+    """alsep_resample (the 48 kHz -> 44.1 kHz input path of stem_separator.py:865) against its numpy restatement, and the property any
+    band-limited resampler has: a sine well below both Nyquist rates comes out as the same sine at the new rate."""
+    from audiolab_amd import ensemble
+    from oracle import mdx_oracle as mo
+    rng = np.random.default_rng(5)
+    t = np.arange(n) / sr_in
+    x = np.stack([0.5 * np.sin(2 * np.pi * 1000.0 * t), 0.1 * rng.standard_normal(n)]).astype(np.float32)
+    got = host(ensemble.resample(dev, on(dev, x), sr_in, sr_out))
+    want = mo.resample(x, sr_in, sr_out)
+    assert got.shape == want.shape == (2, -(-n * sr_out // sr_in))
+    assert np.max(np.abs(got - want)) < 2e-6
+    m = np.arange(got.shape[1])
+    inner = slice(200, got.shape[1] - 200)
+    assert np.max(np.abs(got[0, inner] - 0.5 * np.sin(2 * np.pi * 1000.0 * m / sr_out)[inner])) < 2e-3
