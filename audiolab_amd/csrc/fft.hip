@@ -177,12 +177,16 @@ ALSEP_FFT(512, 8, 8, 8)
 ALSEP_FFT(1024, 8, 8, 8, 2)
 ALSEP_FFT(2048, 8, 8, 8, 4)
 ALSEP_FFT(4096, 8, 8, 8, 8)
+ALSEP_FFT(5120, 5, 8, 8, 8, 2)
 ALSEP_FFT(6144, 3, 4, 8, 8, 8)
 ALSEP_FFT(7680, 5, 8, 3, 8, 8)
 ALSEP_FFT(8192, 8, 8, 8, 8, 2)
+ALSEP_FFT(16384, 8, 8, 8, 8, 4)
 #undef ALSEP_FFT
 
-#define ALSEP_FOR_EACH_NFFT(X) X(256) X(384) X(480) X(512) X(1024) X(2048) X(4096) X(6144) X(7680) X(8192)
+// 5120: UVR-MDX-NET_Crowd_HQ_1; 6144 / 7680: the UVR vocal / instrumental models; 4096 / 8192 / 16384: the KUIELab drums / other / bass
+// models (kuielab_a_bass.onnx is the alt-bass model of stem_separator.py:512) and HTDemucs (4096)
+#define ALSEP_FOR_EACH_NFFT(X) X(256) X(384) X(480) X(512) X(1024) X(2048) X(4096) X(5120) X(6144) X(7680) X(8192) X(16384)
 
 constexpr int kFftThreads = 256;
 
@@ -514,7 +518,8 @@ extern "C" int alsep_plan_create(alsep_ctx* ctx, int n_fft, int hop, int dim_f, 
     if (chunk <= n_fft / 2)     // torch.stft's reflect padding needs pad < length
         return alsep_fail(ctx, ALSEP_ERR_ARG, "chunk %lld must exceed n_fft/2=%d", (long long)chunk, n_fft / 2);
     const int Q = (n_fft + hop - 1) / hop;
-    if ((size_t)(n_fft + Q * hop) * sizeof(float2) > 160 * 1024)
+    const bool regring = hop == 1024 && (n_fft % 1024 == 0 || n_fft == 7680);   // register-ring iSTFT: LDS holds one frame only
+    if ((size_t)(regring ? n_fft : n_fft + Q * hop) * sizeof(float2) > 160 * 1024)
         return alsep_fail(ctx, ALSEP_ERR_ARG, "n_fft=%d hop=%d needs more than 160 KiB of LDS", n_fft, hop);
     alsep_plan* p = new alsep_plan();
     p->ctx = ctx; p->n_fft = n_fft; p->hop = hop; p->dim_f = dim_f; p->dim_t = dim_t; p->chunk = (int)chunk;

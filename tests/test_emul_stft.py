@@ -126,3 +126,23 @@ def test_three_pass_kernels_production_sizes(emul, n_fft, dim_f, dim_t):
         want_s = want_y[:, :, trim:-trim].transpose(1, 0, 2).reshape(2, -1)
         assert np.max(np.abs(st.numpy()[:, :limit] - want_s[:, :limit])) < tol
         assert float(st[:, limit:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n_fft,dim_f,dim_t", [(5120, 2560, 8), (16384, 2048, 20)])
+def test_roster_geometries_5120_16384_vs_oracle(emul, n_fft, dim_f, dim_t):
+    """n_fft of UVR-MDX-NET_Crowd_HQ_1 (5120 = 5 * 2**10) and of kuielab_a_bass.onnx (16384, the alt-bass model of
+    stem_separator.py:512) at hop 1024: STFT and iSTFT (register-ring kernel, one frame in LDS) against the oracle."""
+    from audiolab_amd import _lib
+    from audiolab_amd.mdx import StftPlan
+    plan = StftPlan(emul, n_fft, 1024, dim_f, dim_t)
+    g = mo.MDXGeometry(dim_f, dim_t, n_fft, 1024)
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((1, 2, plan.chunk_size)).astype(np.float32)
+    want = mo.stft(x, g)
+    got = plan.stft_strided(torch.from_numpy(x), plan.chunk_size, 2 * plan.chunk_size, 1, torch.float32, _lib.LAYOUT_REF).numpy()
+    assert np.max(np.abs(got - want)) < 3e-6 * np.max(np.abs(want))
+    spec = rng.standard_normal((1, 4, dim_f, dim_t)).astype(np.float32)
+    want_y = mo.istft(spec, g)
+    out = emul.empty((1, 2, plan.chunk_size))
+    plan.istft_strided(torch.from_numpy(spec), _lib.LAYOUT_REF, out, plan.chunk_size, 2 * plan.chunk_size, 0, plan.chunk_size, plan.chunk_size)
+    assert np.max(np.abs(out.numpy() - want_y)) < 2e-5 * max(1.0, float(np.max(np.abs(want_y))))

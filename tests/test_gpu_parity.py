@@ -108,7 +108,8 @@ def test_demix_30s_real_geometry_golden(ctx, golden_dir, tag):
 
 
 @pytest.mark.parametrize("n_fft,dim_f,dim_t", [(6144, 3073, 7), (6144, 1000, 8), (4096, 2049, 6), (4096, 2048, 9), (7680, 3841, 10),
-                                               (7680, 1000, 10), (2048, 1025, 6)])
+                                               (7680, 1000, 10), (2048, 1025, 6), (5120, 2560, 8), (8192, 2048, 12),
+                                               (16384, 2048, 20)])      # 5120 / 8192 / 16384: Crowd_HQ_1 / kuielab other / bass
 def test_production_fft_kernels_band_variants_vs_oracle(ctx, n_fft, dim_f, dim_t):
     """Full band (Nyquist bin stored), production band and a narrow band (zero-filled bins: the clamped-address + select
     path of the batched spectrum loads) through the three-pass / register-ring kernels, plain and stitched stores."""
