@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libalsep.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 PROF_CONV3X3, PROF_CONV3X3_SMALL, PROF_TDF, PROF_PIX, PROF_POINTWISE, PROF_STFT, PROF_ISTFT = 1, 2, 3, 4, 5, 6, 7
 PROF_CONV3X3_REGW, PROF_CONV3X3_PIPE, PROF_CONV3X3_BIG, PROF_CONV3X3_BIG3 = 8, 9, 10, 11
 LAYOUT_REF, LAYOUT_NHWC = 0, 1
@@ -152,11 +152,13 @@ def dtype_code(dt: torch.dtype) -> int:
         return F32
     if dt == torch.bfloat16:
         return BF16
+    if dt == torch.float16:
+        return F16
     raise AlsepError(f"unsupported dtype {dt}")
 
 
 def torch_dtype(code: int) -> torch.dtype:
-    return torch.float32 if code == F32 else torch.bfloat16
+    return {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[code]
 
 
 class Context:

@@ -16,9 +16,23 @@
 // (cdna_hip_programming.md Guideline 17: no static __shared__ in front of it).
 extern __shared__ __attribute__((aligned(16))) char alsep_smem[];
 
+// The 16-bit storage type of the half-precision kernels.  Every such kernel is written once against `bf16_t`; the translation units
+// tdfnet_f16.hip / fft_f16.hip compile the same sources a second time with ALSEP_F16_TU defined, where the type is IEEE binary16
+// (_Float16: 10 mantissa bits instead of 7, the reference's autocast type) and the MFMA is v_mfma_f32_16x16x32_f16.  Their entry
+// points carry the suffix _f16tu and are reached through the dtype dispatch of the public functions (ALSEP_F16).
+#ifdef ALSEP_F16_TU
+typedef _Float16 bf16_t;
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bf16x4 __attribute__((ext_vector_type(4)));
+#define ALSEP_HALF_DTYPE ALSEP_F16
+#define ALSEP_TU_NAME(name) name##_f16tu
+#else
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define ALSEP_HALF_DTYPE ALSEP_BF16
+#define ALSEP_TU_NAME(name) name
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct alsep_ctx {
@@ -99,7 +113,7 @@ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b;
 
 template <typename T> struct dtype_of;
 template <> struct dtype_of<float> { static constexpr int value = ALSEP_F32; };
-template <> struct dtype_of<bf16_t> { static constexpr int value = ALSEP_BF16; };
+template <> struct dtype_of<bf16_t> { static constexpr int value = ALSEP_HALF_DTYPE; };
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }

@@ -417,7 +417,7 @@ extern "C" int alsep_resample(alsep_ctx* ctx, const float* x, float* y, int64_t 
 extern "C" int alsep_zero_low_bins(alsep_ctx* ctx, void* spec, int dtype, int layout, int64_t B, int64_t dim_f, int64_t T,
                                    int nbins) {
     ALSEP_ENTER(ctx);
-    if (!ctx || !spec || B < 0 || nbins < 0 || nbins > dim_f || (dtype != ALSEP_F32 && dtype != ALSEP_BF16))
+    if (!ctx || !spec || B < 0 || nbins < 0 || nbins > dim_f || (dtype != ALSEP_F32 && dtype != ALSEP_BF16 && dtype != ALSEP_F16))
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_zero_low_bins: bad argument");
     if (B == 0 || nbins == 0) return ALSEP_OK;
     const int64_t n = B * 4 * nbins * T;

@@ -498,6 +498,10 @@ spec_convert_kernel(const T* __restrict__ src, T* __restrict__ dst, int F, int T
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+#ifndef ALSEP_F16_TU
+extern "C" int alsep_stft_f16tu(alsep_ctx*, const alsep_plan*, const float*, int64_t, int64_t, int64_t, void*, int, int);
+extern "C" int alsep_istft_f16tu(alsep_ctx*, const alsep_plan*, const void*, int, int, int64_t, float*, int64_t, int64_t, int64_t, int64_t,
+                                 int64_t);
 extern "C" int alsep_plan_supported_nfft(int n_fft) {
     switch (n_fft) {
 #define X(N_) case N_:
@@ -564,6 +568,7 @@ extern "C" int alsep_plan_destroy(alsep_plan* plan) {
     delete plan;
     return ALSEP_OK;
 }
+#endif  // !ALSEP_F16_TU (plans are dtype-free: main translation unit only)
 
 // Hop-blocks per workgroup of the persistent iSTFT kernels.  A workgroup spends run + Q - 1 frames on `run` blocks
 // (Q - 1 warm-up frames re-done by every workgroup), and the grid runs in ceil(workgroups / slots) rounds: pick the
@@ -636,12 +641,15 @@ static int launch_stft(alsep_ctx* ctx, const alsep_plan* p, const float* pcm, in
     return ALSEP_OK;
 }
 
-extern "C" int alsep_stft(alsep_ctx* ctx, const alsep_plan* plan, const float* pcm, int64_t ch_stride,
+extern "C" int ALSEP_TU_NAME(alsep_stft)(alsep_ctx* ctx, const alsep_plan* plan, const float* pcm, int64_t ch_stride,
                           int64_t chunk_stride, int64_t n_chunks, void* spec, int dtype, int layout) {
     ALSEP_ENTER(ctx);
+#ifndef ALSEP_F16_TU
+    if (dtype == ALSEP_F16) return alsep_stft_f16tu(ctx, plan, pcm, ch_stride, chunk_stride, n_chunks, spec, dtype, layout);
+#endif
     if (!ctx || !plan || !pcm || !spec) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_stft: null argument");
     if (n_chunks == 0) return ALSEP_OK;
-    if (n_chunks < 0 || (dtype != ALSEP_F32 && dtype != ALSEP_BF16) ||
+    if (n_chunks < 0 || (dtype != ALSEP_F32 && dtype != ALSEP_HALF_DTYPE) ||
         (layout != ALSEP_LAYOUT_REF && layout != ALSEP_LAYOUT_NHWC))
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_stft: bad n_chunks/dtype/layout");
 #define X(N_)                                                                                          \
@@ -730,14 +738,18 @@ static int launch_istft(alsep_ctx* ctx, const alsep_plan* p, const void* spec, i
     return ALSEP_OK;
 }
 
-extern "C" int alsep_istft(alsep_ctx* ctx, const alsep_plan* plan, const void* spec, int dtype, int layout,
+extern "C" int ALSEP_TU_NAME(alsep_istft)(alsep_ctx* ctx, const alsep_plan* plan, const void* spec, int dtype, int layout,
                            int64_t n_chunks, float* out, int64_t out_ch_stride, int64_t out_chunk_stride,
                            int64_t keep_lo, int64_t keep_hi, int64_t out_limit) {
     ALSEP_ENTER(ctx);
+#ifndef ALSEP_F16_TU
+    if (dtype == ALSEP_F16)
+        return alsep_istft_f16tu(ctx, plan, spec, dtype, layout, n_chunks, out, out_ch_stride, out_chunk_stride, keep_lo, keep_hi, out_limit);
+#endif
     if (!ctx || !plan || !spec || !out) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_istft: null argument");
     if (n_chunks == 0) return ALSEP_OK;
     if (n_chunks < 0 || keep_lo < 0 || keep_hi > plan->chunk || keep_lo >= keep_hi || out_limit <= 0 ||
-        (dtype != ALSEP_F32 && dtype != ALSEP_BF16) || (layout != ALSEP_LAYOUT_REF && layout != ALSEP_LAYOUT_NHWC))
+        (dtype != ALSEP_F32 && dtype != ALSEP_HALF_DTYPE) || (layout != ALSEP_LAYOUT_REF && layout != ALSEP_LAYOUT_NHWC))
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_istft: bad argument");
 #define X(N_)                                                                                          \
     if (plan->n_fft == N_) {                                                                           \
@@ -754,6 +766,7 @@ extern "C" int alsep_istft(alsep_ctx* ctx, const alsep_plan* plan, const void* s
     return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_istft: unsupported n_fft %d", plan->n_fft);
 }
 
+#ifndef ALSEP_F16_TU
 extern "C" int alsep_spec_convert(alsep_ctx* ctx, const void* src, void* dst, int dtype, int src_layout,
                                   int64_t B, int64_t dim_f, int64_t T) {
     ALSEP_ENTER(ctx);
@@ -766,7 +779,7 @@ extern "C" int alsep_spec_convert(alsep_ctx* ctx, const void* src, void* dst, in
         const size_t lds = 4 * 32 * 33 * sizeof(float);
         if (to_nhwc) hipLaunchKernelGGL((spec_convert_kernel<float, 1>), grid, dim3(256), lds, ctx->stream, (const float*)src, (float*)dst, (int)dim_f, (int)T);
         else hipLaunchKernelGGL((spec_convert_kernel<float, 0>), grid, dim3(256), lds, ctx->stream, (const float*)src, (float*)dst, (int)dim_f, (int)T);
-    } else if (dtype == ALSEP_BF16) {
+    } else if (dtype == ALSEP_BF16 || dtype == ALSEP_F16) {      // a 16-bit transposing copy: the element type does not matter
         const size_t lds = 4 * 32 * 33 * sizeof(bf16_t);
         if (to_nhwc) hipLaunchKernelGGL((spec_convert_kernel<bf16_t, 1>), grid, dim3(256), lds, ctx->stream, (const bf16_t*)src, (bf16_t*)dst, (int)dim_f, (int)T);
         else hipLaunchKernelGGL((spec_convert_kernel<bf16_t, 0>), grid, dim3(256), lds, ctx->stream, (const bf16_t*)src, (bf16_t*)dst, (int)dim_f, (int)T);
@@ -776,3 +789,4 @@ extern "C" int alsep_spec_convert(alsep_ctx* ctx, const void* src, void* dst, in
     ALSEP_LAUNCH_CHECK(ctx, "spec_convert_kernel");
     return ALSEP_OK;
 }
+#endif  // !ALSEP_F16_TU

@@ -27,7 +27,11 @@ __device__ __forceinline__ typename Frag<T>::type lds_frag(const T* p) {
 }
 
 __device__ __forceinline__ void mma_step(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+#ifdef ALSEP_F16_TU
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+#else
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ void mma_step(f32x4& acc, const f32x4& a, const f32x4& b) {
 #pragma unroll

@@ -2674,13 +2674,22 @@ int forward_impl(alsep_ctx* ctx, const alsep_net* net, const T* in, T* out, int6
 
 }  // namespace
 
-extern "C" int alsep_net_create(alsep_ctx* ctx, const alsep_net_config* cfg, const alsep_tensor* tensors,
+// the IEEE-half twins of the four entry points below, defined by tdfnet_f16.hip (this file compiled with ALSEP_F16_TU)
+extern "C" int alsep_net_create_f16tu(alsep_ctx*, const alsep_net_config*, const alsep_tensor*, int64_t, alsep_net**);
+extern "C" int alsep_net_destroy_f16tu(alsep_net*);
+extern "C" int64_t alsep_net_workspace_bytes_f16tu(const alsep_net*, int64_t);
+extern "C" int alsep_net_forward_f16tu(alsep_ctx*, const alsep_net*, const void*, void*, int64_t, void*, int64_t, float, float, float);
+
+extern "C" int ALSEP_TU_NAME(alsep_net_create)(alsep_ctx* ctx, const alsep_net_config* cfg, const alsep_tensor* tensors,
                                 int64_t n_tensors, alsep_net** out) {
     ALSEP_ENTER(ctx);
+#ifndef ALSEP_F16_TU
+    if (ctx && cfg && cfg->dtype == ALSEP_F16) return alsep_net_create_f16tu(ctx, cfg, tensors, n_tensors, out);
+#endif
     if (!ctx || !cfg || !tensors || !out) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_create: null argument");
     const int n = cfg->num_blocks / 2;
     if (cfg->num_blocks < 1 || cfg->l < 1 || cfg->g < 16 || cfg->g % 16 != 0 || cfg->bn < 0 ||
-        (cfg->dtype != ALSEP_F32 && cfg->dtype != ALSEP_BF16))
+        (cfg->dtype != ALSEP_F32 && cfg->dtype != ALSEP_HALF_DTYPE))
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_create: unsupported config (g must be a multiple of 16)");
     if (cfg->dim_f % (1 << n) != 0 || cfg->dim_t % (1 << n) != 0 ||
         (cfg->bn > 0 && (cfg->dim_f >> n) % cfg->bn != 0))
@@ -2701,7 +2710,7 @@ extern "C" int alsep_net_create(alsep_ctx* ctx, const alsep_net_config* cfg, con
     const int rc = cfg->dtype == ALSEP_F32 ? build_net<float>(net, tm) : build_net<bf16_t>(net, tm);
     if (rc) {
         const std::string keep = ctx->err;
-        alsep_net_destroy(net);
+        ALSEP_TU_NAME(alsep_net_destroy)(net);
         ctx->err = keep;
         return rc;
     }
@@ -2709,29 +2718,39 @@ extern "C" int alsep_net_create(alsep_ctx* ctx, const alsep_net_config* cfg, con
     return ALSEP_OK;
 }
 
-extern "C" int alsep_net_destroy(alsep_net* net) {
+extern "C" int ALSEP_TU_NAME(alsep_net_destroy)(alsep_net* net) {
     if (!net) return ALSEP_OK;
+#ifndef ALSEP_F16_TU
+    if (net->cfg.dtype == ALSEP_F16) return alsep_net_destroy_f16tu(net);
+#endif
     for (auto& b : net->owned)
         if (b.p) (void)hipFree(b.p);
     delete net;
     return ALSEP_OK;
 }
 
-extern "C" int64_t alsep_net_workspace_bytes(const alsep_net* net, int64_t B) {
+extern "C" int64_t ALSEP_TU_NAME(alsep_net_workspace_bytes)(const alsep_net* net, int64_t B) {
     if (!net || B <= 0) return 0;
+#ifndef ALSEP_F16_TU
+    if (net->cfg.dtype == ALSEP_F16) return alsep_net_workspace_bytes_f16tu(net, B);
+#endif
     return (int64_t)ws_layout(net, B).total;
 }
 
-extern "C" int alsep_net_forward(alsep_ctx* ctx, const alsep_net* net, const void* spec_in, void* spec_out,
+extern "C" int ALSEP_TU_NAME(alsep_net_forward)(alsep_ctx* ctx, const alsep_net* net, const void* spec_in, void* spec_out,
                                  int64_t B, void* workspace, int64_t workspace_bytes, float in_scale,
                                  float out_alpha, float out_beta) {
     ALSEP_ENTER(ctx);
+#ifndef ALSEP_F16_TU
+    if (net && net->cfg.dtype == ALSEP_F16)
+        return alsep_net_forward_f16tu(ctx, net, spec_in, spec_out, B, workspace, workspace_bytes, in_scale, out_alpha, out_beta);
+#endif
     if (!ctx || !net || !spec_in || !spec_out || !workspace) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_forward: null argument");
     if (B == 0) return ALSEP_OK;
     if (B < 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_forward: negative batch");
-    if (workspace_bytes < alsep_net_workspace_bytes(net, B))
+    if (workspace_bytes < ALSEP_TU_NAME(alsep_net_workspace_bytes)(net, B))
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_forward: workspace too small (%lld < %lld)",
-                          (long long)workspace_bytes, (long long)alsep_net_workspace_bytes(net, B));
+                          (long long)workspace_bytes, (long long)ALSEP_TU_NAME(alsep_net_workspace_bytes)(net, B));
     if (((uintptr_t)workspace & 255) != 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_forward: workspace must be 256-byte aligned");
     if (net->cfg.dtype == ALSEP_F32)
         return forward_impl<float>(ctx, net, (const float*)spec_in, (float*)spec_out, B, (char*)workspace, in_scale, out_alpha, out_beta);

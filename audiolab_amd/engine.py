@@ -107,8 +107,10 @@ class Separator:
         self.invert_using_spec = invert_using_spec
         self.use_autocast = use_autocast
         self.ctx = ctx if ctx is not None else _lib.default_context(None)
-        # use_autocast=True is the reference's GPU setting (stem_separator.py:106): half-precision network
-        self.dtype = dtype if dtype is not None else (torch.bfloat16 if use_autocast else torch.float32)
+        # use_autocast=True is the reference's GPU setting (stem_separator.py:106): torch autocast on CUDA = IEEE half.  Measured at
+        # the bench geometry against the fp32 oracle (tests/test_gpu_parity.py): f16 3.5 % relative L2 (SDR 29 dB), bf16 20 % (14 dB),
+        # at the same speed -- so half precision here means float16; bfloat16 stays available through ``dtype=``.
+        self.dtype = dtype if dtype is not None else (torch.float16 if use_autocast else torch.float32)
         self.sample_rate = sample_rate
         self.chunks, self.margin, self.denoise = chunks, margin, denoise
         self.max_batch = max_batch

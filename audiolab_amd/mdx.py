@@ -126,7 +126,7 @@ class ConvTDFNetTrim:
         if freq_pad is not None:
             raise AlsepError("custom freq_pad is not supported; bins >= dim_f are zero")
         x = x.contiguous()
-        if x.dtype not in (torch.float32, torch.bfloat16):
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
             x = x.float()
         b = x.shape[0]
         out = self.ctx.empty((b, 2, self.chunk_size), torch.float32)

@@ -67,7 +67,8 @@ class EnsembleDemucsMDXMusicSeparationModel:
         self.options = options
         self.separator = separator if separator is not None else Separator(
             log_level=logging.ERROR, model_file_dir=os.path.join(app_path, "models", "audio_separator"),
-            invert_using_spec=True, use_autocast=not options.get("cpu", False) and options.get("precision", "bf16") != "fp32")
+            invert_using_spec=True, use_autocast=not options.get("cpu", False) and options.get("precision", "fp16") != "fp32",
+            dtype={"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}.get(options.get("precision", "fp16")))
         self.ctx = self.separator.ctx
         self.vocals_only = bool(options.get("vocals_only", False))
         self.separate_drums = bool(options.get("separate_drums", False))
@@ -417,7 +418,7 @@ def predict_with_model(options: Dict, callback: Callable = None, separator: Opti
 
 
 def separate_music(input_dict: Dict[str, List[str]], callback: Callable = None, **kwargs) -> List[str]:
-    """:949-1001 -- same option names and defaults; extra keys ``precision`` ("bf16"|"fp32") and
+    """:949-1001 -- same option names and defaults; extra keys ``precision`` ("fp16"|"bf16"|"fp32") and
     ``separator`` (a pre-built engine) are this build's."""
     options = {
         "input_dict": input_dict,
@@ -444,6 +445,6 @@ def separate_music(input_dict: Dict[str, List[str]], callback: Callable = None, 
         "callback": callback,
         "ensemble_strength": kwargs.get("ensemble_strength", 2),
         "residual_blend": kwargs.get("residual_blend", 0.4),
-        "precision": kwargs.get("precision", "bf16"),
+        "precision": kwargs.get("precision", "fp16"),
     }
     return predict_with_model(options, callback, separator=kwargs.get("separator"))

@@ -187,7 +187,7 @@ def other_workload(args) -> None:
         seconds = args.seconds if args.seconds != TRACK_SECONDS else 180
         n = seconds * SR
         tracks = [torch.from_numpy(synth_mix(n, seed=1000 + rank * 100 + k)).to(device) for k in range(args.tracks)]
-        eng = Separator(ctx=ctx, use_autocast=True, allow_synthetic=True, max_batch=args.batch)
+        eng = Separator(ctx=ctx, dtype=torch.bfloat16, allow_synthetic=True, max_batch=args.batch)
         model = EnsembleDemucsMDXMusicSeparationModel({"ensemble_strength": 2, "vocals_only": False}, separator=eng)
         stems, audio_s, sr = 7, args.tracks * world * n / SR, SR
         desc = (f"{args.tracks} tracks x {seconds} s per GPU: 2 MDX-Net vocal models (n_fft 7680, bf16) blended + de-bleed, then "
@@ -204,13 +204,13 @@ def other_workload(args) -> None:
         sr = 48000
         n = seconds * sr * (world if weak else 1)
         mix8 = torch.from_numpy(np.concatenate([synth_mix(n, sr=sr, seed=50 + c) for c in range(4)])).to(device)
-        eng = Separator(ctx=ctx, use_autocast=True, allow_synthetic=True, max_batch=args.batch, chunker="ola", overlap=0.75,
+        eng = Separator(ctx=ctx, dtype=torch.float16, allow_synthetic=True, max_batch=args.batch, chunker="ola", overlap=0.75,
                         sharded=world > 1, roster={"longform_vocals.onnx": ("Vocals", "Instrumental", _bench_cfg())})
         eng.load_model("longform_vocals.onnx")
         stems, audio_s = 2, n / sr
-        desc = (f"8 channels (4 stereo pairs) x {seconds} s at 48 kHz (native rate), one MDX-Net model (bench geometry, bf16 -- no fp16 "
-                f"kernels yet), Hann overlap-add at overlap 0.75, chunks sharded")
-        dtype_name, sharding = "bf16", f"chunks/{world} + all_reduce of the seam sums"
+        desc = (f"8 channels (4 stereo pairs) x {seconds} s at 48 kHz (native rate), one MDX-Net model (bench geometry, fp16 storage + f16 MFMA), "
+                f"Hann overlap-add at overlap 0.75, chunks sharded")
+        dtype_name, sharding = "f16", f"chunks/{world} + all_reduce of the seam sums"
 
         def step():
             return eng.separate_array(mix8)
@@ -255,7 +255,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--batch", type=int, default=8, help="model windows per network launch")
     ap.add_argument("--seconds", type=int, default=TRACK_SECONDS, help="audio seconds per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -291,7 +291,7 @@ def main() -> None:
     from audiolab_amd.synth import synth_mix, synthetic_state_dict
     from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
 
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     device = torch.device("cuda", local_rank)
     ctx = _lib.Context(device)
     cfg = TDFNetConfig()
@@ -317,11 +317,12 @@ def main() -> None:
     for _ in range(args.warmup):
         stems = step()
     fence()
-    klevels = conv_kernel_levels(cfg, dtype == torch.bfloat16, args.batch)
+    half = dtype in (torch.bfloat16, torch.float16)          # the f16 build runs the same kernels (tdfnet_f16.hip)
+    klevels = conv_kernel_levels(cfg, half, args.batch)
     KCLASS = {"big": ("conv3x3_bf16_big_kernel<2>", _lib.PROF_CONV3X3_BIG),
               "big3": ("conv3x3_bf16_big_kernel<3>", _lib.PROF_CONV3X3_BIG3),
               "regw": ("conv3x3_bf16_regw_kernel<1>", _lib.PROF_CONV3X3_REGW),
-              "plain": ("conv3x3_bf16_kernel<64>" if dtype == torch.bfloat16 else "conv3x3_kernel<f32,16,48,64>",
+              "plain": ("conv3x3_bf16_kernel<64>" if half else "conv3x3_kernel<f32,16,48,64>",
                         _lib.PROF_CONV3X3)}
     primary = "big" if klevels["big"] else "plain"          # the single kernel with the largest share of the step
     ctx.profile_begin(KCLASS[primary][1])
@@ -342,8 +343,8 @@ def main() -> None:
     n_win = n_samples // gen + 1
     from audiolab_amd.dist import window_range
     w_lo, w_hi = window_range(n_win, world, rank)
-    es = 2 if dtype == torch.bfloat16 else 4
-    peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+    es = 2 if half else 4
+    peak = PEAK_BF16_TFLOPS if half else PEAK_F32_TFLOPS
 
     def conv_entry(cls, ms, launches, passes):
         """Roofline object of one 3x3-conv kernel class from its HIP-event time over `passes` steps."""

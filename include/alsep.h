@@ -14,7 +14,9 @@
  *   - Return value: 0 = ok, negative = error; alsep_last_error(ctx) describes the most
  *     recent failure.  No C++ exception crosses the ABI.
  *   - dtype: ALSEP_F32 = float32 storage + f32 MFMA (parity mode),
- *            ALSEP_BF16 = bfloat16 storage + bf16 MFMA with f32 accumulation.
+ *            ALSEP_BF16 = bfloat16 storage + bf16 MFMA with f32 accumulation,
+ *            ALSEP_F16  = IEEE half storage + f16 MFMA with f32 accumulation (the type of the reference's
+ *                         use_autocast=True, stem_separator.py:106; 8x finer rounding than bf16, range 65504).
  *   - layout of a spectrogram: ALSEP_LAYOUT_REF  = [B,4,dim_f,T]  (the reference's
  *     model I/O, mdxnet.py:56,170; patch_separate.py:52), channels (L_re,L_im,R_re,R_im);
  *     ALSEP_LAYOUT_NHWC = [B,T,dim_f,4] (the network's internal channels-last order).
@@ -31,7 +33,7 @@ extern "C" {
 
 #define ALSEP_ABI_VERSION 1
 
-enum { ALSEP_F32 = 0, ALSEP_BF16 = 1 };
+enum { ALSEP_F32 = 0, ALSEP_BF16 = 1, ALSEP_F16 = 2 };
 enum { ALSEP_LAYOUT_REF = 0, ALSEP_LAYOUT_NHWC = 1 };
 enum {
     ALSEP_OK = 0,

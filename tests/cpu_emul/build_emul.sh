@@ -6,7 +6,7 @@ set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 CXX="${ALSEP_HOST_CXX:-/opt/rocm/lib/llvm/bin/clang++}"
-SRC="$ROOT/audiolab_amd/csrc/fft.hip $ROOT/audiolab_amd/csrc/tdfnet.hip $ROOT/audiolab_amd/csrc/elementwise.hip $ROOT/audiolab_amd/csrc/vrnet.hip $ROOT/audiolab_amd/csrc/nn.hip"
+SRC="$ROOT/audiolab_amd/csrc/fft.hip $ROOT/audiolab_amd/csrc/tdfnet.hip $ROOT/audiolab_amd/csrc/elementwise.hip $ROOT/audiolab_amd/csrc/vrnet.hip $ROOT/audiolab_amd/csrc/nn.hip $ROOT/audiolab_amd/csrc/tdfnet_f16.hip $ROOT/audiolab_amd/csrc/fft_f16.hip"
 COMMON="-std=c++17 -fPIC -shared -pthread -I$HERE -I$ROOT/audiolab_amd/csrc -Wno-unused-value -Wno-pass-failed -Wno-unknown-pragmas"
 XS=""
 for f in $SRC; do XS="$XS -x c++ $f"; done

@@ -125,6 +125,29 @@ static inline emul_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(emul_bf16x8 a, 
     return c;
 }
 
+typedef _Float16 emul_f16x8 __attribute__((ext_vector_type(8)));
+static inline emul_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_f16(emul_f16x8 a, emul_f16x8 b, emul_f32x4 c, int, int, int) {
+    char* slab = emul::wave_slab();
+    const int l = emul::lane_id();
+    std::memcpy(slab + l * 256, &a, 16);
+    std::memcpy(slab + l * 256 + 16, &b, 16);
+    emul::wave_sync();
+    const int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r;
+        float s = c[r];
+        for (int g = 0; g < 4; ++g) {
+            emul_f16x8 av, bv;
+            std::memcpy(&av, slab + (16 * g + row) * 256, 16);
+            std::memcpy(&bv, slab + (16 * g + col) * 256 + 16, 16);
+            for (int e = 0; e < 8; ++e) s += (float)av[e] * (float)bv[e];
+        }
+        c[r] = s;
+    }
+    emul::wave_sync();
+    return c;
+}
+
 // lane l: A[l&15][l>>4], B[l>>4][l&15]; k-ordered fmaf chain (matches the hardware's numerics).
 static inline emul_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emul_f32x4 c,
                                                                int, int, int) {

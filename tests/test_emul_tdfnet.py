@@ -136,3 +136,19 @@ def test_net_rejects_bad_inputs(emul):
         TDFNet(cfg, bad, ctx=emul)
     with pytest.raises(AlsepError):                                     # dim_f not divisible by 2^n
         TDFNet(TDFNetConfig(dim_f=36, dim_t=16, n_fft=256, hop=64, num_blocks=5, g=16), sd, ctx=emul)
+
+
+def test_net_f16_g48_vs_storage_oracle(emul):
+    """IEEE-half storage + f16 MFMA (tdfnet_f16.hip: the bf16 kernel sources compiled with _Float16): against the oracle in its
+    half-precision storage mode the only disagreement is flipped roundings; against the fp32 oracle the error is ~8x below bf16's."""
+    from audiolab_amd.tdfnet import TDFNet
+    for nb in (1, 3):
+        cfg, sd = make(dict(dim_f=64, dim_t=16, n_fft=256, hop=64, num_blocks=nb, g=48))
+        net = TDFNet(cfg, sd, ctx=emul, dtype=torch.float16, max_batch=2)
+        x = (torch.randn((2, 4, cfg.dim_f, cfg.dim_t), generator=torch.Generator().manual_seed(7)) * 4.0).to(torch.float16).float()
+        w32 = tdfnet_oracle.forward(sd, x, cfg.num_blocks, cfg.l, cfg.bn)
+        wst = tdfnet_oracle.forward(sd, x, cfg.num_blocks, cfg.l, cfg.bn, storage=torch.float16)
+        got = net.forward_nhwc(x.permute(0, 3, 2, 1).contiguous().to(torch.float16)).float().permute(0, 3, 2, 1)
+        r = lambda a, b: float((a - b).norm() / b.norm())
+        print(f"f16 num_blocks={nb}: vs storage oracle {r(got, wst):.3e}, vs fp32 oracle {r(got, w32):.3e}")
+        assert r(got, wst) < 1e-3 and r(got, w32) < 3e-3

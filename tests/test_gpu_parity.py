@@ -327,6 +327,38 @@ def test_full_size_mdx_bf16_vs_oracle(ctx):
     assert r_32 < 0.3
 
 
+def test_full_size_mdx_f16_vs_oracle(ctx):
+    """IEEE-half storage (ALSEP_F16: the type of the reference's use_autocast=True; BASELINE configs[4]) at the bench geometry, end to
+    end in PCM: 8x finer rounding than bf16.  Same two oracles and yardstick as the bf16 test, plus an absolute bound."""
+    from audiolab_amd.mdx import Predictor
+    from audiolab_amd.tdfnet import TDFNet
+    from oracle import mdx_oracle, tdfnet_oracle
+    c = _full_size_case()
+    cfg, want, sd = c["cfg"], c["want"], c["sd"]
+    net = TDFNet(cfg, sd, ctx=ctx, dtype=torch.float16, max_batch=8)
+    args = types.SimpleNamespace(margin=44100, chunks=0, denoise=False, dim_f=cfg.dim_f, dim_t=8, n_fft=cfg.n_fft)
+    ctx.launch_counts_reset()
+    got = Predictor(args, net, ctx=ctx).demix(torch.from_numpy(c["mix"]).cuda()).cpu().numpy()
+    assert ctx.launch_count("conv3x3_bf16_big_kernel<2>") == 6 and ctx.launch_count("conv3x3_bf16_regw_kernel") == 6   # same kernels, f16 build
+    assert np.isfinite(got).all()
+
+    def model_run_f16(spek):
+        with torch.no_grad():
+            return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)),
+                                         cfg.num_blocks, cfg.l, cfg.bn, storage=torch.float16).numpy()
+    g = mdx_oracle.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
+    want_st = mdx_oracle.demix(c["mix"], g, model_run_f16, chunks=0, margin=44100, dtype=np.float32)
+
+    def rel(a, b):
+        d = (a - b).astype(np.float64)
+        return float(np.sqrt((d ** 2).sum() / (b.astype(np.float64) ** 2).sum()))
+    r_st, r_32, r_oo = rel(got, want_st), rel(got, want), rel(want_st, want)
+    print(f"full-size f16: vs f16-storage oracle rel L2 = {r_st:.3e}; vs fp32 oracle {r_32:.3e} (SDR {-20 * np.log10(r_32):.1f} dB); "
+          f"f16-storage oracle vs fp32 oracle {r_oo:.3e}; max|delta| vs fp32 oracle = {np.max(np.abs(got - want)):.3e}")
+    assert r_st < 0.8 * r_oo and r_32 < 1.25 * r_oo
+    assert r_32 < 5e-2
+
+
 def test_properties_at_baseline_size(ctx):
     """configs[1] size (5 min stereo): the runner is linear with a linear network, and shifting the
     track by one model window (gen samples) shifts the interior of the output by the same amount."""
