@@ -109,6 +109,13 @@ _SIGNATURES = {
     "alsep_demucs_spec_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_float]),
     "alsep_demucs_mix_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64]),
+    "alsep_nn_bgemm_bias": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 +
+                            [C.POINTER(C.c_int64)] * 3 + [C.c_float, C.c_void_p, C.c_int]),
+    "alsep_nn_rmsnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64]),
+    "alsep_nn_rotary": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64]),
+    "alsep_nn_gate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
+    "alsep_roformer_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "alsep_roformer_mask": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 3),
 }
 
 EXPORTS: Tuple[str, ...] = tuple(_SIGNATURES)

@@ -49,7 +49,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 struct GemmStrides { int64_t b1, b2, r, k; };
 __global__ void __launch_bounds__(kNnThreads)
 nn_bgemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int nb2, int M, int N, int K,
-                GemmStrides sa, GemmStrides sb, GemmStrides sc, float alpha) {
+                GemmStrides sa, GemmStrides sb, GemmStrides sc, float alpha, const float* __restrict__ bias, int act) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int b1 = blockIdx.z / nb2, b2 = blockIdx.z % nb2;
@@ -90,7 +90,13 @@ nn_bgemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float*
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + m * 16 + 4 * lq + r;
-                if (row < M) c[(int64_t)row * sc.r + (int64_t)col * sc.k] = alpha * acc[m][n][r];
+                if (row < M) {
+                    float v = alpha * acc[m][n][r];
+                    if (bias) v += bias[col];
+                    if (act == 3) v = gelu_erf(v);
+                    else if (act == 5) v = tanhf(v);
+                    c[(int64_t)row * sc.r + (int64_t)col * sc.k] = v;
+                }
             }
     }
 }
@@ -188,6 +194,7 @@ nn_act_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n_out,
         if (act == 1) r = fmaxf(v, 0.f);
         else if (act == 3) r = gelu_erf(v);
         else if (act == 4) r = v * sigmoidf_(x[row * C + c + Co]);
+        else if (act == 5) r = tanhf(v);
         y[i] = r;
     }
 }
@@ -316,6 +323,89 @@ nn_swap_last2_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t
     }
 }
 
+// lucidrains RMSNorm: y = x / max(||x||_2, 1e-12) * sqrt(C) * gamma over the last axis; row r of x at x + r * x_stride, of y at y + r * y_stride
+// (in place on a column slice of a wider matrix when both strides are that matrix's width).  One wave per row.
+__global__ void __launch_bounds__(kNnThreads)
+nn_rmsnorm_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ gamma, int64_t rows, int C, int64_t x_stride,
+                  int64_t y_stride) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * x_stride;
+    double ss = 0.0;
+    for (int c = lane; c < C; c += 64) ss += (double)xr[c] * (double)xr[c];
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float inv = sqrtf((float)C) / fmaxf((float)sqrt(ss), 1e-12f);
+    float* yr = y + row * y_stride;
+    for (int c = lane; c < C; c += 64) yr[c] = xr[c] * inv * gamma[c];
+}
+// rotary embedding (rotary_embedding_torch, interleaved pairs, theta 10000) in place on heads x d columns starting at col_off of every row;
+// position of row r = (r / pos_div) % pos_mod
+__global__ void __launch_bounds__(kNnThreads)
+nn_rotary_kernel(float* __restrict__ x, int64_t n_pairs, int64_t row_stride, int col_off, int heads, int d, int64_t pos_div, int64_t pos_mod) {
+    const int half = d / 2;
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n_pairs; i += (int64_t)gridDim.x * kNnThreads) {
+        const int j = (int)(i % half);
+        const int h = (int)((i / half) % heads);
+        const int64_t r = i / ((int64_t)half * heads);
+        const float pos = (float)((r / pos_div) % pos_mod);
+        const float inv = 1.f / powf(10000.f, (float)(2 * j) / (float)d);
+        const float ang = pos * inv, cs = cosf(ang), sn = sinf(ang);
+        float* p = x + r * row_stride + col_off + h * d + 2 * j;
+        const float a = p[0], b = p[1];
+        p[0] = a * cs - b * sn;
+        p[1] = b * cs + a * sn;
+    }
+}
+// out[r, h * d + j] *= sigmoid(gates[r, h])
+__global__ void __launch_bounds__(kNnThreads)
+nn_gate_kernel(float* __restrict__ out, const float* __restrict__ gates, int64_t n, int heads, int d) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int64_t r = i / ((int64_t)heads * d);
+        const int h = (int)((i / d) % heads);
+        out[i] *= sigmoidf_(gates[r * heads + h]);
+    }
+}
+// Roformer band split input: feat[t, 2 i + c] = spec[(s * 2 + c), f, t] for the i-th entry m = midx[i] of the concatenated band index
+// lists (m = 2 f + s: frequency-major, channel-minor); spec [4, F, T] as alsep_stft writes it
+__global__ void __launch_bounds__(kNnThreads)
+roformer_gather_kernel(const float* __restrict__ spec, const int* __restrict__ midx, float* __restrict__ feat, int64_t n, int n_idx, int F,
+                       int T) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int c = (int)(i & 1);
+        const int k = (int)((i >> 1) % n_idx);
+        const int64_t t = i / (2 * (int64_t)n_idx);
+        const int m = midx[k], s = m & 1, f = m >> 1;
+        feat[i] = spec[((int64_t)(s * 2 + c) * F + f) * T + t];
+    }
+}
+// Roformer output: for merged bin m = 2 f + s and frame t, mask = (1 / max(n_occ, 1)) * sum over the occurrences o of m in the bands of
+// GLU(h)[o] (complex: columns col_a[o], col_a[o] + 1 gated by col_g[o], col_g[o] + 1 of h [T, H]); out = spec * mask (complex), same layout
+__global__ void __launch_bounds__(kNnThreads)
+roformer_mask_kernel(const float* __restrict__ spec, const float* __restrict__ h, const int* __restrict__ occ_start,
+                     const int* __restrict__ col_a, const int* __restrict__ col_g, float* __restrict__ out, int64_t n, int F, int T, int H) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int t = (int)(i % T);
+        const int f = (int)((i / T) % F);
+        const int s = (int)(i / ((int64_t)T * F));
+        const int m = 2 * f + s;
+        const int o0 = occ_start[m], o1 = occ_start[m + 1];
+        const float* hr = h + (int64_t)t * H;
+        float mr = 0.f, mi = 0.f;
+        for (int o = o0; o < o1; ++o) {
+            mr += hr[col_a[o]] * sigmoidf_(hr[col_g[o]]);
+            mi += hr[col_a[o] + 1] * sigmoidf_(hr[col_g[o] + 1]);
+        }
+        const float inv = 1.f / (float)(o1 - o0 > 1 ? o1 - o0 : 1);
+        mr *= inv;
+        mi *= inv;
+        const int64_t ire = ((int64_t)(s * 2) * F + f) * T + t, iim = ((int64_t)(s * 2 + 1) * F + f) * T + t;
+        const float zr = spec[ire], zi = spec[iim];
+        out[ire] = zr * mr - zi * mi;
+        out[iim] = zr * mi + zi * mr;
+    }
+}
+
 unsigned ew_grid(int64_t n) {
     int64_t b = ceil_div64(n, kNnThreads);
     if (b < 1) b = 1;
@@ -333,7 +423,20 @@ extern "C" int alsep_nn_bgemm(alsep_ctx* ctx, const float* A, const float* B, fl
            "alsep_nn_bgemm");
     GemmStrides a{sa[0], sa[1], sa[2], sa[3]}, b{sb[0], sb[1], sb[2], sb[3]}, c{sc[0], sc[1], sc[2], sc[3]};
     hipLaunchKernelGGL(nn_bgemm_kernel, dim3((unsigned)ceil_div64(N, 128), (unsigned)ceil_div64(M, 64), (unsigned)(nb1 * nb2)),
-                       dim3(kNnThreads), 0, ctx->stream, A, B, C, nb2, M, N, K, a, b, c, alpha);
+                       dim3(kNnThreads), 0, ctx->stream, A, B, C, nb2, M, N, K, a, b, c, alpha, (const float*)nullptr, 0);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_bgemm_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_bgemm_bias(alsep_ctx* ctx, const float* A, const float* B, float* C, int nb1, int nb2, int M, int N, int K,
+                                   const int64_t* sa, const int64_t* sb, const int64_t* sc, float alpha, const float* bias, int act) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && A && B && C && sa && sb && sc && nb1 > 0 && nb2 > 0 && M > 0 && N > 0 && K > 0 && (int64_t)nb1 * nb2 <= 65535 &&
+               (act == 0 || act == 3 || act == 5),
+           "alsep_nn_bgemm_bias");
+    GemmStrides a{sa[0], sa[1], sa[2], sa[3]}, b{sb[0], sb[1], sb[2], sb[3]}, c{sc[0], sc[1], sc[2], sc[3]};
+    hipLaunchKernelGGL(nn_bgemm_kernel, dim3((unsigned)ceil_div64(N, 128), (unsigned)ceil_div64(M, 64), (unsigned)(nb1 * nb2)),
+                       dim3(kNnThreads), 0, ctx->stream, A, B, C, nb2, M, N, K, a, b, c, alpha, bias, act);
     ALSEP_LAUNCH_CHECK(ctx, "nn_bgemm_kernel");
     return ALSEP_OK;
 }
@@ -412,7 +515,7 @@ extern "C" int alsep_nn_affine_stats(alsep_ctx* ctx, const float* x, float* y, c
 
 extern "C" int alsep_nn_act(alsep_ctx* ctx, const float* x, float* y, int64_t rows, int C, int act) {
     ALSEP_ENTER(ctx);
-    NN_ARG(ctx && x && y && rows > 0 && C > 0 && (act == 1 || act == 3 || (act == 4 && C % 2 == 0)), "alsep_nn_act");
+    NN_ARG(ctx && x && y && rows > 0 && C > 0 && (act == 1 || act == 3 || act == 5 || (act == 4 && C % 2 == 0)), "alsep_nn_act");
     const int64_t n_out = rows * (act == 4 ? C / 2 : C);
     hipLaunchKernelGGL(nn_act_kernel, dim3(ew_grid(n_out)), dim3(kNnThreads), 0, ctx->stream, x, y, n_out, C, act);
     ALSEP_LAUNCH_CHECK(ctx, "nn_act_kernel");
@@ -511,5 +614,56 @@ extern "C" int alsep_nn_swap_last2(alsep_ctx* ctx, const float* x, float* y, int
     NN_ARG(ctx && x && y && B > 0 && C > 0 && L > 0, "alsep_nn_swap_last2");
     hipLaunchKernelGGL(nn_swap_last2_kernel, dim3(ew_grid(B * C * L)), dim3(kNnThreads), 0, ctx->stream, x, y, B * C * L, C, L);
     ALSEP_LAUNCH_CHECK(ctx, "nn_swap_last2_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_rmsnorm(alsep_ctx* ctx, const float* x, float* y, const float* gamma, int64_t rows, int C, int64_t x_stride,
+                                int64_t y_stride) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && x && y && gamma && rows > 0 && C > 0 && x_stride >= C && y_stride >= C, "alsep_nn_rmsnorm");
+    hipLaunchKernelGGL(nn_rmsnorm_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(kNnThreads), 0, ctx->stream, x, y, gamma, rows, C, x_stride,
+                       y_stride);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_rmsnorm_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_rotary(alsep_ctx* ctx, float* x, int64_t rows, int64_t row_stride, int col_off, int heads, int d, int64_t pos_div,
+                               int64_t pos_mod) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && x && rows > 0 && heads > 0 && d > 0 && d % 2 == 0 && col_off >= 0 && col_off + heads * d <= row_stride && pos_div > 0 &&
+               pos_mod > 0,
+           "alsep_nn_rotary");
+    const int64_t n = rows * heads * (d / 2);
+    hipLaunchKernelGGL(nn_rotary_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, x, n, row_stride, col_off, heads, d, pos_div,
+                       pos_mod);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_rotary_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_gate(alsep_ctx* ctx, float* out, const float* gates, int64_t rows, int heads, int d) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && out && gates && rows > 0 && heads > 0 && d > 0, "alsep_nn_gate");
+    hipLaunchKernelGGL(nn_gate_kernel, dim3(ew_grid(rows * heads * d)), dim3(kNnThreads), 0, ctx->stream, out, gates, rows * heads * d, heads, d);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_gate_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_roformer_gather(alsep_ctx* ctx, const float* spec, const int* midx, float* feat, int n_idx, int F, int T) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && spec && midx && feat && n_idx > 0 && F > 0 && T > 0, "alsep_roformer_gather");
+    const int64_t n = (int64_t)T * n_idx * 2;
+    hipLaunchKernelGGL(roformer_gather_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, spec, midx, feat, n, n_idx, F, T);
+    ALSEP_LAUNCH_CHECK(ctx, "roformer_gather_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_roformer_mask(alsep_ctx* ctx, const float* spec, const float* h, const int* occ_start, const int* col_a, const int* col_g,
+                                   float* out, int F, int T, int H) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && spec && h && occ_start && col_a && col_g && out && F > 0 && T > 0 && H > 0, "alsep_roformer_mask");
+    const int64_t n = 2 * (int64_t)F * T;
+    hipLaunchKernelGGL(roformer_mask_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, spec, h, occ_start, col_a, col_g, out, n, F, T,
+                       H);
+    ALSEP_LAUNCH_CHECK(ctx, "roformer_mask_kernel");
     return ALSEP_OK;
 }

@@ -38,6 +38,7 @@ from ._lib import AlsepError, Context
 from .mdx import Predictor
 from .synth import synthetic_state_dict
 from .htdemucs import DemucsRunner, HTDemucs, HTDemucsConfig
+from .roformer import Roformer, RoformerConfig, RoformerRunner
 from .tdfnet import TDFNet, TDFNetConfig
 
 logger = logging.getLogger(__name__)
@@ -67,6 +68,20 @@ MODEL_ROSTER: Dict[str, tuple] = {
     "kuielab_a_drums.onnx": ("Drums", "No Drums", _cfg(4096, 2048, 128), {"compensate": 1.035}),
     "kuielab_a_bass.onnx": ("Bass", "No Bass", _cfg(16384, 2048, 512), {"compensate": 1.035}),
     "kuielab_a_other.onnx": ("Other", "No Other", _cfg(8192, 2048, 512), {"compensate": 1.035}),
+    # Roformer members of the ensemble (stem_separator.py:380-382) and the de-reverb / de-echo transforms (:796-797, wrappers/separate.py:
+    # 123-130).  Hyper-parameters as published with the checkpoints (upstream, uncited); a ``<name>.yaml`` beside the weights overrides them.
+    "vocals_mel_band_roformer.ckpt": ("roformer", RoformerConfig(kind="mel", dim=384, depth=6), {"labels": ("Vocals",), "secondary": "Instrumental"}),
+    "model_bs_roformer_ep_368_sdr_12.9628.ckpt": ("roformer", RoformerConfig(kind="bs", dim=384, depth=12),
+                                                  {"labels": ("Vocals",), "secondary": "Instrumental"}),
+    "melband_roformer_big_beta4.ckpt": ("roformer", RoformerConfig(kind="mel", dim=384, depth=12), {"labels": ("Vocals",), "secondary": "Instrumental"}),
+    "dereverb_mel_band_roformer_anvuew_sdr_19.1729.ckpt": ("roformer", RoformerConfig(kind="mel", dim=384, depth=6),
+                                                           {"labels": ("No Reverb",), "secondary": "Reverb"}),
+    "dereverb-echo_mel_band_roformer_sdr_13.4843_v2.ckpt": ("roformer", RoformerConfig(kind="mel", dim=384, depth=6),
+                                                            {"labels": ("dry",), "secondary": "No dry"}),
+    "dereverb-echo_mel_band_roformer_sdr_10.0169.ckpt": ("roformer", RoformerConfig(kind="mel", dim=384, depth=6),
+                                                         {"labels": ("dry",), "secondary": "No dry"}),
+    "mel_band_roformer_crowd_aufr33_viperx_sdr_8.7144.ckpt": ("roformer", RoformerConfig(kind="mel", dim=384, depth=6),
+                                                              {"labels": ("No Crowd",), "secondary": "Crowd"}),
     # the multi-stem stage (stem_separator.py:466): HTDemucs 6 sources on the full mix; DemucsSeparator defaults shifts 2, overlap 0.25
     "htdemucs_6s.yaml": ("demucs", HTDemucsConfig(), {"shifts": 2, "overlap": 0.25}),
 }
@@ -90,6 +105,7 @@ class _ModelInstance:
         self.model_run = net                                  # callable(spek) -> pred, the patch_separate seam
         self.extra: List[tuple] = []                          # multi-stem models: further (label, net, predictor)
         self.demucs: Optional[DemucsRunner] = None            # Demucs-family model: one network, all sources at once
+        self.roformer: Optional[RoformerRunner] = None        # Roformer-family model: its own chunked runner
 
 
 class Separator:
@@ -154,6 +170,9 @@ class Separator:
         if entry[0] == "demucs":
             self._load_demucs(model_filename, entry)
             return
+        if entry[0] == "roformer":
+            self._load_roformer(model_filename, entry)
+            return
         meta = entry[3] if len(entry) > 3 and entry[0] != "multi" else {}
         entry = entry[:3]
         provenance = []
@@ -216,8 +235,9 @@ class Separator:
         cfg = entry[1]
         opts = entry[2] if len(entry) > 2 else {}
         pt = os.path.join(self.model_file_dir, model_filename + ".pt")
-        if os.path.exists(pt):
-            sd, weights = torch.load(pt, map_location="cpu", weights_only=True), "real"
+        sd = self._weights_file(model_filename)
+        if sd is not None:
+            weights = "real"
         elif self.allow_synthetic:
             from .htdemucs import synthetic_state_dict as demucs_synth
             seed = int.from_bytes(hashlib.sha256(model_filename.encode()).digest()[:4], "little")
@@ -230,6 +250,62 @@ class Separator:
         net = HTDemucs(cfg, sd, ctx=self.ctx)
         inst = _ModelInstance(model_filename, net, None, cfg.sources[0].capitalize(), None)
         inst.demucs = DemucsRunner(net, shifts=int(opts.get("shifts", 2)), overlap=float(opts.get("overlap", 0.25)), sharded=self.sharded)
+        inst.output_dir = self.output_dir
+        inst.weights = weights
+        self._cache[model_filename] = inst
+        self.model_instance = inst
+
+    def _weights_file(self, model_filename: str):
+        """state_dict of ``<dir>/<name>`` (a .ckpt / .pth / .pt written with torch.save; plain tensors only: weights_only) or ``<name>.pt``"""
+        for cand in (os.path.join(self.model_file_dir, model_filename), os.path.join(self.model_file_dir, model_filename + ".pt")):
+            if os.path.isfile(cand) and not cand.lower().endswith((".onnx", ".yaml")):
+                sd = torch.load(cand, map_location="cpu", weights_only=True)
+                if isinstance(sd, dict) and isinstance(sd.get("state_dict"), dict):
+                    sd = sd["state_dict"]
+                if isinstance(sd, dict) and isinstance(sd.get("state"), dict):
+                    sd = sd["state"]
+                return sd
+        return None
+
+    def _load_roformer(self, model_filename: str, entry: tuple) -> None:
+        """("roformer", RoformerConfig, {labels, secondary}).  A ``<name>.yaml`` in the training project's layout beside the weights
+        (model: dim / depth / heads / dim_head / num_bands | freqs_per_bands / stft_n_fft / stft_hop_length / num_stems /
+        mask_estimator_depth / mlp_expansion_factor; audio: chunk_size; inference: num_overlap) overrides the roster's hyper-parameters."""
+        import dataclasses
+        cfg, opts = entry[1], (entry[2] if len(entry) > 2 else {})
+        ypath = os.path.join(self.model_file_dir, os.path.splitext(model_filename)[0] + ".yaml")
+        if os.path.isfile(ypath):
+            import yaml
+            y = yaml.safe_load(open(ypath)) or {}
+            m, over = y.get("model", {}) or {}, {}
+            for src, dst in (("dim", "dim"), ("depth", "depth"), ("heads", "heads"), ("dim_head", "dim_head"), ("num_bands", "num_bands"),
+                             ("num_stems", "num_stems"), ("stft_n_fft", "n_fft"), ("stft_hop_length", "hop"),
+                             ("mask_estimator_depth", "mask_estimator_depth"), ("mlp_expansion_factor", "mlp_expansion_factor"),
+                             ("sample_rate", "sample_rate")):
+                if src in m:
+                    over[dst] = int(m[src])
+            if "freqs_per_bands" in m:
+                over["freqs_per_bands"], over["kind"] = tuple(int(v) for v in m["freqs_per_bands"]), "bs"
+            elif "num_bands" in m:
+                over["kind"] = "mel"
+            if "chunk_size" in (y.get("audio") or {}):
+                over["chunk_size"] = int(y["audio"]["chunk_size"])
+            if "num_overlap" in (y.get("inference") or {}):
+                over["num_overlap"] = int(y["inference"]["num_overlap"])
+            cfg = dataclasses.replace(cfg, **over)
+        sd, weights = self._weights_file(model_filename), "real"
+        if sd is None:
+            if not self.allow_synthetic:
+                raise AlsepError(f"model '{model_filename}': no weight file under {self.model_file_dir}; random-init weights are only used "
+                                 f"with Separator(allow_synthetic=True)")
+            from .roformer import synthetic_state_dict as roformer_synth
+            seed = int.from_bytes(hashlib.sha256(model_filename.encode()).digest()[:4], "little")
+            sd, weights = roformer_synth(cfg, seed=seed), "synthetic"
+            logger.warning("%s: no weight file under %s -- SYNTHETIC random-init weights (allow_synthetic=True)", model_filename, self.model_file_dir)
+        net = Roformer(cfg, sd, ctx=self.ctx)
+        labels = tuple(opts.get("labels", ("Vocals",)))[: cfg.num_stems]
+        inst = _ModelInstance(model_filename, net, None, labels[0], opts.get("secondary") if cfg.num_stems == 1 else None)
+        inst.roformer = RoformerRunner(net, labels)
         inst.output_dir = self.output_dir
         inst.weights = weights
         self._cache[model_filename] = inst
@@ -264,6 +340,14 @@ class Separator:
         inst = self.model_instance
         if inst.demucs is not None:                             # all sources from one pass; labels as DemucsSeparator names its files
             return {name.capitalize(): t for name, t in inst.demucs.separate(m).items()}
+        if inst.roformer is not None:
+            out = inst.roformer.separate(m)
+            if inst.secondary_stem_name:                        # single-target model: the other stem is mix - target
+                sec = m.clone()
+                first = out[inst.primary_stem_name].contiguous()
+                self.ctx.check(self.ctx.lib.alsep_axpby(self.ctx.handle, -1.0, _lib.ptr(first), 1.0, _lib.ptr(sec), sec.numel()), "alsep_axpby")
+                out[inst.secondary_stem_name] = sec
+            return out
         primary = inst.predictor.demix(m)
         if primary.dim() == 3:                                  # Predictor returns [1,2,N] like the reference
             primary = primary[0]

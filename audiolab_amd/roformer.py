@@ -1,0 +1,368 @@
+"""Roformer separation networks (BS-RoFormer, Mel-Band RoFormer) on the GPU -- the first members of the reference's default
+ensemble (modules/separator/stem_separator.py:379-382: ``vocals_mel_band_roformer.ckpt``, ``model_bs_roformer_ep_368_sdr_12.9628.ckpt``,
+``melband_roformer_big_beta4.ckpt``) and its de-reverb / de-echo transforms (:796-797), reached there through
+``Separator.load_model(<name>.ckpt)`` / ``.separate``.
+
+The network code lives in the un-vendored ``audio-separator[gpu]>=0.32.0`` (setup.sh:96): PARITY UNPINNED -- restated from the published
+design; oracle/roformer_oracle.py is the torch-CPU fp32 twin the kernels are checked against.  Parameter names are that code's
+(``band_split.to_features.{i}.1.weight``, ``layers.{l}.{0|1}.layers.0.0.to_qkv.weight``, ``mask_estimators.{s}.to_freqs.{i}.0.net.{2j}.weight``),
+so a real ``state_dict`` loads as it is; the band layout (contiguous ``freqs_per_bands`` or the bins under each slaney mel filter) is
+rebuilt from the hyper-parameters.
+
+Everything runs in libalsep.so on float32 tensors (csrc/nn.hip): tokens are kept ``[T, bands, dim]`` for the whole network -- the time
+transformer (attention over frames within a band) and the frequency transformer (attention over bands within a frame) differ only in
+the strides given to the batched GEMMs and in the position fed to the rotary embedding, so nothing is ever transposed.  STFT / iSTFT:
+the n_fft 2048 / hop 441 kernels of csrc/fft.hip.  Runner: the chunked inference of the training project (chunks every
+``chunk_size / num_overlap`` samples of the reflect-padded track, linear edge fades, sum / counter).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AlsepError, Context
+
+BS_FREQS_PER_BANDS = (2,) * 24 + (4,) * 12 + (12,) * 8 + (24,) * 8 + (48,) * 8 + (128, 129)
+
+
+@dataclass(frozen=True)
+class RoformerConfig:
+    kind: str = "bs"                       # "bs" | "mel"
+    dim: int = 384
+    depth: int = 12
+    heads: int = 8
+    dim_head: int = 64
+    num_stems: int = 1
+    n_fft: int = 2048
+    hop: int = 441
+    num_bands: int = 60
+    freqs_per_bands: Tuple[int, ...] = BS_FREQS_PER_BANDS
+    sample_rate: int = 44100
+    mask_estimator_depth: int = 2
+    mlp_expansion_factor: int = 4
+    chunk_size: int = 352800
+    num_overlap: int = 4
+
+    @property
+    def n_freq(self) -> int:
+        return self.n_fft // 2 + 1
+
+
+def _mel_points(sr: int, n_mels: int) -> np.ndarray:
+    """slaney mel scale: n_mels + 2 band edges in Hz between 0 and sr / 2 (librosa.mel_frequencies, htk=False)"""
+    f_sp, min_log_hz = 200.0 / 3, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, math.log(6.4) / 27.0
+
+    def to_mel(f):
+        return min_log_mel + math.log(f / min_log_hz) / logstep if f >= min_log_hz else f / f_sp
+    m = np.linspace(to_mel(0.0), to_mel(sr / 2.0), n_mels + 2)
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def band_indices(cfg: RoformerConfig) -> List[np.ndarray]:
+    """per band: indices into the merged (frequency, channel) axis, m = 2 f + s"""
+    nf = cfg.n_freq
+    if cfg.kind == "bs":
+        if sum(cfg.freqs_per_bands) != nf:
+            raise AlsepError("freqs_per_bands must sum to n_fft / 2 + 1")
+        edges = np.cumsum((0,) + tuple(cfg.freqs_per_bands))
+        per_f = [np.arange(edges[i], edges[i + 1]) for i in range(len(cfg.freqs_per_bands))]
+    elif cfg.kind == "mel":
+        # bins with a positive weight under each triangular filter of librosa.filters.mel(sr, n_fft, n_mels); the first filter also takes
+        # bin 0 and the last one the Nyquist bin (mel_band_roformer.py sets those two weights to 1)
+        pts = _mel_points(cfg.sample_rate, cfg.num_bands)
+        freqs = np.linspace(0, cfg.sample_rate / 2.0, nf)
+        per_f = []
+        for i in range(cfg.num_bands):
+            lower = (freqs - pts[i]) / (pts[i + 1] - pts[i])
+            upper = (pts[i + 2] - freqs) / (pts[i + 2] - pts[i + 1])
+            wt = np.maximum(0.0, np.minimum(lower, upper)) * (2.0 / (pts[i + 2] - pts[i]))
+            on = wt.astype(np.float32) > 0
+            if i == 0:
+                on[0] = True
+            if i == cfg.num_bands - 1:
+                on[-1] = True
+            per_f.append(np.nonzero(on)[0])
+    else:
+        raise AlsepError("RoformerConfig.kind must be 'bs' or 'mel'")
+    return [(f[:, None] * 2 + np.arange(2)[None]).reshape(-1) for f in per_f]
+
+
+class _Lin:
+    def __init__(self, ctx: Context, w: torch.Tensor, b: Optional[torch.Tensor]):
+        self.out, self.inp = (int(v) for v in w.shape)
+        self.w = w.detach().float().contiguous().to(ctx.device)              # [out, in]: the B operand of alsep_nn_bgemm (rows n, k contiguous)
+        self.b = b.detach().float().contiguous().to(ctx.device) if b is not None else None
+
+
+class Roformer:
+    def __init__(self, cfg: RoformerConfig, state_dict: Dict[str, torch.Tensor], ctx: Optional[Context] = None):
+        self.cfg = cfg
+        self.ctx = ctx if ctx is not None else _lib.default_context(None)
+        self.dtype = torch.float32
+        sd = state_dict
+        dev = self.ctx.device
+        bands = band_indices(cfg)
+        self.nb = len(bands)
+        self.band_len = [len(b) for b in bands]
+        self.band_off = np.concatenate([[0], np.cumsum(self.band_len)]).astype(np.int64)      # offsets in merged-index entries
+        self.n_idx = int(self.band_off[-1])
+        self.midx = torch.from_numpy(np.concatenate(bands).astype(np.int32)).to(dev)
+        # occurrences of every merged bin in the concatenated band lists (CSR), with the columns of the mask estimator's output
+        H = 4 * self.n_idx                                                  # per band 2 * (2 len): value half | gate half
+        occ: List[List[Tuple[int, int]]] = [[] for _ in range(2 * cfg.n_freq)]
+        for bi, idx in enumerate(bands):
+            cb, n = 4 * int(self.band_off[bi]), 2 * len(idx)
+            for i, m in enumerate(idx):
+                occ[int(m)].append((cb + 2 * i, cb + n + 2 * i))
+        if any(len(o) == 0 for o in occ):
+            raise AlsepError("band layout leaves a frequency bin uncovered")
+        self.occ_start = torch.tensor(np.concatenate([[0], np.cumsum([len(o) for o in occ])]), dtype=torch.int32, device=dev)
+        self.col_a = torch.tensor([a for o in occ for a, _ in o], dtype=torch.int32, device=dev)
+        self.col_g = torch.tensor([g for o in occ for _, g in o], dtype=torch.int32, device=dev)
+        self.H = H
+        try:
+            v = lambda k: sd[k].detach().float().contiguous().to(dev)
+            self.split = [(v(f"band_split.to_features.{i}.0.gamma"),
+                           _Lin(self.ctx, sd[f"band_split.to_features.{i}.1.weight"], sd[f"band_split.to_features.{i}.1.bias"]))
+                          for i in range(self.nb)]
+            self.layers = []
+            for li in range(cfg.depth):
+                pair = []
+                for tr in (0, 1):
+                    p = f"layers.{li}.{tr}.layers.0"
+                    pair.append(dict(norm=v(p + ".0.norm.gamma"), qkv=_Lin(self.ctx, sd[p + ".0.to_qkv.weight"], None),
+                                     gates=_Lin(self.ctx, sd[p + ".0.to_gates.weight"], sd[p + ".0.to_gates.bias"]),
+                                     out=_Lin(self.ctx, sd[p + ".0.to_out.0.weight"], None), ffn=v(p + ".1.net.0.gamma"),
+                                     l1=_Lin(self.ctx, sd[p + ".1.net.1.weight"], sd[p + ".1.net.1.bias"]),
+                                     l2=_Lin(self.ctx, sd[p + ".1.net.4.weight"], sd[p + ".1.net.4.bias"])))
+                self.layers.append(pair)
+            self.final_norm = v("final_norm.gamma")
+            self.masks = [[[_Lin(self.ctx, sd[f"mask_estimators.{s}.to_freqs.{i}.0.net.{2 * j}.weight"],
+                                 sd[f"mask_estimators.{s}.to_freqs.{i}.0.net.{2 * j}.bias"]) for j in range(cfg.mask_estimator_depth)]
+                           for i in range(self.nb)] for s in range(cfg.num_stems)]
+        except KeyError as e:
+            raise AlsepError(f"state_dict is missing {e} for this RoformerConfig") from e
+        self._plans: Dict[int, object] = {}
+
+    # -- helpers --------------------------------------------------------------------------------------------
+    def _gemm(self, a_ptr: int, sa, lin: _Lin, c_ptr: int, sc, M: int, act: int = 0, nb1: int = 1, nb2: int = 1, use_bias: bool = True) -> None:
+        """C = act(A W^T + b) with A / C given by (pointer, strides)"""
+        ctx = self.ctx
+        arr = C.c_int64 * 4
+        bias = _lib.ptr(lin.b) if (lin.b is not None and use_bias) else None
+        ctx.check(ctx.lib.alsep_nn_bgemm_bias(ctx.handle, C.c_void_p(a_ptr), _lib.ptr(lin.w), C.c_void_p(c_ptr), nb1, nb2, M, lin.out, lin.inp,
+                                              arr(*sa), arr(0, 0, lin.inp, 1), arr(*sc), 1.0, bias, act), "alsep_nn_bgemm_bias")
+
+    def _dense(self, x: torch.Tensor, rows: int, lin: _Lin, act: int = 0) -> torch.Tensor:
+        y = self.ctx.empty((rows, lin.out))
+        self._gemm(x.data_ptr(), (0, 0, lin.inp, 1), lin, y.data_ptr(), (0, 0, lin.out, 1), rows, act)
+        return y
+
+    def _rmsnorm(self, x: torch.Tensor, rows: int, Cn: int, gamma: torch.Tensor) -> torch.Tensor:
+        ctx = self.ctx
+        y = ctx.empty((rows, Cn))
+        ctx.check(ctx.lib.alsep_nn_rmsnorm(ctx.handle, _lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), rows, Cn, Cn, Cn), "alsep_nn_rmsnorm")
+        return y
+
+    def _transformer(self, x: torch.Tensor, T: int, P, over_time: bool) -> torch.Tensor:
+        """x [T, bands, dim] -> same.  over_time: sequences are the frames of one band; else the bands of one frame."""
+        ctx, cfg = self.ctx, self.cfg
+        lib, h = ctx.lib, ctx.handle
+        nb, dim, Hh, d = self.nb, cfg.dim, cfg.heads, cfg.dim_head
+        inner = Hh * d
+        rows = T * nb
+        xn = self._rmsnorm(x, rows, dim, P["norm"])
+        qkv = self._dense(xn, rows, P["qkv"])                                 # [rows, 3 inner], columns (qkv, head, d)
+        pos = (nb, T) if over_time else (1, nb)                               # row r = t * bands + f: position t, or f
+        for off in (0, inner):
+            ctx.check(lib.alsep_nn_rotary(h, _lib.ptr(qkv), rows, 3 * inner, off, Hh, d, pos[0], pos[1]), "alsep_nn_rotary")
+        arr = C.c_int64 * 4
+        ld = 3 * inner
+        if over_time:                                                         # batch (band, head); a sequence's rows are bands * ld apart
+            n_seq, L, seq_stride, row_stride = nb, T, ld, nb * ld
+        else:                                                                 # batch (frame, head); rows are ld apart
+            n_seq, L, seq_stride, row_stride = T, nb, nb * ld, ld
+        scores = ctx.empty((n_seq, Hh, L, L))
+        base = qkv.data_ptr()
+        ctx.check(lib.alsep_nn_bgemm(h, C.c_void_p(base), C.c_void_p(base + 4 * inner), _lib.ptr(scores), n_seq, Hh, L, L, d,
+                                     arr(seq_stride, d, row_stride, 1), arr(seq_stride, d, row_stride, 1), arr(Hh * L * L, L * L, L, 1),
+                                     d ** -0.5), "alsep_nn_bgemm")
+        ctx.check(lib.alsep_nn_softmax_rows(h, _lib.ptr(scores), n_seq * Hh * L, L), "alsep_nn_softmax_rows")
+        att = ctx.empty((rows, inner))
+        o_seq, o_row = (inner, nb * inner) if over_time else (nb * inner, inner)
+        ctx.check(lib.alsep_nn_bgemm(h, _lib.ptr(scores), C.c_void_p(base + 8 * inner), _lib.ptr(att), n_seq, Hh, L, d, L,
+                                     arr(Hh * L * L, L * L, L, 1), arr(seq_stride, d, 1, row_stride), arr(o_seq, d, o_row, 1), 1.0), "alsep_nn_bgemm")
+        gates = self._dense(xn, rows, P["gates"])
+        ctx.check(lib.alsep_nn_gate(h, _lib.ptr(att), _lib.ptr(gates), rows, Hh, d), "alsep_nn_gate")
+        a = self._dense(att, rows, P["out"])
+        x1 = ctx.empty((rows, dim))
+        ctx.check(lib.alsep_nn_scale_add(h, _lib.ptr(x), _lib.ptr(a), None, _lib.ptr(x1), rows, dim), "alsep_nn_scale_add")
+        f = self._dense(self._rmsnorm(x1, rows, dim, P["ffn"]), rows, P["l1"], act=3)
+        f = self._dense(f, rows, P["l2"])
+        x2 = ctx.empty((rows, dim))
+        ctx.check(lib.alsep_nn_scale_add(h, _lib.ptr(x1), _lib.ptr(f), None, _lib.ptr(x2), rows, dim), "alsep_nn_scale_add")
+        return x2
+
+    def _plan(self, dim_t: int):
+        from .mdx import StftPlan
+        if dim_t not in self._plans:
+            self._plans[dim_t] = StftPlan(self.ctx, self.cfg.n_fft, self.cfg.hop, self.cfg.n_freq, dim_t)
+        return self._plans[dim_t]
+
+    # -- forward --------------------------------------------------------------------------------------------
+    def forward(self, audio: torch.Tensor) -> torch.Tensor:
+        """audio [2, L] float32 on the device, L a multiple of hop -> [num_stems, 2, L]"""
+        ctx, cfg = self.ctx, self.cfg
+        lib, h = ctx.lib, ctx.handle
+        if audio.dim() != 2 or audio.shape[0] != 2 or audio.dtype != torch.float32:
+            raise AlsepError("Roformer.forward expects a float32 [2, L] tensor")
+        L = audio.shape[-1]
+        if L % cfg.hop:
+            raise AlsepError(f"Roformer.forward: length {L} is not a multiple of hop {cfg.hop}")
+        audio = audio.contiguous()
+        T, Fq, nb, dim = L // cfg.hop + 1, cfg.n_freq, self.nb, cfg.dim
+        plan = self._plan(T)
+        spec = plan.stft_strided(audio, L, 2 * L, 1, torch.float32, _lib.LAYOUT_REF)        # [1, 4, Fq, T]
+        feat = ctx.empty((T, 2 * self.n_idx))
+        ctx.check(lib.alsep_roformer_gather(h, _lib.ptr(spec), _lib.ptr(self.midx), _lib.ptr(feat), self.n_idx, Fq, T), "alsep_roformer_gather")
+        x = ctx.empty((T, nb, dim))
+        FW = 2 * self.n_idx
+        for i, (gamma, lin) in enumerate(self.split):                         # band split: RMSNorm + Linear per band, on column slices
+            col = 2 * int(self.band_off[i])
+            p = feat.data_ptr() + 4 * col
+            ctx.check(lib.alsep_nn_rmsnorm(h, C.c_void_p(p), C.c_void_p(p), _lib.ptr(gamma), T, lin.inp, FW, FW), "alsep_nn_rmsnorm")
+            self._gemm(p, (0, 0, FW, 1), lin, x.data_ptr() + 4 * i * dim, (0, 0, nb * dim, 1), T)
+        for pair in self.layers:
+            x = self._transformer(x, T, pair[0], over_time=True)
+            x = self._transformer(x, T, pair[1], over_time=False)
+        x = self._rmsnorm(x, T * nb, dim, self.final_norm)
+        out = ctx.empty((cfg.num_stems, 2, L))
+        hidden = cfg.dim * cfg.mlp_expansion_factor
+        for s in range(cfg.num_stems):
+            hm = ctx.empty((T, self.H))
+            for i in range(nb):
+                cur_ptr, cur_stride = x.data_ptr() + 4 * i * dim, nb * dim
+                nl = len(self.masks[s][i])
+                for j, lin in enumerate(self.masks[s][i]):
+                    if j + 1 < nl:
+                        tmp = ctx.empty((T, lin.out))
+                        self._gemm(cur_ptr, (0, 0, cur_stride, 1), lin, tmp.data_ptr(), (0, 0, lin.out, 1), T, act=5)
+                        cur_ptr, cur_stride, keep = tmp.data_ptr(), lin.out, tmp
+                    else:
+                        self._gemm(cur_ptr, (0, 0, cur_stride, 1), lin, hm.data_ptr() + 4 * 4 * int(self.band_off[i]), (0, 0, self.H, 1), T)
+            masked = ctx.empty((1, 4, Fq, T))
+            ctx.check(lib.alsep_roformer_mask(h, _lib.ptr(spec), _lib.ptr(hm), _lib.ptr(self.occ_start), _lib.ptr(self.col_a), _lib.ptr(self.col_g),
+                                              _lib.ptr(masked), Fq, T, self.H), "alsep_roformer_mask")
+            plan.istft_strided(masked, _lib.LAYOUT_REF, out[s], L, 2 * L, 0, L, L)
+        _ = hidden
+        return out
+
+    __call__ = forward
+
+
+class RoformerRunner:
+    """chunked inference (``demix_track`` of the training project the checkpoints come from): mix [2, L] -> {label: [2, L]}"""
+
+    def __init__(self, net: Roformer, labels: Tuple[str, ...]):
+        self.net, self.ctx, self.labels = net, net.ctx, labels
+        if len(labels) != net.cfg.num_stems:
+            raise AlsepError("one label per stem")
+
+    def demix(self, mix: torch.Tensor) -> torch.Tensor:
+        ctx, net = self.ctx, self.net
+        cfg = net.cfg
+        lib, h = ctx.lib, ctx.handle
+        mix = mix.contiguous().float()
+        L0 = mix.shape[-1]
+        Cn = cfg.chunk_size
+        step = Cn // cfg.num_overlap
+        border = Cn - step
+        padded = L0 > 2 * border and border > 0
+        if padded:
+            buf = ctx.empty((2, L0 + 2 * border))
+            ctx.check(lib.alsep_nn_reflect_pad(h, _lib.ptr(mix), _lib.ptr(buf), 2, L0, border, border), "alsep_nn_reflect_pad")
+            mix = buf
+        total = mix.shape[-1]
+        fade = Cn // 10
+        fin, fout = torch.linspace(0, 1, fade), torch.linspace(1, 0, fade)
+        w_start, w_mid, w_fin = torch.ones(Cn), torch.ones(Cn), torch.ones(Cn)
+        w_start[-fade:] *= fout
+        w_fin[:fade] *= fin
+        w_mid[-fade:] *= fout
+        w_mid[:fade] *= fin
+        wins = [w.to(ctx.device) for w in (w_start, w_mid, w_fin)]
+        S = cfg.num_stems
+        result = ctx.zeros((S * 2, total))
+        counter = torch.zeros(total)
+        for i in range(0, total, step):
+            length = min(Cn, total - i)
+            part = mix[:, i:i + length]
+            if length < Cn:
+                chunk = ctx.zeros((2, Cn))
+                if length > Cn // 2 + 1:                                   # F.pad(mode="reflect") on the right
+                    piece = part.contiguous()
+                    ctx.check(lib.alsep_nn_reflect_pad(h, _lib.ptr(piece), _lib.ptr(chunk), 2, length, 0, Cn - length), "alsep_nn_reflect_pad")
+                else:
+                    chunk[:, :length] = part
+            else:
+                chunk = part.contiguous()
+            y = net.forward(chunk)                                           # [S, 2, Cn]
+            k = 0 if i == 0 else (2 if i + step >= total else 1)
+            ctx.check(lib.alsep_nn_vec_fma(h, C.c_void_p(result.data_ptr() + 4 * i), _lib.ptr(y), _lib.ptr(wins[k]), S * 2, length, total, Cn),
+                      "alsep_nn_vec_fma")
+            counter[i:i + length] += (w_start, w_mid, w_fin)[k][:length]
+        cnt = counter.to(ctx.device)
+        ctx.check(lib.alsep_nn_vec_div(h, _lib.ptr(result), _lib.ptr(cnt), S * 2, total), "alsep_nn_vec_div")
+        out = result.view(S, 2, total)
+        return out[..., border:border + L0].contiguous() if padded else out
+
+    def separate(self, mix: torch.Tensor) -> Dict[str, torch.Tensor]:
+        out = self.demix(mix)
+        return {label: out[i] for i, label in enumerate(self.labels)}
+
+
+# ---- synthetic weights (data only; bench / tests, allow_synthetic=True) -----------------------------------------------------------
+def synthetic_state_dict(cfg: RoformerConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def lin(p, out, inp, bias=True, gain=1.0):
+        b = gain / math.sqrt(inp)
+        sd[p + ".weight"] = (torch.rand(out, inp, generator=g) * 2 - 1) * b
+        if bias:
+            sd[p + ".bias"] = (torch.rand(out, generator=g) * 2 - 1) * b
+
+    def gamma(p, n):
+        sd[p + ".gamma"] = 1.0 + 0.1 * (torch.rand(n, generator=g) * 2 - 1)
+
+    bands = band_indices(cfg)
+    inner = cfg.heads * cfg.dim_head
+    for i, idx in enumerate(bands):
+        gamma(f"band_split.to_features.{i}.0", 2 * len(idx))
+        lin(f"band_split.to_features.{i}.1", cfg.dim, 2 * len(idx))
+    for li in range(cfg.depth):
+        for tr in (0, 1):
+            p = f"layers.{li}.{tr}.layers.0"
+            gamma(p + ".0.norm", cfg.dim)
+            lin(p + ".0.to_qkv", 3 * inner, cfg.dim, bias=False, gain=2.0)
+            lin(p + ".0.to_gates", cfg.heads, cfg.dim)
+            lin(p + ".0.to_out.0", cfg.dim, inner, bias=False)
+            gamma(p + ".1.net.0", cfg.dim)
+            lin(p + ".1.net.1", 4 * cfg.dim, cfg.dim)
+            lin(p + ".1.net.4", cfg.dim, 4 * cfg.dim)
+    gamma("final_norm", cfg.dim)
+    hidden = cfg.dim * cfg.mlp_expansion_factor
+    for s in range(cfg.num_stems):
+        for i, idx in enumerate(bands):
+            p = f"mask_estimators.{s}.to_freqs.{i}.0.net"
+            dims = (cfg.dim,) + (hidden,) * (cfg.mask_estimator_depth - 1) + (2 * len(idx) * 2,)
+            for j in range(cfg.mask_estimator_depth):
+                lin(f"{p}.{2 * j}", dims[j + 1], dims[j], gain=1.5)
+    return sd

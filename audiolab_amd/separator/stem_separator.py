@@ -61,7 +61,10 @@ def _call_progress(callback, frac: float, desc: str, total: int) -> None:
 class EnsembleDemucsMDXMusicSeparationModel:
     """:82-840.  Holds one ``Separator`` (weights stay resident across files and stages)."""
 
-    ENSEMBLE = [("UVR-MDX-NET-Voc_FT.onnx", 6.9, 14.9), ("Kim_Vocal_2.onnx", 6.9, 14.9), ("Kim_Vocal_1.onnx", 6.8, 14.9)]
+    # models_with_weights of the reference, in its order (:379-387): (file, vocal weight, instrumental weight)
+    ENSEMBLE = [("vocals_mel_band_roformer.ckpt", 8.6, 16.0), ("model_bs_roformer_ep_368_sdr_12.9628.ckpt", 8.4, 16.0),
+                ("melband_roformer_big_beta4.ckpt", 8.5, 16.0), ("MDX23C-8KFFT-InstVoc_HQ.ckpt", 7.2, 14.9),
+                ("UVR-MDX-NET-Voc_FT.onnx", 6.9, 14.9), ("Kim_Vocal_2.onnx", 6.9, 14.9), ("Kim_Vocal_1.onnx", 6.8, 14.9)]
 
     def __init__(self, options: Dict, callback: Callable = None, separator: Optional[Separator] = None):
         self.options = options
@@ -113,7 +116,15 @@ class EnsembleDemucsMDXMusicSeparationModel:
                                     "v_weights": [], "i_weights": [], "output_folder": f["output_folder"]} for f in files_data}
         if self.ensemble_strength <= 2:                          # :389-390
             self.options["residual_blend"] = min(float(self.options.get("residual_blend", 0.4)), 0.2)
-        members = self.ENSEMBLE[: max(1, int(self.ensemble_strength))]
+        # the first ``ensemble_strength`` members (:391) -- of those whose architecture the engine's roster knows: with the default roster
+        # that is the reference's list minus the architectures still without kernels (named in the log), with a caller's roster its own models
+        known = [m for m in self.ENSEMBLE if m[0] in self.separator.roster]
+        for m in self.ENSEMBLE:
+            if m[0] not in self.separator.roster:
+                logger.warning("ensemble member '%s' is not in this engine's roster (architecture without kernels yet); skipped", m[0])
+        members = known[: max(1, int(self.ensemble_strength))]
+        if not members:
+            raise RuntimeError("no ensemble member of the reference's list is available in this engine's roster")
         for model_name, v_wt, i_wt in members:                   # model-major: weights resident per model (:393-395)
             self.separator.load_model(model_name)
             for f in files_data:
@@ -379,7 +390,7 @@ def predict_with_model(options: Dict, callback: Callable = None, separator: Opti
     count_v = sum(1 for o in trans_opts if o in {"All", "All Vocals", "Main Vocals"})
     count_i = sum(1 for o in trans_opts if o == "All")
     multi = not model.vocals_only
-    model.total_steps = (min(max(1, model.ensemble_strength), len(model.ENSEMBLE)) * n          # ensemble (:884-886)
+    model.total_steps = (min(max(1, model.ensemble_strength), len([m for m in model.ENSEMBLE if m[0] in model.separator.roster])) * n   # ensemble (:884-886)
                          + (n if model.separate_bg_vocals else 0) + (count_v + count_i) * n      # bg split, transforms
                          + (n if multi else 0) + (n if (model.alt_bass_model and multi) else 0)
                          + (n if (model.separate_drums and multi) else 0) + (n if (model.separate_woodwinds and multi) else 0)

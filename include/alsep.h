@@ -270,6 +270,27 @@ int alsep_demucs_spec_out(alsep_ctx* ctx, const float* x, const float* stats, fl
 /* out [B,S,2,L] = (xt [B,L,S*2] * stdt + meant) + xs [B*S,2,L]   (the last lines of HTDemucs.forward) */
 int alsep_demucs_mix_out(alsep_ctx* ctx, const float* xt, const float* statst, const float* xs, float* out, int64_t B, int S, int64_t L);
 
+/* ---- Roformer family (BS-RoFormer / Mel-Band RoFormer: the first members of the reference's default ensemble and its de-reverb /
+ * de-echo models, stem_separator.py:379-382, 796-797; network source in the un-vendored audio-separator -- PARITY UNPINNED).  Further
+ * building blocks on the same channels-last float32 tensors; activation 5 = tanh. ---- */
+/* alsep_nn_bgemm with an epilogue: C = act(alpha * A B^T + bias[column]); bias may be NULL; act 0, 3 (GELU) or 5 (tanh) */
+int alsep_nn_bgemm_bias(alsep_ctx* ctx, const float* A, const float* B, float* C, int nb1, int nb2, int M, int N, int K, const int64_t* sa,
+                        const int64_t* sb, const int64_t* sc, float alpha, const float* bias, int act);
+/* RMSNorm over the last axis: y = x / max(||x||, 1e-12) * sqrt(C) * gamma; rows at x + r * x_stride / y + r * y_stride (a column slice of a
+ * wider matrix in place when both strides are its width) */
+int alsep_nn_rmsnorm(alsep_ctx* ctx, const float* x, float* y, const float* gamma, int64_t rows, int C, int64_t x_stride, int64_t y_stride);
+/* rotary position embedding (interleaved pairs, theta 10000) in place on the heads * d columns from col_off of every row of x
+ * [rows, row_stride]; position of row r = (r / pos_div) % pos_mod */
+int alsep_nn_rotary(alsep_ctx* ctx, float* x, int64_t rows, int64_t row_stride, int col_off, int heads, int d, int64_t pos_div, int64_t pos_mod);
+/* out [rows, heads * d] *= sigmoid(gates [rows, heads]) per head */
+int alsep_nn_gate(alsep_ctx* ctx, float* out, const float* gates, int64_t rows, int heads, int d);
+/* band-split input: feat [T, 2 * n_idx], feat[t, 2 i + c] = spec[(s*2 + c), f, t] with midx[i] = 2 f + s (spec [4, F, T] from alsep_stft) */
+int alsep_roformer_gather(alsep_ctx* ctx, const float* spec, const int* midx, float* feat, int n_idx, int F, int T);
+/* mask estimator output h [T, H] -> complex masks (GLU, averaged over the bands that cover a bin: occurrences occ_start[m] .. occ_start[m+1]
+ * with value columns col_a[o], col_a[o]+1 and gate columns col_g[o], col_g[o]+1), out = spec * mask, same [4, F, T] layout */
+int alsep_roformer_mask(alsep_ctx* ctx, const float* spec, const float* h, const int* occ_start, const int* col_a, const int* col_g,
+                        float* out, int F, int T, int H);
+
 #ifdef __cplusplus
 }
 #endif

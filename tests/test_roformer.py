@@ -1,0 +1,114 @@
+"""Roformer networks (audiolab_amd/roformer.py -> csrc/nn.hip, fft.hip) against the torch-CPU fp32 oracle (oracle/roformer_oracle.py;
+PARITY UNPINNED: the network code is not in /root/reference) on the emulated kernels and on the GPU: band split (contiguous and
+mel-gathered, overlapping), time / frequency transformers with rotary embeddings and head gates, mask estimators, complex masking with
+per-bin averaging, STFT / iSTFT at a hop that does not divide n_fft, and the chunked runner."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import roformer_oracle as ro
+from tests.conftest import host, on
+
+BS_BANDS = (2,) * 8 + (4,) * 6 + (8,) * 5 + (16,) * 3 + (1,)          # 129 bins
+
+
+def small_cfg(kind, **kw):
+    base = dict(kind=kind, dim=32, depth=2, heads=2, dim_head=16, n_fft=256, hop=60, num_bands=10, freqs_per_bands=BS_BANDS, sample_rate=8000,
+                chunk_size=60 * 30, num_overlap=2, num_stems=2 if kind == "bs" else 1)
+    base.update(kw)
+    return ro.RoformerConfig(**base)
+
+
+def build(dev, ocfg, seed=1):
+    from audiolab_amd.roformer import Roformer, RoformerConfig
+    sd = ro.synthetic_state_dict(ocfg, seed)
+    return Roformer(RoformerConfig(**dataclasses.asdict(ocfg)), sd, ctx=dev), sd
+
+
+def test_band_layouts_match_the_oracle():
+    from audiolab_amd.roformer import RoformerConfig, band_indices
+    for ocfg in (ro.RoformerConfig(kind="mel"), ro.RoformerConfig(kind="bs"), small_cfg("mel"), small_cfg("bs"),
+                 ro.RoformerConfig(kind="mel", num_bands=64, n_fft=4096, hop=512)):
+        want, _ = ro.band_layout(ocfg)
+        got = band_indices(RoformerConfig(**dataclasses.asdict(ocfg)))
+        assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+@pytest.mark.parametrize("kind", ["bs", "mel"])
+def test_forward_one_chunk_vs_oracle(dev, kind):
+    ocfg = small_cfg(kind)
+    net, sd = build(dev, ocfg)
+    x = torch.randn(2, ocfg.chunk_size, generator=torch.Generator().manual_seed(3)) * 0.3
+    want = ro.forward(ocfg, sd, x[None])[0].numpy()
+    got = host(net.forward(on(dev, x)))
+    assert got.shape == want.shape == (ocfg.num_stems, 2, ocfg.chunk_size)
+    err = float(np.max(np.abs(got - want)))
+    print(f"roformer[{kind}] forward: max|delta| = {err:.3e}, peak = {np.max(np.abs(want)):.3f}")
+    assert np.max(np.abs(want)) > 1e-2 and err < 1e-4
+
+
+@pytest.mark.parametrize("kind,n", [("mel", 5000), ("bs", 1000), ("mel", 2500)])
+def test_runner_vs_oracle(dev, kind, n):
+    from audiolab_amd.roformer import RoformerRunner
+    if dev.device.type == "cpu" and n != 5000:
+        pytest.skip("emulated suite keeps one runner case (the others run on the GPU)")
+    ocfg = small_cfg(kind)
+    net, sd = build(dev, ocfg, seed=5)
+    mix = torch.randn(2, n, generator=torch.Generator().manual_seed(9)) * 0.25
+    want = ro.demix_track(ocfg, sd, mix).numpy()
+    labels = ("vocals", "other")[: ocfg.num_stems]
+    out = RoformerRunner(net, labels).separate(on(dev, mix))
+    got = np.stack([host(out[k]) for k in labels])
+    assert got.shape == want.shape
+    assert float(np.max(np.abs(got - want))) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["mel", "bs"])
+def test_full_size_chunk_vs_oracle(gpu_ctx, kind):
+    """the shapes of the reference's ensemble members: Mel-Band RoFormer (60 mel bands, dim 384, depth 6) and BS-RoFormer (62 bands, dim 384,
+    depth 12 -- run here at depth 4 to keep the CPU oracle within the test budget) on one 8 s chunk: |delta| < 1e-4 PCM"""
+    import time
+    from audiolab_amd.roformer import Roformer, RoformerConfig
+    from audiolab_amd.synth import synth_mix
+    ocfg = ro.RoformerConfig(kind=kind, depth=6 if kind == "mel" else 4)
+    sd = ro.synthetic_state_dict(ocfg, 0)
+    net = Roformer(RoformerConfig(**dataclasses.asdict(ocfg)), sd, ctx=gpu_ctx)
+    x = torch.from_numpy(synth_mix(ocfg.chunk_size))
+    want = ro.forward(ocfg, sd, x[None])[0].numpy()
+    gpu_ctx.synchronize()
+    t0 = time.perf_counter()
+    got = net.forward(x.cuda())
+    gpu_ctx.synchronize()
+    dt = time.perf_counter() - t0
+    err = float(np.max(np.abs(got.cpu().numpy() - want)))
+    print(f"roformer[{kind}] full-size chunk: max|delta| = {err:.3e}, peak = {np.max(np.abs(want)):.3f}, {dt * 1e3:.0f} ms (first call)")
+    assert np.max(np.abs(want)) > 1e-2 and err < 1e-4
+
+
+def test_engine_loads_ckpt_and_yaml(dev, tmp_path):
+    """Separator.load_model("vocals_mel_band_roformer.ckpt") -- the reference's first ensemble member (stem_separator.py:380) -- with the
+    weight file (a torch.save'd state_dict) and the training project's yaml beside it: hyper-parameters from the yaml, weights from the file
+    (provenance "real"), Vocals + Instrumental out, equal to the oracle on the same weights."""
+    from audiolab_amd.engine import Separator
+    if dev.device.type == "cpu":
+        pytest.skip("GPU only (the emulated suite covers the network and the runner above)")
+    ocfg = small_cfg("mel")
+    sd = ro.synthetic_state_dict(ocfg, 13)
+    name = "vocals_mel_band_roformer.ckpt"
+    torch.save({"state_dict": sd}, str(tmp_path / name))
+    (tmp_path / "vocals_mel_band_roformer.yaml").write_text(
+        f"audio:\n  chunk_size: {ocfg.chunk_size}\nmodel:\n  dim: {ocfg.dim}\n  depth: {ocfg.depth}\n  heads: {ocfg.heads}\n  dim_head: {ocfg.dim_head}\n"
+        f"  num_bands: {ocfg.num_bands}\n  num_stems: 1\n  stft_n_fft: {ocfg.n_fft}\n  stft_hop_length: {ocfg.hop}\n  sample_rate: {ocfg.sample_rate}\n"
+        f"inference:\n  num_overlap: {ocfg.num_overlap}\n")
+    eng = Separator(model_file_dir=str(tmp_path), ctx=dev, use_autocast=False)
+    eng.load_model(name)
+    assert eng.weights_provenance() == "real"
+    mix = torch.randn(2, 4000, generator=torch.Generator().manual_seed(21)) * 0.25
+    out = eng.separate_array(mix)
+    assert list(out) == ["Vocals", "Instrumental"]
+    want = ro.demix_track(ocfg, sd, mix)[0].numpy()
+    assert float(np.max(np.abs(host(out["Vocals"]) - want))) < 1e-4
+    assert float(np.max(np.abs(host(out["Instrumental"]) - (mix.numpy() - want)))) < 1e-4
