@@ -406,6 +406,86 @@ roformer_mask_kernel(const float* __restrict__ spec, const float* __restrict__ h
     }
 }
 
+// InstanceNorm2d statistics on channels-last data x [P pixels, C]: partial sums per channel over a slab of pixels; thread = channel
+// (consecutive threads read consecutive channels of one pixel: coalesced); part [NB][C][2] in fp64
+__global__ void __launch_bounds__(kNnThreads)
+nn_chan_stats_partial_kernel(const float* __restrict__ x, int64_t P, int C, int nb, double* __restrict__ part) {
+    const int c = blockIdx.x * kNnThreads + threadIdx.x;
+    if (c >= C) return;
+    const int64_t chunk = (P + nb - 1) / nb;
+    const int64_t lo = (int64_t)blockIdx.y * chunk, hi = lo + chunk < P ? lo + chunk : P;
+    double s = 0.0, q = 0.0;
+    for (int64_t p = lo; p < hi; ++p) {
+        const double v = (double)x[p * C + c];
+        s += v;
+        q += v * v;
+    }
+    part[((int64_t)blockIdx.y * C + c) * 2] = s;
+    part[((int64_t)blockIdx.y * C + c) * 2 + 1] = q;
+}
+__global__ void nn_chan_stats_final_kernel(const double* __restrict__ part, int nb, int64_t P, int C, float eps, float* __restrict__ stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nb; ++b) {
+        s += part[((int64_t)b * C + c) * 2];
+        q += part[((int64_t)b * C + c) * 2 + 1];
+    }
+    const double mean = s / (double)P;
+    double var = q / (double)P - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * c] = (float)mean;
+    stats[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+__global__ void __launch_bounds__(kNnThreads)
+nn_chan_norm_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                          const float* __restrict__ stats, int64_t n, int C, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int c = (int)(i % C);
+        float v = (x[i] - stats[2 * c]) * stats[2 * c + 1];
+        if (gamma) v = fmaf(v, gamma[c], beta[c]);
+        y[i] = act == 3 ? gelu_erf(v) : v;
+    }
+}
+__global__ void __launch_bounds__(kNnThreads)
+nn_mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) y[i] = a[i] * b[i];
+}
+// ConvTranspose2d(kernel = stride = (2, 2)), second half: g [H, W, 4 * Cout] (1x1 conv, columns (dy*2+dx)*Cout + co) ->
+// y [2H, 2W, y_ct] channel slice [y_c0, y_c0 + Cout)
+__global__ void __launch_bounds__(kNnThreads)
+nn_depth_to_space2_kernel(const float* __restrict__ g, float* __restrict__ y, int64_t n, int H, int W, int Cout, int y_ct, int y_c0) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int co = (int)(i % Cout);
+        const int64_t p = i / Cout;
+        const int ox = (int)(p % (2 * W)), oy = (int)(p / (2 * W));
+        y[p * y_ct + y_c0 + co] = g[(((int64_t)(oy >> 1) * W + (ox >> 1)) * 4 + (oy & 1) * 2 + (ox & 1)) * Cout + co];
+    }
+}
+// MDX23C input: spec [4, dim_f, T] (alsep_stft reference layout) -> x [T, f, 4 k] with f = dim_f / k sub-band bins:
+// x[t, ff, c2 * k + kk] = spec[c2, kk * f + ff, t]   (STFT.__call__ + cac2cws, transposed to frames-major)
+__global__ void __launch_bounds__(kNnThreads)
+mdx23c_spec_in_kernel(const float* __restrict__ spec, float* __restrict__ x, int64_t n, int f, int k, int T) {
+    const int Cn = 4 * k, dim_f = f * k;
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int ch = (int)(i % Cn), kk = ch % k, c2 = ch / k;
+        const int ff = (int)((i / Cn) % f);
+        const int64_t t = i / ((int64_t)Cn * f);
+        x[i] = spec[((int64_t)c2 * dim_f + kk * f + ff) * T + t];
+    }
+}
+// MDX23C output: y [T, f, S * 4 k] -> spec [S, 4, dim_f, T]: spec[s, c2, kk * f + ff, t] = y[t, ff, (s * 4 + c2) * k + kk]   (cws2cac)
+__global__ void __launch_bounds__(kNnThreads)
+mdx23c_spec_out_kernel(const float* __restrict__ y, float* __restrict__ spec, int64_t n, int S, int f, int k, int T) {
+    const int dim_f = f * k, Cn = S * 4 * k;
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int t = (int)(i % T);
+        const int fb = (int)((i / T) % dim_f), kk = fb / f, ff = fb % f;
+        const int sc = (int)(i / ((int64_t)T * dim_f));       // s * 4 + c2
+        spec[i] = y[((int64_t)t * f + ff) * Cn + sc * k + kk];
+    }
+}
+
 unsigned ew_grid(int64_t n) {
     int64_t b = ceil_div64(n, kNnThreads);
     if (b < 1) b = 1;
@@ -665,5 +745,66 @@ extern "C" int alsep_roformer_mask(alsep_ctx* ctx, const float* spec, const floa
     hipLaunchKernelGGL(roformer_mask_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, spec, h, occ_start, col_a, col_g, out, n, F, T,
                        H);
     ALSEP_LAUNCH_CHECK(ctx, "roformer_mask_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int64_t alsep_nn_instnorm_workspace_bytes(int64_t P, int C) {
+    if (P <= 0 || C <= 0) return -1;
+    int64_t nb = ceil_div64(P, 512);
+    if (nb > 256) nb = 256;
+    return (int64_t)sizeof(double) * 2 * C * nb + (int64_t)sizeof(float) * 2 * C + 64;
+}
+extern "C" int alsep_nn_instnorm(alsep_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta, int64_t P, int C, float eps,
+                                 int act, void* workspace) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && x && y && workspace && P > 0 && C > 0 && (act == 0 || act == 3) && ((gamma == nullptr) == (beta == nullptr)) &&
+               ((uintptr_t)workspace & 7) == 0,
+           "alsep_nn_instnorm");
+    int64_t nb = ceil_div64(P, 512);
+    if (nb > 256) nb = 256;
+    double* part = reinterpret_cast<double*>(workspace);
+    float* stats = reinterpret_cast<float*>(part + 2 * (int64_t)C * nb);
+    hipLaunchKernelGGL(nn_chan_stats_partial_kernel, dim3((unsigned)ceil_div64(C, kNnThreads), (unsigned)nb), dim3(kNnThreads), 0, ctx->stream, x, P,
+                       C, (int)nb, part);
+    hipLaunchKernelGGL(nn_chan_stats_final_kernel, dim3((unsigned)ceil_div64(C, 64)), dim3(64), 0, ctx->stream, (const double*)part, (int)nb, P, C,
+                       eps, stats);
+    hipLaunchKernelGGL(nn_chan_norm_apply_kernel, dim3(ew_grid(P * C)), dim3(kNnThreads), 0, ctx->stream, x, y, gamma, beta, (const float*)stats,
+                       P * C, C, act);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_instnorm kernels");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_mul(alsep_ctx* ctx, const float* a, const float* b, float* y, int64_t n) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && a && b && y && n > 0, "alsep_nn_mul");
+    hipLaunchKernelGGL(nn_mul_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, a, b, y, n);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_mul_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_depth_to_space2(alsep_ctx* ctx, const float* g, float* y, int H, int W, int Cout, int y_ctotal, int y_coff) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && g && y && H > 0 && W > 0 && Cout > 0 && y_coff >= 0 && y_coff + Cout <= y_ctotal, "alsep_nn_depth_to_space2");
+    const int64_t n = 4 * (int64_t)H * W * Cout;
+    hipLaunchKernelGGL(nn_depth_to_space2_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, g, y, n, H, W, Cout, y_ctotal, y_coff);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_depth_to_space2_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_mdx23c_spec_in(alsep_ctx* ctx, const float* spec, float* x, int f, int k, int T) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && spec && x && f > 0 && k > 0 && T > 0, "alsep_mdx23c_spec_in");
+    const int64_t n = (int64_t)T * f * 4 * k;
+    hipLaunchKernelGGL(mdx23c_spec_in_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, spec, x, n, f, k, T);
+    ALSEP_LAUNCH_CHECK(ctx, "mdx23c_spec_in_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_mdx23c_spec_out(alsep_ctx* ctx, const float* y, float* spec, int S, int f, int k, int T) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && y && spec && S > 0 && f > 0 && k > 0 && T > 0, "alsep_mdx23c_spec_out");
+    const int64_t n = (int64_t)S * 4 * f * k * T;
+    hipLaunchKernelGGL(mdx23c_spec_out_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, y, spec, n, S, f, k, T);
+    ALSEP_LAUNCH_CHECK(ctx, "mdx23c_spec_out_kernel");
     return ALSEP_OK;
 }

@@ -38,6 +38,7 @@ from ._lib import AlsepError, Context
 from .mdx import Predictor
 from .synth import synthetic_state_dict
 from .htdemucs import DemucsRunner, HTDemucs, HTDemucsConfig
+from .mdx23c import MDX23C, MDX23CConfig
 from .roformer import Roformer, RoformerConfig, RoformerRunner
 from .tdfnet import TDFNet, TDFNetConfig
 
@@ -82,6 +83,11 @@ MODEL_ROSTER: Dict[str, tuple] = {
                                                          {"labels": ("dry",), "secondary": "No dry"}),
     "mel_band_roformer_crowd_aufr33_viperx_sdr_8.7144.ckpt": ("roformer", RoformerConfig(kind="mel", dim=384, depth=6),
                                                               {"labels": ("No Crowd",), "secondary": "Crowd"}),
+    # MDX23C (TFC-TDF v3): ensemble slot 4 (:383) and the drum-kit splitter (:541; its hyper-parameters are not known offline -- the
+    # InstVoc shape with six instruments stands in until a yaml sits beside the weights)
+    "MDX23C-8KFFT-InstVoc_HQ.ckpt": ("mdx23c", MDX23CConfig(instruments=("vocals", "other")), {"labels": ("Vocals", "Instrumental")}),
+    "MDX23C-DrumSep-aufr33-jarredou.ckpt": ("mdx23c", MDX23CConfig(instruments=("kick", "snare", "toms", "hh", "ride", "crash")),
+                                            {"labels": ("Kick", "Snare", "Toms", "HH", "Ride", "Crash")}),
     # the multi-stem stage (stem_separator.py:466): HTDemucs 6 sources on the full mix; DemucsSeparator defaults shifts 2, overlap 0.25
     "htdemucs_6s.yaml": ("demucs", HTDemucsConfig(), {"shifts": 2, "overlap": 0.25}),
 }
@@ -172,6 +178,9 @@ class Separator:
             return
         if entry[0] == "roformer":
             self._load_roformer(model_filename, entry)
+            return
+        if entry[0] == "mdx23c":
+            self._load_mdx23c(model_filename, entry)
             return
         meta = entry[3] if len(entry) > 3 and entry[0] != "multi" else {}
         entry = entry[:3]
@@ -306,6 +315,48 @@ class Separator:
         labels = tuple(opts.get("labels", ("Vocals",)))[: cfg.num_stems]
         inst = _ModelInstance(model_filename, net, None, labels[0], opts.get("secondary") if cfg.num_stems == 1 else None)
         inst.roformer = RoformerRunner(net, labels)
+        inst.output_dir = self.output_dir
+        inst.weights = weights
+        self._cache[model_filename] = inst
+        self.model_instance = inst
+
+    def _load_mdx23c(self, model_filename: str, entry: tuple) -> None:
+        """("mdx23c", MDX23CConfig, {labels}); a yaml of the training project beside the weights (audio: n_fft / hop_length / dim_f /
+        chunk_size; model: num_subbands / num_scales / num_blocks_per_scale / num_channels / growth / bottleneck_factor; training:
+        instruments; inference: num_overlap) overrides the roster's hyper-parameters."""
+        import dataclasses
+        cfg, opts = entry[1], (entry[2] if len(entry) > 2 else {})
+        labels = tuple(opts.get("labels", tuple(n.capitalize() for n in cfg.instruments)))
+        ypath = os.path.join(self.model_file_dir, os.path.splitext(model_filename)[0] + ".yaml")
+        if os.path.isfile(ypath):
+            import yaml
+            y = yaml.safe_load(open(ypath)) or {}
+            a, m, over = y.get("audio", {}) or {}, y.get("model", {}) or {}, {}
+            for src, dst in (("n_fft", "n_fft"), ("hop_length", "hop"), ("dim_f", "dim_f"), ("chunk_size", "chunk_size")):
+                if src in a:
+                    over[dst] = int(a[src])
+            for key in ("num_subbands", "num_scales", "num_blocks_per_scale", "num_channels", "growth", "bottleneck_factor"):
+                if key in m:
+                    over[key] = int(m[key])
+            if "instruments" in (y.get("training") or {}):
+                over["instruments"] = tuple(str(v) for v in y["training"]["instruments"])
+                if "labels" not in opts or len(opts["labels"]) != len(over["instruments"]):
+                    labels = tuple(n.capitalize() for n in over["instruments"])
+            if "num_overlap" in (y.get("inference") or {}):
+                over["num_overlap"] = int(y["inference"]["num_overlap"])
+            cfg = dataclasses.replace(cfg, **over)
+        sd, weights = self._weights_file(model_filename), "real"
+        if sd is None:
+            if not self.allow_synthetic:
+                raise AlsepError(f"model '{model_filename}': no weight file under {self.model_file_dir}; random-init weights are only used "
+                                 f"with Separator(allow_synthetic=True)")
+            from .mdx23c import synthetic_state_dict as mdx23c_synth
+            seed = int.from_bytes(hashlib.sha256(model_filename.encode()).digest()[:4], "little")
+            sd, weights = mdx23c_synth(cfg, seed=seed), "synthetic"
+            logger.warning("%s: no weight file under %s -- SYNTHETIC random-init weights (allow_synthetic=True)", model_filename, self.model_file_dir)
+        net = MDX23C(cfg, sd, ctx=self.ctx)
+        inst = _ModelInstance(model_filename, net, None, labels[0], None)
+        inst.roformer = RoformerRunner(net, labels)             # the same chunked runner (training project's demix_track)
         inst.output_dir = self.output_dir
         inst.weights = weights
         self._cache[model_filename] = inst

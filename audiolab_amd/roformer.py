@@ -270,7 +270,9 @@ class Roformer:
 class RoformerRunner:
     """chunked inference (``demix_track`` of the training project the checkpoints come from): mix [2, L] -> {label: [2, L]}"""
 
-    def __init__(self, net: Roformer, labels: Tuple[str, ...]):
+    def __init__(self, net, labels: Tuple[str, ...]):
+        """``net``: a Roformer, or any network of the same training project with ``cfg.chunk_size / num_overlap / num_stems`` and
+        ``forward([2, chunk]) -> [num_stems, 2, chunk]`` (MDX23C)"""
         self.net, self.ctx, self.labels = net, net.ctx, labels
         if len(labels) != net.cfg.num_stems:
             raise AlsepError("one label per stem")

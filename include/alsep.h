@@ -291,6 +291,23 @@ int alsep_roformer_gather(alsep_ctx* ctx, const float* spec, const int* midx, fl
 int alsep_roformer_mask(alsep_ctx* ctx, const float* spec, const float* h, const int* occ_start, const int* col_a, const int* col_g,
                         float* out, int F, int T, int H);
 
+/* ---- MDX23C (TFC-TDF v3: ensemble slot 4 and the drum-kit splitter, stem_separator.py:383, 541; network source in the un-vendored
+ * audio-separator -- PARITY UNPINNED).  Further building blocks. ---- */
+/* nn.InstanceNorm2d(affine) on channels-last x [P, C] (one sample): per-channel statistics over the P pixels, y = act(n * gamma + beta);
+ * act 0 or 3 (GELU); gamma / beta may both be NULL */
+int64_t alsep_nn_instnorm_workspace_bytes(int64_t P, int C);
+int alsep_nn_instnorm(alsep_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta, int64_t P, int C, float eps, int act,
+                      void* workspace);
+/* y = a * b element-wise */
+int alsep_nn_mul(alsep_ctx* ctx, const float* a, const float* b, float* y, int64_t n);
+/* second half of ConvTranspose2d(kernel = stride = 2): g [H, W, 4*Cout] (1x1 conv, columns (dy*2+dx)*Cout + co) -> channel slice
+ * [y_coff, y_coff + Cout) of y [2H, 2W, y_ctotal] */
+int alsep_nn_depth_to_space2(alsep_ctx* ctx, const float* g, float* y, int H, int W, int Cout, int y_ctotal, int y_coff);
+/* spec [4, f*k, T] (alsep_stft) -> x [T, f, 4k], x[t, ff, c2*k + kk] = spec[c2, kk*f + ff, t] (STFT + cac2cws of tfc_tdf_v3);
+ * y [T, f, S*4k] -> spec [S, 4, f*k, T] (cws2cac) */
+int alsep_mdx23c_spec_in(alsep_ctx* ctx, const float* spec, float* x, int f, int k, int T);
+int alsep_mdx23c_spec_out(alsep_ctx* ctx, const float* y, float* spec, int S, int f, int k, int T);
+
 #ifdef __cplusplus
 }
 #endif
