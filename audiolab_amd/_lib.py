@@ -122,6 +122,10 @@ _SIGNATURES = {
     "alsep_nn_depth_to_space2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5),
     "alsep_mdx23c_spec_in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "alsep_mdx23c_spec_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "alsep_vr_band_crop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8),
+    "alsep_vr_split_pred": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "alsep_vr_mirror": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4),
+    "alsep_vr_band_spec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8),
 }
 
 EXPORTS: Tuple[str, ...] = tuple(_SIGNATURES)

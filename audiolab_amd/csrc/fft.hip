@@ -171,9 +171,12 @@ template <int N, int NT> struct Fft;
 #define ALSEP_FFT(N_, ...)                                                                 \
     template <int NT> struct Fft<N_, NT> { typedef FftRegs<N_, NT, 1, __VA_ARGS__> Regs; };
 ALSEP_FFT(256, 8, 8, 4)
+ALSEP_FFT(320, 5, 8, 8)
 ALSEP_FFT(384, 3, 2, 8, 8)
 ALSEP_FFT(480, 5, 3, 8, 4)
 ALSEP_FFT(512, 8, 8, 8)
+ALSEP_FFT(640, 5, 8, 8, 2)
+ALSEP_FFT(960, 5, 3, 8, 8)
 ALSEP_FFT(1024, 8, 8, 8, 2)
 ALSEP_FFT(2048, 8, 8, 8, 4)
 ALSEP_FFT(4096, 8, 8, 8, 8)
@@ -186,7 +189,8 @@ ALSEP_FFT(16384, 8, 8, 8, 8, 4)
 
 // 5120: UVR-MDX-NET_Crowd_HQ_1; 6144 / 7680: the UVR vocal / instrumental models; 4096 / 8192 / 16384: the KUIELab drums / other / bass
 // models (kuielab_a_bass.onnx is the alt-bass model of stem_separator.py:512) and HTDemucs (4096)
-#define ALSEP_FOR_EACH_NFFT(X) X(256) X(384) X(480) X(512) X(1024) X(2048) X(4096) X(5120) X(6144) X(7680) X(8192) X(16384)
+// 320 / 640 / 960 (+ 512): the four bands of the VR models (lib_v5/modelparams/4band_v2.json, 4band_v3.json)
+#define ALSEP_FOR_EACH_NFFT(X) X(256) X(320) X(384) X(480) X(512) X(640) X(960) X(1024) X(2048) X(4096) X(5120) X(6144) X(7680) X(8192) X(16384)
 
 constexpr int kFftThreads = 256;
 

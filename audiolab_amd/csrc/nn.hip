@@ -486,6 +486,78 @@ mdx23c_spec_out_kernel(const float* __restrict__ y, float* __restrict__ spec, in
     }
 }
 
+// ---- VR multi-band front / back end (reference modules/rvc/infer/lib/uvr5_pack/lib_v5/spec_utils.py, modules/rvc/infer/modules/uvr5/vr.py) ----
+// complex spectrograms are float2-interleaved [2 channels, bins, frames]; band spectrograms from / for the FFT kernels are [4 = (L_re, L_im,
+// R_re, R_im), Fb, Tb]
+// out[c, o0 + i, t] = gain[i] * band[(2c, 2c+1), f0 + i, t0 + t], i < h, t < l   (combine_spectrograms :95-125; the high-end crop of vr.py:88-96)
+__global__ void __launch_bounds__(kNnThreads)
+vr_band_crop_kernel(const float* __restrict__ band, float* __restrict__ out, const float* __restrict__ gain, int64_t n, int Fb, int Tb, int f0,
+                    int t0, int h, int l, int out_bins, int o0) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int t = (int)(i % l), b = (int)((i / l) % h), c = (int)(i / ((int64_t)l * h));
+        const float g = gain ? gain[b] : 1.f;
+        const int64_t src = ((int64_t)(2 * c) * Fb + f0 + b) * Tb + t0 + t;
+        const int64_t dst = (((int64_t)c * out_bins + o0 + b) * l + t) * 2;
+        out[dst] = g * band[src];
+        out[dst + 1] = g * band[src + (int64_t)Fb * Tb];
+    }
+}
+// y = pred * exp(i angle(X)), v = X - y   (vr.py:110-111; angle(0) = 0)
+__global__ void __launch_bounds__(kNnThreads)
+vr_split_pred_kernel(const float* __restrict__ pred, const float* __restrict__ X, float* __restrict__ y, float* __restrict__ v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const float xr = X[2 * i], xi = X[2 * i + 1];
+        const float m = hypotf(xr, xi);
+        const float pr = m > 0.f ? xr / m : 1.f, pi = m > 0.f ? xi / m : 0.f;
+        const float yr = pred[i] * pr, yi = pred[i] * pi;
+        y[2 * i] = yr;
+        y[2 * i + 1] = yi;
+        v[2 * i] = xr - yr;
+        v[2 * i + 1] = xi - yi;
+    }
+}
+// spec_utils.mirroring("mirroring", :453-470): mirror = flip(|spec_m[:, lo : lo + hh]|) * exp(i angle(he)); out = |he| <= |mirror| ? he : mirror
+__global__ void __launch_bounds__(kNnThreads)
+vr_mirror_kernel(const float* __restrict__ spec_m, const float* __restrict__ he, float* __restrict__ out, int64_t n, int bins, int hh, int l,
+                 int lo) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int t = (int)(i % l), b = (int)((i / l) % hh), c = (int)(i / ((int64_t)l * hh));
+        const int64_t sm = (((int64_t)c * bins + lo + (hh - 1 - b)) * l + t) * 2;
+        const float mag = hypotf(spec_m[sm], spec_m[sm + 1]);
+        const float hr = he[2 * i], hi = he[2 * i + 1];
+        const float hm = hypotf(hr, hi);
+        if (hm <= mag) {
+            out[2 * i] = hr;
+            out[2 * i + 1] = hi;
+        } else {                                              // hm > mag >= 0: the phase of he is defined
+            out[2 * i] = mag * hr / hm;
+            out[2 * i + 1] = mag * hi / hm;
+        }
+    }
+}
+// one band's spectrogram for the iSTFT (cmb_spectrogram_to_wave :353-429): band[(2c, 2c+1), f, t] = gain[f] * (bins of spec_m
+// [o0, o0 + h) at f in [f0, f0 + h); extra[c, f - e0, t] for f in [e0, e0 + eh) when given -- the later assignment wins; 0 elsewhere)
+__global__ void __launch_bounds__(kNnThreads)
+vr_band_spec_kernel(const float* __restrict__ spec_m, const float* __restrict__ extra, const float* __restrict__ gain, float* __restrict__ band,
+                    int64_t n, int bins, int l, int Fb, int f0, int h, int o0, int e0, int eh) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) {
+        const int t = (int)(i % l), f = (int)((i / l) % Fb), c = (int)(i / ((int64_t)l * Fb));
+        float re = 0.f, im = 0.f;
+        if (extra && f >= e0 && f < e0 + eh) {
+            const int64_t s = (((int64_t)c * eh + f - e0) * l + t) * 2;
+            re = extra[s];
+            im = extra[s + 1];
+        } else if (f >= f0 && f < f0 + h) {
+            const int64_t s = (((int64_t)c * bins + o0 + f - f0) * l + t) * 2;
+            re = spec_m[s];
+            im = spec_m[s + 1];
+        }
+        const float g = gain[f];
+        band[((int64_t)(2 * c) * Fb + f) * l + t] = g * re;
+        band[((int64_t)(2 * c + 1) * Fb + f) * l + t] = g * im;
+    }
+}
+
 unsigned ew_grid(int64_t n) {
     int64_t b = ceil_div64(n, kNnThreads);
     if (b < 1) b = 1;
@@ -806,5 +878,48 @@ extern "C" int alsep_mdx23c_spec_out(alsep_ctx* ctx, const float* y, float* spec
     const int64_t n = (int64_t)S * 4 * f * k * T;
     hipLaunchKernelGGL(mdx23c_spec_out_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, y, spec, n, S, f, k, T);
     ALSEP_LAUNCH_CHECK(ctx, "mdx23c_spec_out_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_vr_band_crop(alsep_ctx* ctx, const float* band, float* out, const float* gain, int Fb, int Tb, int f0, int t0, int h, int l,
+                                  int out_bins, int o0) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && band && out && Fb > 0 && Tb > 0 && f0 >= 0 && t0 >= 0 && h > 0 && l > 0 && f0 + h <= Fb && t0 + l <= Tb && o0 >= 0 &&
+               o0 + h <= out_bins,
+           "alsep_vr_band_crop");
+    const int64_t n = 2 * (int64_t)h * l;
+    hipLaunchKernelGGL(vr_band_crop_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, band, out, gain, n, Fb, Tb, f0, t0, h, l, out_bins,
+                       o0);
+    ALSEP_LAUNCH_CHECK(ctx, "vr_band_crop_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_vr_split_pred(alsep_ctx* ctx, const float* pred, const float* X, float* y, float* v, int64_t n) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && pred && X && y && v && n > 0, "alsep_vr_split_pred");
+    hipLaunchKernelGGL(vr_split_pred_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, pred, X, y, v, n);
+    ALSEP_LAUNCH_CHECK(ctx, "vr_split_pred_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_vr_mirror(alsep_ctx* ctx, const float* spec_m, const float* he, float* out, int bins, int hh, int l, int lo) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && spec_m && he && out && bins > 0 && hh > 0 && l > 0 && lo >= 0 && lo + hh <= bins, "alsep_vr_mirror");
+    const int64_t n = 2 * (int64_t)hh * l;
+    hipLaunchKernelGGL(vr_mirror_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, spec_m, he, out, n, bins, hh, l, lo);
+    ALSEP_LAUNCH_CHECK(ctx, "vr_mirror_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_vr_band_spec(alsep_ctx* ctx, const float* spec_m, const float* extra, const float* gain, float* band, int bins, int l,
+                                  int Fb, int f0, int h, int o0, int e0, int eh) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && spec_m && gain && band && bins > 0 && l > 0 && Fb > 0 && f0 >= 0 && h > 0 && f0 + h <= Fb && o0 >= 0 && o0 + h <= bins &&
+               (!extra || (e0 >= 0 && eh > 0 && e0 + eh <= Fb)),
+           "alsep_vr_band_spec");
+    const int64_t n = 2 * (int64_t)Fb * l;
+    hipLaunchKernelGGL(vr_band_spec_kernel, dim3(ew_grid(n)), dim3(kNnThreads), 0, ctx->stream, spec_m, extra, gain, band, n, bins, l, Fb, f0, h,
+                       o0, e0, eh);
+    ALSEP_LAUNCH_CHECK(ctx, "vr_band_spec_kernel");
     return ALSEP_OK;
 }

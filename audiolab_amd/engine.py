@@ -88,6 +88,17 @@ MODEL_ROSTER: Dict[str, tuple] = {
     "MDX23C-8KFFT-InstVoc_HQ.ckpt": ("mdx23c", MDX23CConfig(instruments=("vocals", "other")), {"labels": ("Vocals", "Instrumental")}),
     "MDX23C-DrumSep-aufr33-jarredou.ckpt": ("mdx23c", MDX23CConfig(instruments=("kick", "snare", "toms", "hh", "ride", "crash")),
                                             {"labels": ("Kick", "Snare", "Toms", "HH", "Ride", "Crash")}),
+    # VR-architecture models: woodwinds split (stem_separator.py:596), noise removal (:148, wrappers/separate.py:114-117), the standalone
+    # de-echo / de-reverb list (:1048-1050).  (architecture, parameter set, nout, nout_lstm) and which stem the network predicts are the
+    # values published with the models (upstream, uncited); labels as the orchestrator matches them ("(woodwinds)" :615, "No Noise" :800).
+    # Not here: UVR-BVE-4B_SN-44100-1.pth (:752) -- its parameter set asks for the "stereo_n" channel conversion (modelparams/
+    # 4band_v2_sn.json:48), which the reference tree's own spec_utils does not implement either; the BG-vocal stage stays skipped.
+    "17_HP-Wind_Inst-UVR.pth": ("vr", dict(arch="nets_123821KB", params="4band_v2"), {"labels": ("No Woodwinds", "Woodwinds")}),
+    "UVR-DeNoise.pth": ("vr", dict(arch="new", params="4band_v3", nout=48, nout_lstm=128), {"labels": ("Noise", "No Noise")}),
+    "UVR-DeNoise-Lite.pth": ("vr", dict(arch="new", params="4band_v3", nout=16, nout_lstm=128), {"labels": ("Noise", "No Noise")}),
+    "UVR-DeEcho-DeReverb.pth": ("vr", dict(arch="new", params="4band_v3", nout=64, nout_lstm=128), {"labels": ("No Reverb", "Reverb")}),
+    "UVR-De-Echo-Normal.pth": ("vr", dict(arch="new", params="4band_v3", nout=48, nout_lstm=128), {"labels": ("No Echo", "Echo")}),
+    "UVR-De-Echo-Aggressive.pth": ("vr", dict(arch="new", params="4band_v3", nout=48, nout_lstm=128), {"labels": ("No Echo", "Echo")}),
     # the multi-stem stage (stem_separator.py:466): HTDemucs 6 sources on the full mix; DemucsSeparator defaults shifts 2, overlap 0.25
     "htdemucs_6s.yaml": ("demucs", HTDemucsConfig(), {"shifts": 2, "overlap": 0.25}),
 }
@@ -112,6 +123,7 @@ class _ModelInstance:
         self.extra: List[tuple] = []                          # multi-stem models: further (label, net, predictor)
         self.demucs: Optional[DemucsRunner] = None            # Demucs-family model: one network, all sources at once
         self.roformer: Optional[RoformerRunner] = None        # Roformer-family model: its own chunked runner
+        self.vr = None                                        # VR-architecture model: vr_frontend.VRSeparator
 
 
 class Separator:
@@ -181,6 +193,9 @@ class Separator:
             return
         if entry[0] == "mdx23c":
             self._load_mdx23c(model_filename, entry)
+            return
+        if entry[0] == "vr":
+            self._load_vr(model_filename, entry)
             return
         meta = entry[3] if len(entry) > 3 and entry[0] != "multi" else {}
         entry = entry[:3]
@@ -362,6 +377,42 @@ class Separator:
         self._cache[model_filename] = inst
         self.model_instance = inst
 
+    def _load_vr(self, model_filename: str, entry: tuple) -> None:
+        """("vr", {arch, params, nout, nout_lstm}, {labels: (predicted stem, residual stem), aggression, window_size, tta,
+        high_end_process}): a VR network behind the multi-band front / back end (vr_frontend.VRSeparator).  The runner options default
+        to the values the reference's engine uses when AudioLab passes none (window 512, aggression 5, no TTA, no mirrored high end --
+        audio-separator's ``vr_params`` defaults; upstream, uncited); the in-tree runner (vr.py:20-37: agg 10, mirroring) is
+        ``VRSeparator(net, params, agg=10, high_end_process=True)``.  float32 (the kernels of this family are fp32)."""
+        from .vr_frontend import MODEL_PARAMS, VRSeparator
+        from . import vrnet
+        spec, opts = entry[1], (entry[2] if len(entry) > 2 else {})
+        n_fft = 2 * MODEL_PARAMS[spec["params"]]["bins"]
+        sd, weights = self._weights_file(model_filename), "real"
+        if sd is None:
+            if not self.allow_synthetic:
+                raise AlsepError(f"model '{model_filename}': no weight file under {self.model_file_dir}; random-init weights are only used "
+                                 f"with Separator(allow_synthetic=True)")
+            seed = int.from_bytes(hashlib.sha256(model_filename.encode()).digest()[:4], "little")
+            if spec["arch"] == "new":
+                sd = vrnet.random_state_dict_new(n_fft, spec["nout"], spec["nout_lstm"], seed=seed)
+            else:
+                sd = vrnet.random_state_dict(vrnet.WIDTHS[spec["arch"]], seed=seed)
+            weights = "synthetic"
+            logger.warning("%s: no weight file under %s -- SYNTHETIC random-init weights (allow_synthetic=True)", model_filename, self.model_file_dir)
+        if spec["arch"] == "new":
+            net = vrnet.VRNetNew(n_fft, sd, nout=spec["nout"], nout_lstm=spec["nout_lstm"], ctx=self.ctx)
+        else:
+            net = vrnet.VRNet(n_fft, sd, variant=spec["arch"], ctx=self.ctx)
+        labels = tuple(opts.get("labels", ("Instrumental", "Vocals")))
+        inst = _ModelInstance(model_filename, net, None, labels[0], labels[1])
+        inst.vr = VRSeparator(net, spec["params"], agg=int(opts.get("aggression", 5)), window_size=int(opts.get("window_size", 512)),
+                              tta=bool(opts.get("tta", False)), max_batch=min(self.max_batch, 4),
+                              high_end_process=bool(opts.get("high_end_process", False)))
+        inst.output_dir = self.output_dir
+        inst.weights = weights
+        self._cache[model_filename] = inst
+        self.model_instance = inst
+
     # -- inference --------------------------------------------------------------------------------
     def separate_array(self, mix) -> Dict[str, torch.Tensor]:
         """mix [C,N] (numpy or tensor) -> {stem label: [C,N] device tensor}.  Mono is duplicated to stereo (and comes
@@ -391,6 +442,10 @@ class Separator:
         inst = self.model_instance
         if inst.demucs is not None:                             # all sources from one pass; labels as DemucsSeparator names its files
             return {name.capitalize(): t for name, t in inst.demucs.separate(m).items()}
+        if inst.vr is not None:                                 # both stems come from the network's spectrogram split; the back end
+            y, v = inst.vr.separate(m)                          # yields 480 * (n // 480) samples (as the reference's files): zero tail
+            pad = lambda t: torch.nn.functional.pad(t, (0, m.shape[1] - t.shape[1]))
+            return {inst.primary_stem_name: pad(y), inst.secondary_stem_name: pad(v)}
         if inst.roformer is not None:
             out = inst.roformer.separate(m)
             if inst.secondary_stem_name:                        # single-target model: the other stem is mix - target

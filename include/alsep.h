@@ -308,6 +308,21 @@ int alsep_nn_depth_to_space2(alsep_ctx* ctx, const float* g, float* y, int H, in
 int alsep_mdx23c_spec_in(alsep_ctx* ctx, const float* spec, float* x, int f, int k, int T);
 int alsep_mdx23c_spec_out(alsep_ctx* ctx, const float* y, float* spec, int S, int f, int k, int T);
 
+/* ---- VR multi-band front / back end (in-tree reference: modules/rvc/infer/lib/uvr5_pack/lib_v5/spec_utils.py, modules/rvc/infer/modules/uvr5/
+ * vr.py:43-196).  Complex spectrograms are float2-interleaved [2, bins, frames]; band spectrograms from / for alsep_stft / alsep_istft are
+ * [4 = (L_re, L_im, R_re, R_im), Fb, Tb]. ---- */
+/* out[c, o0 + i, t] = gain[i] * band[c, f0 + i, t0 + t] (i < h, t < l; gain may be NULL): combine_spectrograms (:95-125) and the high-end crop */
+int alsep_vr_band_crop(alsep_ctx* ctx, const float* band, float* out, const float* gain, int Fb, int Tb, int f0, int t0, int h, int l,
+                       int out_bins, int o0);
+/* y = pred * exp(i angle X), v = X - y over n complex values (vr.py:110-111) */
+int alsep_vr_split_pred(alsep_ctx* ctx, const float* pred, const float* X, float* y, float* v, int64_t n);
+/* spec_utils.mirroring("mirroring") (:453-470): spec_m [2, bins, l], he / out [2, hh, l], lo = pre_filter_start - 10 - hh */
+int alsep_vr_mirror(alsep_ctx* ctx, const float* spec_m, const float* he, float* out, int bins, int hh, int l, int lo);
+/* one band's spectrogram for the iSTFT (cmb_spectrogram_to_wave :353-429): bins [o0, o0+h) of spec_m at [f0, f0+h), then `extra` [2, eh, l]
+ * at [e0, e0+eh) (NULL: none), all times gain[f] (the low-pass / high-pass ramps and zeroed ranges), zero elsewhere; band [4, Fb, l] */
+int alsep_vr_band_spec(alsep_ctx* ctx, const float* spec_m, const float* extra, const float* gain, float* band, int bins, int l, int Fb, int f0,
+                       int h, int o0, int e0, int eh);
+
 #ifdef __cplusplus
 }
 #endif

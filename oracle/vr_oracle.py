@@ -1,0 +1,173 @@
+"""numpy restatement of the VR models' multi-band front / back end (TEST INFRASTRUCTURE -- see ``oracle/__init__.py``).
+
+Follows the in-tree reference /root/reference/modules/rvc/infer/lib/uvr5_pack/lib_v5/spec_utils.py (``wave_to_spectrogram`` :30-56,
+``combine_spectrograms`` :95-125, ``cmb_spectrogram_to_wave`` :353-429, ``fft_lp_filter`` / ``fft_hp_filter`` :432-451, ``mirroring``
+:453-490) and the driver modules/rvc/infer/modules/uvr5/vr.py:43-196 (``AudioPre._path_audio_``).
+
+PINNED (tests/golden/vr_frontend.npz, oracle/make_golden_vr_frontend.py): the band cropping / stacking, the pre-filter gains, the low-pass /
+high-pass ramps, mirroring and the band recombination are checked against the reference's own functions, imported here with ``librosa``
+replaced by the three primitives below.  UNPINNED: those primitives themselves -- librosa is not in the image:
+  * ``stft`` / ``istft``: librosa >= 0.10 semantics (requirements.txt:47 asks >= 0.11): periodic Hann window, ``center=True`` with
+    ``pad_mode="constant"``, inverse normalised by the summed squared window, length ``hop * (frames - 1)``;
+  * ``resample``: the reference asks librosa for four different resamplers (``polyphase``, ``kaiser_fast``, ``sinc_fastest``, ``scipy``);
+    this build uses its one Kaiser-windowed sinc (mdx_oracle.resample / alsep_resample) for all of them.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import numpy as np
+
+from .mdx_oracle import resample as _resample
+
+# model parameter sets of the reference (lib_v5/modelparams/4band_v2.json, 4band_v3.json): hyper-parameters of the published models
+_BANDS_4 = {
+    1: dict(sr=7350, hl=80, n_fft=640, crop_start=0, crop_stop=85, lpf_start=25, lpf_stop=53),
+    2: dict(sr=7350, hl=80, n_fft=320, crop_start=4, crop_stop=87, hpf_start=25, hpf_stop=12, lpf_start=31, lpf_stop=62),
+    3: dict(sr=14700, hl=160, n_fft=512, crop_start=17, crop_stop=216, hpf_start=48, hpf_stop=24, lpf_start=139, lpf_stop=210),
+    4: dict(sr=44100, hl=480, n_fft=960, crop_start=78, crop_stop=383, hpf_start=130, hpf_stop=86),
+}
+MODEL_PARAMS = {
+    "4band_v2": dict(bins=672, unstable_bins=8, reduction_bins=637, band=_BANDS_4, sr=44100, pre_filter_start=668, pre_filter_stop=672),
+    "4band_v3": dict(bins=672, unstable_bins=8, reduction_bins=530, band=_BANDS_4, sr=44100, pre_filter_start=668, pre_filter_stop=672),
+}
+
+
+def stft(x: np.ndarray, n_fft: int, hop: int) -> np.ndarray:
+    """[n] float32 -> complex64 [n_fft/2+1, 1 + n // hop] (librosa.stft, center, zero padding, periodic Hann)"""
+    x = np.asarray(x, dtype=np.float32)
+    w = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)).astype(np.float32)
+    xp = np.pad(x, (n_fft // 2, n_fft // 2))
+    n_frames = 1 + len(x) // hop
+    frames = np.stack([xp[t * hop: t * hop + n_fft] * w for t in range(n_frames)], axis=1)
+    return np.fft.rfft(frames.astype(np.float64), axis=0).astype(np.complex64)
+
+
+def istft(z: np.ndarray, hop: int) -> np.ndarray:
+    """complex [n_fft/2+1, T] -> float32 [hop * (T - 1)] (librosa.istft, center, window-sum-square normalisation)"""
+    n_fft = 2 * (z.shape[0] - 1)
+    T = z.shape[1]
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)
+    y = np.zeros(n_fft + hop * (T - 1))
+    env = np.zeros_like(y)
+    frames = np.fft.irfft(z.astype(np.complex128), n=n_fft, axis=0)
+    for t in range(T):
+        y[t * hop: t * hop + n_fft] += frames[:, t] * w
+        env[t * hop: t * hop + n_fft] += w * w
+    nz = env > np.finfo(np.float32).tiny
+    y[nz] /= env[nz]
+    return y[n_fft // 2: n_fft // 2 + hop * (T - 1)].astype(np.float32)
+
+
+def resample(x: np.ndarray, sr_in: int, sr_out: int) -> np.ndarray:
+    return x if sr_in == sr_out else _resample(np.atleast_2d(x), sr_in, sr_out).reshape(x.shape[:-1] + (-1,))
+
+
+def wave_to_spectrogram(wave: np.ndarray, hop: int, n_fft: int) -> np.ndarray:
+    """spec_utils.py:30-56 (no mid-side / reverse: both False in the 4-band parameter sets): [2, n] -> complex [2, bins, frames]"""
+    return np.stack([stft(wave[0], n_fft, hop), stft(wave[1], n_fft, hop)])
+
+
+def fft_lp_filter(spec, bin_start, bin_stop):
+    g = 1.0
+    for b in range(bin_start, bin_stop):
+        g -= 1 / (bin_stop - bin_start)
+        spec[:, b, :] = g * spec[:, b, :]
+    spec[:, bin_stop:, :] *= 0
+    return spec
+
+
+def fft_hp_filter(spec, bin_start, bin_stop):
+    g = 1.0
+    for b in range(bin_start, bin_stop, -1):
+        g -= 1 / (bin_start - bin_stop)
+        spec[:, b, :] = g * spec[:, b, :]
+    spec[:, 0: bin_stop + 1, :] *= 0
+    return spec
+
+
+def combine_spectrograms(specs: Dict[int, np.ndarray], mp: dict) -> np.ndarray:
+    """spec_utils.py:95-125"""
+    l = min(specs[i].shape[2] for i in specs)
+    spec_c = np.zeros((2, mp["bins"] + 1, l), dtype=np.complex64)
+    offset = 0
+    bands_n = len(mp["band"])
+    for d in range(1, bands_n + 1):
+        bp = mp["band"][d]
+        h = bp["crop_stop"] - bp["crop_start"]
+        spec_c[:, offset: offset + h, :l] = specs[d][:, bp["crop_start"]: bp["crop_stop"], :l]
+        offset += h
+    if mp["pre_filter_start"] > 0:
+        gp = 1
+        for b in range(mp["pre_filter_start"] + 1, mp["pre_filter_stop"]):
+            g = math.pow(10, -(b - mp["pre_filter_start"]) * (3.5 - gp) / 20.0)
+            gp = g
+            spec_c[:, b, :] *= g
+    return spec_c
+
+
+def mirroring(spec_m: np.ndarray, input_high_end: np.ndarray, mp: dict) -> np.ndarray:
+    """spec_utils.py:453-470 ("mirroring")"""
+    h = input_high_end.shape[1]
+    lo = mp["pre_filter_start"] - 10 - h
+    mirror = np.flip(np.abs(spec_m[:, lo: lo + h, :]), 1)
+    mirror = mirror * np.exp(1.0j * np.angle(input_high_end))
+    return np.where(np.abs(input_high_end) <= np.abs(mirror), input_high_end, mirror)
+
+
+def cmb_spectrogram_to_wave(spec_m: np.ndarray, mp: dict, extra_bins_h=None, extra_bins=None) -> np.ndarray:
+    """spec_utils.py:353-429 -> [n, 2].  (The reference allocates each band's spectrogram with np.ndarray, i.e. uninitialised; every bin
+    it does not fill is zeroed by the filters except the Nyquist bin of the top band -- taken as zero here.)"""
+    bands_n = len(mp["band"])
+    offset = 0
+    wave = None
+    for d in range(1, bands_n + 1):
+        bp = mp["band"][d]
+        spec_s = np.zeros((2, bp["n_fft"] // 2 + 1, spec_m.shape[2]), dtype=complex)
+        h = bp["crop_stop"] - bp["crop_start"]
+        spec_s[:, bp["crop_start"]: bp["crop_stop"], :] = spec_m[:, offset: offset + h, :]
+        offset += h
+        to_wave = lambda s: np.stack([istft(s[0], bp["hl"]), istft(s[1], bp["hl"])])
+        if d == bands_n:
+            if extra_bins_h:
+                max_bin = bp["n_fft"] // 2
+                spec_s[:, max_bin - extra_bins_h: max_bin, :] = extra_bins[:, :extra_bins_h, :]
+            if bp.get("hpf_start", 0) > 0:
+                spec_s = fft_hp_filter(spec_s, bp["hpf_start"], bp["hpf_stop"] - 1)
+            wave = to_wave(spec_s) if bands_n == 1 else np.add(wave, to_wave(spec_s))
+        else:
+            sr = mp["band"][d + 1]["sr"]
+            if d == 1:
+                spec_s = fft_lp_filter(spec_s, bp["lpf_start"], bp["lpf_stop"])
+                wave = resample(to_wave(spec_s), bp["sr"], sr)
+            else:
+                spec_s = fft_hp_filter(spec_s, bp["hpf_start"], bp["hpf_stop"] - 1)
+                spec_s = fft_lp_filter(spec_s, bp["lpf_start"], bp["lpf_stop"])
+                wave = resample(np.add(wave, to_wave(spec_s)), bp["sr"], sr)
+    return wave.T
+
+
+def front_end(wave: np.ndarray, mp: dict) -> Tuple[np.ndarray, np.ndarray, int]:
+    """vr.py:55-96: [2, n] at mp["sr"] -> (X_spec_m, input_high_end, input_high_end_h)"""
+    bands_n = len(mp["band"])
+    X_wave, X_spec_s = {}, {}
+    for d in range(bands_n, 0, -1):
+        bp = mp["band"][d]
+        X_wave[d] = wave if d == bands_n else resample(X_wave[d + 1], mp["band"][d + 1]["sr"], bp["sr"])
+        X_spec_s[d] = wave_to_spectrogram(X_wave[d], bp["hl"], bp["n_fft"])
+        if d == bands_n:
+            hh = (bp["n_fft"] // 2 - bp["crop_stop"]) + (mp["pre_filter_stop"] - mp["pre_filter_start"])
+            high_end = X_spec_s[d][:, bp["n_fft"] // 2 - hh: bp["n_fft"] // 2, :]
+    return combine_spectrograms(X_spec_s, mp), high_end, hh
+
+
+def back_end(X_spec_m: np.ndarray, pred: np.ndarray, X_phase: np.ndarray, high_end: np.ndarray, hh: int, mp: dict):
+    """vr.py:103-113, 161-168: pred (magnitudes) -> (instrument wave [n, 2], vocal wave [n, 2])"""
+    y_spec_m = pred * X_phase
+    v_spec_m = X_spec_m - y_spec_m
+    out = []
+    for spec in (y_spec_m, v_spec_m):
+        he = mirroring(spec, high_end, mp)
+        out.append(cmb_spectrogram_to_wave(spec, mp, hh, he))
+    return out[0], out[1]
