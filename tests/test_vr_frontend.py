@@ -144,6 +144,7 @@ def test_engine_runs_vr_models_full_size(gpu_ctx, tmp_path, name):
     X, _ = f.analyse(on(gpu_ctx, wave))
     whole = host(f.synthesise(X))
     assert np.max(np.abs(a[:, :whole.shape[1]] + b[:, :whole.shape[1]] - whole)) < 1e-4 * max(1.0, float(np.max(np.abs(whole))))
-    # the recombined mix is the input up to the band filters' ripple (not a parity statement: a sanity bound on the whole chain)
+    # the recombined mix is the input minus what lies above the top band's crop (17.6 kHz; the oracle measures 25 % of this signal's
+    # RMS there, 1.3 % with the high end put back) -- not a parity statement: a sanity bound on the whole chain
     mid = slice(4800, whole.shape[1] - 4800)
-    assert np.sqrt(np.mean((whole[:, mid] - wave[:, :whole.shape[1]][:, mid]) ** 2)) < 0.1 * np.sqrt(np.mean(wave ** 2))
+    assert np.sqrt(np.mean((whole[:, mid] - wave[:, :whole.shape[1]][:, mid]) ** 2)) < 0.35 * np.sqrt(np.mean(wave ** 2))
