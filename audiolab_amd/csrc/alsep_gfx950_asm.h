@@ -100,6 +100,9 @@ __device__ __forceinline__ void lds_wait_n() {
 
 // no instruction may be scheduled across this point
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// shader-clock counter (cycles) and the constant 100 MHz counter, for in-kernel phase stamps (timing experiments only)
+__device__ __forceinline__ unsigned long long clock_cycles() { return __builtin_amdgcn_s_memtime(); }
+__device__ __forceinline__ unsigned long long clock_100mhz() { return __builtin_amdgcn_s_memrealtime(); }
 
 // Extends the live range of a register value to this point (no code).
 template <typename T>

@@ -51,6 +51,13 @@ __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
     q[0] = (bf16_t)v[0]; q[1] = (bf16_t)v[1]; q[2] = (bf16_t)v[2]; q[3] = (bf16_t)v[3];
     *reinterpret_cast<bf16x4*>(p) = q;
 }
+// store 8 consecutive channels as one 16-byte access
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    bf16x8 q;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[e] = (bf16_t)v[e];
+    *reinterpret_cast<bf16x8*>(p) = q;
+}
 __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
     const float4 q = *reinterpret_cast<const float4*>(p);
     v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;

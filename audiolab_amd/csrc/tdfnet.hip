@@ -791,6 +791,16 @@ struct ConvBig {
     static constexpr size_t ring_bytes = 16 * (size_t)(PGROUPS + 2 * WGROUPS);
     static constexpr size_t lds_bytes = ring_bytes + 2 * NY * BN * sizeof(float) + 1024;   // + 1 KiB scratch (surplus DMA pieces)
     static_assert(lds_bytes <= 160 * 1024, "ConvBig: LDS budget");
+    // Output-channel order of the packed weight rows.  An MFMA leaves a lane with rows 4 lq .. 4 lq + 3 of each 16-row block: with the
+    // natural order that is 8 bytes of a pixel record per block and 24 (36) scattered 8-byte stores per tile and wave.  Here the 16-row
+    // blocks b = 3 yy + mi are paired: rows (4 lq + r) of blocks 2 j and 2 j + 1 hold channels 32 j + 8 lq + {r, 4 + r}, so a lane owns
+    // 8 consecutive channels per pair = one 16-byte store, and the four lq lanes of a pixel write 64 contiguous bytes.  An odd last block
+    // (NY = 3: b = 8) keeps 4 channels per lane: 128 + 4 lq + r.
+    static constexpr int NB = 3 * NY, NPAIR = NB / 2;
+    __host__ __device__ static constexpr int channel_of_row(int R) {
+        const int b = R / 16, lq = (R % 16) / 4, r = R % 4;
+        return b < 2 * NPAIR ? (b >> 1) * 32 + lq * 8 + (b & 1) * 4 + r : b * 16 + lq * 4 + r;
+    }
 };
 
 // ---- software-pipelined k-loop of the big-tile kernel (SWP) ------------------------------------------------------------
@@ -840,13 +850,27 @@ __device__ __forceinline__ void big_swp_steps(f32x4 (&acc)[3][4], bf16x8 (&xa)[4
     }
 }
 
-template <int NY, bool SWP = true>                           // SWP: software-pipelined k-loop (fragments of k-step s+1 requested before the MFMAs of s)
+// STAMP (timing experiments, ALSEP_CONV_BIG_STAMP=1): per-wave cycle sums of the phases of a stage, written to `stamps`
+// [workgroup][wave][8] = {vmcnt wait, stage barrier, k-loop, patch barrier, patch issue, epilogue, whole kernel, 100 MHz ticks}
+template <int NY, bool SWP = true, bool STAMP = false>       // SWP: software-pipelined k-loop (fragments of k-step s+1 requested before the MFMAs of s)
 __global__ void __launch_bounds__(kBigThreads, 2)
 conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
                         const float* __restrict__ scale, const float* __restrict__ shift,
                         const bf16_t* __restrict__ zero_page, int Th, int Fw, int Cin, int Cout, int tiles_t,
-                        int tiles_f, int ntiles) {
+                        int tiles_f, int ntiles, unsigned long long* __restrict__ stamps = nullptr) {
     typedef ConvBig<NY> Cf;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tk0 = 0, tr0 = 0, tlast = 0;
+    auto stamp = [&](int k) {
+        if constexpr (STAMP) {
+            const unsigned long long now = clock_cycles();
+            tacc[k] += now - tlast;
+            tlast = now;
+        }
+    };
+    if constexpr (STAMP) {
+        tk0 = tlast = clock_cycles();
+        tr0 = clock_100mhz();
+    }
     bf16_t* patch = reinterpret_cast<bf16_t*>(alsep_smem);
     bf16_t* wring = patch + (size_t)Cf::PGROUPS * 8;
     float* ss = reinterpret_cast<float*>(alsep_smem + Cf::ring_bytes);
@@ -891,22 +915,37 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
         t0 = tt * Cf::TH;
         f0 = tf * Cf::TW;
     };
+    // LDS-DMA descriptors of the halo patch, computed once: piece j of this wave is instruction i = wave + 8 j of the PINST = 62 that
+    // cover the patch; lane -> (pixel, channel group) never changes, so the element offset from the tile's first pixel and the four
+    // "outside the image if the tile touches that border" bits are per-lane constants.  (Computed per patch, the divisions and 64-bit
+    // address arithmetic of 8 pieces cost each wave ~4,000 cycles per patch: 14 % of the kernel, in-kernel stamps of round 2.)
+    constexpr int PJ = (Cf::PINST + 7) / 8;
+    int prel[PJ];
+    unsigned pflags = 0;                                     // 4 bits per piece: top row, bottom row, left column, right column of the halo
+    bool plast_ok = true;                                    // lanes of the last, partial instruction that hold a patch group
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+        const int gidx = (wave + 8 * j) * 64 + lane;
+        const int gi = gidx < Cf::PGROUPS ? gidx : Cf::PGROUPS - 1;
+        const int pix = gi / Cf::CG, g = gi % Cf::CG;
+        const int dt = pix / Cf::PW - 1, df = pix % Cf::PW - 1;
+        prel[j] = (dt * Fw + df) * Cin + g * 8;
+        pflags |= (unsigned)((dt < 0) | ((dt >= Cf::TH) << 1) | ((df < 0) << 2) | ((df >= Cf::TW) << 3)) << (4 * j);
+        if (j == PJ - 1) plast_ok = gidx < Cf::PGROUPS;
+    }
     auto issue_patch = [&](int ps) {                         // (tile ps / nq, chunk ps % nq); waited with vmcnt(0)
         int t0, f0; int64_t b;
         tile_coords(ps / nq, t0, f0, b);
-        const bf16_t* xb = X + b * (int64_t)Th * Fw * Cin + (ps % nq) * Cf::KC;
+        const bf16_t* xb = X + ((b * Th + t0) * (int64_t)Fw + f0) * Cin + (ps % nq) * Cf::KC;
+        const unsigned border = (unsigned)(t0 == 0) | ((unsigned)(t0 + Cf::TH >= Th) << 1) | ((unsigned)(f0 == 0) << 2) |
+                                ((unsigned)(f0 + Cf::TW >= Fw) << 3);
 #pragma unroll
-        for (int j = 0; j < (Cf::PINST + 7) / 8; ++j) {
+        for (int j = 0; j < PJ; ++j) {
             const int i = wave + 8 * j;
-            if (i < Cf::PINST) {
-                const int gidx = i * 64 + lane;
-                if (gidx < Cf::PGROUPS) {
-                    const int pix = gidx / Cf::CG, g = gidx % Cf::CG;
-                    const int t = t0 - 1 + pix / Cf::PW, f = f0 - 1 + pix % Cf::PW;
-                    const bool inb = t >= 0 && t < Th && f >= 0 && f < Fw;
-                    const bf16_t* src = inb ? xb + ((int64_t)t * Fw + f) * Cin + g * 8 : zero_page;
-                    glds16(src, patch + (size_t)i * 64 * 8);
-                }
+            if (j < PJ - 1 || i < Cf::PINST) {
+                const bool out = (pflags & (border << (4 * j))) != 0;
+                const bf16_t* src = out ? zero_page : xb + prel[j];
+                if (j < PJ - 1 || plast_ok) glds16(src, patch + (size_t)i * 64 * 8);
             }
         }
     };
@@ -938,7 +977,7 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
     //    finished tile -- the next stage waits with vmcnt(ST), i.e. for the patch and weights but not for the stores.
     // Barriers: one per stage plus one per patch (was two per stage plus one per patch, with every tile's stores and every
     // patch's DMA latency drained at vmcnt(0)).
-    constexpr int ST = NY * 12;                              // epilogue stores per wave
+    constexpr int ST = 4 * (Cf::NPAIR + Cf::NB % 2);         // epilogue stores per wave
     f32x4 acc[NY][3][4];
     if (nstage > 0) {
         issue_patch(0);
@@ -952,7 +991,9 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
         const bool after_epilogue = ny == 0 && q == 0 && s > 0;   // the previous stage ended a tile: its stores are younger
         if (after_epilogue) wait_vmcnt<ST>();
         else wait_vmcnt<0>();
+        stamp(0);
         barrier_nodrain();
+        stamp(1);
         if (SWP || !last) weights_prep(s + 1);                   // SWP: the (branch-free) DMA of the last stage refills the free slot once more
         {
             const bf16_t* wts = wring + (size_t)(s & 1) * Cf::WGROUPS * 8;
@@ -995,31 +1036,57 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
                 }
             }
         }
+        stamp(2);
         if (ny == NY - 1) {
             barrier_nodrain();                               // every wave has left the patch: it may be refilled
+            stamp(3);
             if (!last) issue_patch(ps + 1);
+            stamp(4);
             if (q == nq - 1) {
                 int t0, f0; int64_t b;
                 tile_coords(ps / nq, t0, f0, b);
                 bf16_t* yb = Y + ((b * Th + t0 + wave) * (int64_t)Fw + f0) * Cout;
 #pragma unroll
-                for (int yy = 0; yy < NY; ++yy)
+                for (int ni = 0; ni < 4; ++ni) {
+                    bf16_t* yp = yb + (int64_t)(ni * 16 + l15) * Cout;
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
+                    for (int j = 0; j < Cf::NPAIR; ++j) {            // blocks 2 j, 2 j + 1: channels 32 j + 8 lq + [0, 8) (ConvBig::channel_of_row)
+                        const int co = j * 32 + lq * 8;
+                        float y[8];
 #pragma unroll
-                        for (int mi = 0; mi < 3; ++mi) {
-                            const int co = yy * Cf::BN + mi * 16 + 4 * lq;
-                            const f32x4 scv = *reinterpret_cast<const f32x4*>(ss + co);      // ext-vector load: see regw kernel
-                            const f32x4 shv = *reinterpret_cast<const f32x4*>(ss + NY * Cf::BN + co);
-                            float y[4];
+                        for (int h = 0; h < 2; ++h) {
+                            const int bb = 2 * j + h;
+                            const f32x4 scv = *reinterpret_cast<const f32x4*>(ss + co + 4 * h);      // ext-vector load: see regw kernel
+                            const f32x4 shv = *reinterpret_cast<const f32x4*>(ss + NY * Cf::BN + co + 4 * h);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[yy][mi][ni][r], scv[r], shv[r]), 0.f);
-                            store4(yb + (int64_t)(ni * 16 + l15) * Cout + co, y);
+                            for (int r = 0; r < 4; ++r) y[4 * h + r] = fmaxf(fmaf(acc[bb / 3][bb % 3][ni][r], scv[r], shv[r]), 0.f);
                         }
+                        store8(yp + co, y);
+                    }
+                    if constexpr (Cf::NB % 2 == 1) {
+                        constexpr int bb = Cf::NB - 1;
+                        const int co = bb * 16 + lq * 4;
+                        const f32x4 scv = *reinterpret_cast<const f32x4*>(ss + co);
+                        const f32x4 shv = *reinterpret_cast<const f32x4*>(ss + NY * Cf::BN + co);
+                        float y[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[bb / 3][bb % 3][ni][r], scv[r], shv[r]), 0.f);
+                        store4(yp + co, y);
+                    }
+                }
+                stamp(5);
             }
         }
     }
     if constexpr (SWP) wait_vmcnt<0>();                      // the surplus LDS-DMA of the last stage lands before the wave ends
+    if constexpr (STAMP) {
+        if (lane == 0 && stamps) {
+            unsigned long long* o = stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+            for (int k = 0; k < 6; ++k) o[k] = tacc[k];
+            o[6] = clock_cycles() - tk0;
+            o[7] = clock_100mhz() - tr0;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1918,6 +1985,7 @@ struct DevBuf {
 
 struct ConvLayer {       // 3x3
     DevBuf w, scale, shift;
+    DevBuf w_big;            // conv3x3_bf16_big_kernel's image (c = 96 / 144): rows in ConvBig::channel_of_row order
     int cin = 0, cout = 0;
     bool dma_path = false;   // packed for conv3x3_bf16_kernel (swizzled, unpadded)
 };
@@ -2028,6 +2096,16 @@ std::vector<bf16_t> pack_conv3x3_dma(const std::vector<float>& w, int cin, int c
     return out;
 }
 
+// the same image with the output channels in the row order of conv3x3_bf16_big_kernel<NY> (ConvBig::channel_of_row)
+template <int NY>
+std::vector<bf16_t> pack_conv3x3_big(const std::vector<float>& w, int cin) {
+    const int cout = 48 * NY;
+    std::vector<float> wp(w.size());
+    const size_t row = (size_t)cin * 9;
+    for (int R = 0; R < cout; ++R) std::copy(w.begin() + ConvBig<NY>::channel_of_row(R) * row, w.begin() + (ConvBig<NY>::channel_of_row(R) + 1) * row, wp.begin() + R * row);
+    return pack_conv3x3_dma(wp, cin, cout);
+}
+
 template <typename T> constexpr bool is_bf16() { return false; }
 template <> constexpr bool is_bf16<bf16_t>() { return true; }
 
@@ -2043,6 +2121,10 @@ int make_conv(alsep_net* net, const TensorMap& tm, const std::string& p, int c, 
         L->dma_path = true;
         auto pk = pack_conv3x3_dma(*w, c, c);
         rc = upload(net, pk.data(), pk.size() * sizeof(bf16_t), &L->w);
+        if (!rc && (c == 96 || c == 144)) {                  // a second image for the big-tile kernel (its own output-channel order)
+            auto pb = c == 96 ? pack_conv3x3_big<2>(*w, c) : pack_conv3x3_big<3>(*w, c);
+            rc = upload(net, pb.data(), pb.size() * sizeof(bf16_t), &L->w_big);
+        }
     } else if (conv_uses_main<T>(c, c)) {
         auto pk = pack_conv3x3<T, ConvSel<T>::KC, ConvSel<T>::BN>(*w, c, c);
         rc = upload(net, pk.data(), pk.size() * sizeof(T), &L->w);
@@ -2333,6 +2415,7 @@ int launch_conv_big(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     const int tiles_t = Th / Cf::TH, tiles_f = Fw / Cf::TW;
     const int64_t ntiles = B * tiles_t * tiles_f;
     if (ntiles > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "conv3x3: too many tiles");
+    if (!L.w_big.p) return alsep_fail(ctx, ALSEP_ERR_STATE, "conv3x3: no big-tile weight image for this layer");
     ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_big_kernel<NY, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)Cf::lds_bytes));
     const int gx = ntiles < 256 ? (int)ntiles : 256;
@@ -2343,15 +2426,49 @@ int launch_conv_big(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     // (MI355X_MICROARCH.md, DVFS give-back), and keeps it lower for the kernels that follow.
     static const int swp = [] { const char* e = getenv("ALSEP_CONV_BIG_SWP"); return e ? atoi(e) : 0; }();
     ProfScope prof(ctx, NY == 3 ? ALSEP_PROF_CONV3X3_BIG3 : ALSEP_PROF_CONV3X3_BIG);
+#ifndef ALSEP_CPU_EMUL
+    // ALSEP_CONV_BIG_STAMP=n (timing experiments): the first n launches run the stamped variant, synchronise and print the per-phase
+    // cycle sums (mean over waves, and waves 0 / 7 of workgroup 0) to stderr
+    static int stamp_left = [] { const char* e = getenv("ALSEP_CONV_BIG_STAMP"); return e ? atoi(e) : 0; }();
+    if (stamp_left > 0) {
+        --stamp_left;
+        static unsigned long long* dbuf = nullptr;
+        const size_t n = (size_t)256 * 8 * 8;
+        if (!dbuf) ALSEP_HIP(ctx, hipMalloc(&dbuf, n * sizeof(unsigned long long)));
+        ALSEP_HIP(ctx, hipMemsetAsync(dbuf, 0, n * sizeof(unsigned long long), ctx->stream));
+        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_big_kernel<NY, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)Cf::lds_bytes));
+        hipLaunchKernelGGL((conv3x3_bf16_big_kernel<NY, false, true>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                           (const bf16_t*)L.w_big.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
+                           L.cout, tiles_t, tiles_f, (int)ntiles, dbuf);
+        ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_big_kernel");
+        ALSEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<unsigned long long> h(n);
+        ALSEP_HIP(ctx, hipMemcpy(h.data(), dbuf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double mean[8] = {0};
+        for (int w = 0; w < gx * 8; ++w)
+            for (int k = 0; k < 8; ++k) mean[k] += (double)h[(size_t)w * 8 + k] / (gx * 8);
+        const int stages = (int)((ntiles + gx - 1) / gx) * NY * (L.cin / Cf::KC);
+        fprintf(stderr, "[big<%d> stamp] tiles %lld grid %d stages/wg %d | cycles/wave: vmwait %.0f barrier %.0f kloop %.0f pbarrier %.0f pissue %.0f "
+                        "epilogue %.0f total %.0f | %.2f GHz | per stage: vmwait %.0f barrier %.0f kloop %.0f (MFMA floor %d)\n", NY,
+                (long long)ntiles, gx, stages, mean[0], mean[1], mean[2], mean[3], mean[4], mean[5], mean[6], mean[6] / (mean[7] * 10.0) ,
+                mean[0] / stages, mean[1] / stages, mean[2] / stages, 2 * 14 * 12 * 16);
+        for (int w : {0, 4, 7})
+            fprintf(stderr, "    wg0 wave %d: vmwait %llu barrier %llu kloop %llu pbarrier %llu pissue %llu epilogue %llu total %llu\n", w,
+                    h[w * 8 + 0], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5], h[w * 8 + 6]);
+        note_launch(ctx, NY == 3 ? "conv3x3_bf16_big_kernel<3>" : "conv3x3_bf16_big_kernel<2>");
+        return ALSEP_OK;
+    }
+#endif
     if (swp >= (NY == 2 ? 1 : 2)) {                          // NY = 3: the second fragment set does not fit 256 registers (76 spilled): opt-in only
         ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_big_kernel<NY, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)Cf::lds_bytes));
         hipLaunchKernelGGL((conv3x3_bf16_big_kernel<NY, true>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
-                           (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
+                           (const bf16_t*)L.w_big.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
                            L.cout, tiles_t, tiles_f, (int)ntiles);
     } else {
         hipLaunchKernelGGL((conv3x3_bf16_big_kernel<NY, false>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
-                           (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
+                           (const bf16_t*)L.w_big.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
                            L.cout, tiles_t, tiles_f, (int)ntiles);
     }
     note_launch(ctx, NY == 3 ? "conv3x3_bf16_big_kernel<3>" : "conv3x3_bf16_big_kernel<2>");

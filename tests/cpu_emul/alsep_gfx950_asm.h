@@ -47,6 +47,8 @@ static inline void lds_read_async_b128(bf16x8& dst, const bf16_t* lds_ptr) {
 template <int N>
 static inline void lds_wait_n() {}
 static inline void sched_fence() {}
+static inline unsigned long long clock_cycles() { return 0; }
+static inline unsigned long long clock_100mhz() { return 0; }
 
 template <typename T>
 static inline void keep_vgprs_live(const T&) {}

@@ -108,7 +108,7 @@ def _worker_ola_demucs(rank, world, port, emul_so, out_path):
                              t_heads=4, segment_samples=2560, samplerate=4000)
     hsd = ho.synthetic_state_dict(ocfg, 5)
     hnet = HTDemucs(HTDemucsConfig(**dataclasses.asdict(ocfg)), hsd, ctx=ctx)
-    hm = torch.randn(2, 5000, generator=torch.Generator().manual_seed(8)) * 0.2
+    hm = torch.randn(2, 3500, generator=torch.Generator().manual_seed(8)) * 0.2      # two segments + the shift
     out = DemucsRunner(hnet, shifts=1, overlap=0.25, seed=0, sharded=True).separate(hm)
     hw = ho.separate(ocfg, hsd, hm, shifts=1, overlap=0.25, seed=0).numpy()
     errs.append(float(max(np.max(np.abs(out[k].numpy() - hw[i])) for i, k in enumerate(ocfg.sources))))

@@ -52,7 +52,7 @@ def test_forward_one_chunk_vs_oracle(dev, kind):
 @pytest.mark.parametrize("kind,n", [("mel", 5000), ("bs", 1000), ("mel", 2500)])
 def test_runner_vs_oracle(dev, kind, n):
     from audiolab_amd.roformer import RoformerRunner
-    if dev.device.type == "cpu" and n != 5000:
+    if dev.device.type == "cpu" and n != 2500:
         pytest.skip("emulated suite keeps one runner case (the others run on the GPU)")
     ocfg = small_cfg(kind)
     net, sd = build(dev, ocfg, seed=5)
