@@ -852,13 +852,18 @@ __device__ __forceinline__ void big_swp_steps(f32x4 (&acc)[3][4], bf16x8 (&xa)[4
 
 // STAMP (timing experiments, ALSEP_CONV_BIG_STAMP=1): per-wave cycle sums of the phases of a stage, written to `stamps`
 // [workgroup][wave][8] = {vmcnt wait, stage barrier, k-loop, patch barrier, patch issue, epilogue, whole kernel, 100 MHz ticks}
-template <int NY, bool SWP = true, bool STAMP = false>       // SWP: software-pipelined k-loop (fragments of k-step s+1 requested before the MFMAs of s)
+// ABL (with STAMP only, wrong results): 1 no weight LDS-DMA in the k-loop, 2 one patch fragment read instead of four, 4 one weight
+// fragment read instead of three, 8 four MFMAs per k-step instead of twelve, 16 s_setprio 1 on waves 4-7, 32 no epilogue stores
+template <int NY, bool SWP = true, bool STAMP = false, int ABL = 0>   // SWP: software-pipelined k-loop (fragments of k-step s+1 requested before the MFMAs of s)
 __global__ void __launch_bounds__(kBigThreads, 2)
 conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
                         const float* __restrict__ scale, const float* __restrict__ shift,
                         const bf16_t* __restrict__ zero_page, int Th, int Fw, int Cin, int Cout, int tiles_t,
                         int tiles_f, int ntiles, unsigned long long* __restrict__ stamps = nullptr) {
     typedef ConvBig<NY> Cf;
+    if constexpr ((ABL & 16) != 0) {
+        if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);
+    }
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tk0 = 0, tr0 = 0, tlast = 0;
     auto stamp = [&](int k) {
         if constexpr (STAMP) {
@@ -1023,14 +1028,15 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
                         const int ko = koff_of(st);
                         bf16x8 xf[4], wf[3];
 #pragma unroll
-                        for (int ni = 0; ni < 4; ++ni) xf[ni] = lds_frag<bf16_t>(patch + pbase[ni] + ko);
-#pragma unroll
-                        for (int mi = 0; mi < 3; ++mi) wf[mi] = lds_frag<bf16_t>(wts + ((mi * 16 + l15) * Cf::WGRP + ((4 * st + lq) ^ wswz)) * 8);
+                        for (int ni = 0; ni < 4; ++ni) xf[ni] = (ABL & 2) && ni > 0 ? xf[0] : lds_frag<bf16_t>(patch + pbase[ni] + ko);
 #pragma unroll
                         for (int mi = 0; mi < 3; ++mi)
+                            wf[mi] = (ABL & 4) && mi > 0 ? wf[0] : lds_frag<bf16_t>(wts + ((mi * 16 + l15) * Cf::WGRP + ((4 * st + lq) ^ wswz)) * 8);
+#pragma unroll
+                        for (int mi = 0; mi < ((ABL & 8) ? 1 : 3); ++mi)
 #pragma unroll
                             for (int ni = 0; ni < 4; ++ni) mma_step(acc[yy][mi][ni], wf[mi], xf[ni]);
-                        if (st < 6 && !last) weights_one(st);
+                        if (st < 6 && !last && !(ABL & 1)) weights_one(st);
                     }
                     }
                 }
@@ -1061,7 +1067,7 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
 #pragma unroll
                             for (int r = 0; r < 4; ++r) y[4 * h + r] = fmaxf(fmaf(acc[bb / 3][bb % 3][ni][r], scv[r], shv[r]), 0.f);
                         }
-                        store8(yp + co, y);
+                        if constexpr (!(ABL & 32)) store8(yp + co, y);
                     }
                     if constexpr (Cf::NB % 2 == 1) {
                         constexpr int bb = Cf::NB - 1;
@@ -1079,6 +1085,603 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
         }
     }
     if constexpr (SWP) wait_vmcnt<0>();                      // the surplus LDS-DMA of the last stage lands before the wave ends
+    if constexpr (STAMP) {
+        if (lane == 0 && stamps) {
+            unsigned long long* o = stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+            for (int k = 0; k < 6; ++k) o[k] = tacc[k];
+            o[6] = clock_cycles() - tk0;
+            o[7] = clock_100mhz() - tr0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 3x3 convolution, levels 1 and 2, "merged" form of the big-tile kernel (round 2).
+// In-kernel stamps of conv3x3_bf16_big_kernel (profiles/r02_big_conv_stamps.txt) showed (a) its software-pipelined k-loop already
+// at the MFMA issue floor in cycles, (b) the chip answering with a lower clock (1.4-1.5 GHz): the launch is energy-bound.  What
+// is left is energy per MFMA: LDS bytes and VALU instructions.  Same tile, same patch, same two 43 KiB weight slots, but the K
+// range of a (tile, input chunk) is cut into NY parts instead of the output channels into NY blocks:
+//   a weight slot holds ALL 48 NY output rows x (14 / NY) k-steps, so one k-step reads its 4 patch fragments once for all
+//   3 NY row blocks: 4 + 3 NY LDS reads per 12 NY MFMAs (NY = 2: 10 per 24 instead of 14; NY = 3: 13 per 36 instead of 21);
+//   every LDS address is a per-lane base + an instruction immediate (no VALU in the loop), reads of k-step s + 1 are in flight
+//   during the MFMAs of s (asm reads, own lgkmcnt waits), the next weight slot arrives one LDS-DMA per k-step.
+// Per accumulator the MFMAs run in the same order as in the other conv kernels: bit-identical outputs.
+// ------------------------------------------------------------------------------------------
+template <int NY>
+struct ConvMny {
+    typedef ConvBig<NY> Big;
+    static constexpr int TW = 64, TH = 8, KC = 48, CG = 6, NG = 54, NS = 14, PW = TW + 2, PH = TH + 2;
+    static constexpr int PARTS = NY;                        // k-step ranges per (tile, chunk)
+    static constexpr int KS = (NS + PARTS - 1) / PARTS;     // k-steps of a part (the last one: the remainder): 7 / 5
+    static constexpr int WG = 4 * KS;                       // 16-byte groups per weight row in a slot
+    static constexpr int ROWS = 48 * NY, NB = 3 * NY;
+    static constexpr int PGROUPS = PH * PW * CG, PINST = (PGROUPS + 63) / 64;
+    static constexpr int WGROUPS = ROWS * WG, WINST = (WGROUPS + 63) / 64;      // 2688 -> 42; 2880 -> 45
+    static constexpr int WJ = (WINST + 7) / 8;              // weight pieces per wave (6)
+    static constexpr size_t ring_bytes = 16 * (size_t)(PGROUPS + 2 * WGROUPS);
+    static constexpr size_t lds_bytes = ring_bytes + 2 * ROWS * sizeof(float) + 1024;   // + 1 KiB scratch (surplus DMA pieces)
+    static_assert(lds_bytes <= 160 * 1024, "ConvMny: LDS budget");
+    __host__ __device__ static constexpr int ksteps_of_part(int kt) { return kt < PARTS - 1 ? KS : NS - KS * (PARTS - 1); }
+    // position of k-group lq of a k-step inside its 4-group block, by weight row: makes the ds_read_b128 of 16 rows x {lq, lq ^ 1}
+    // (the instruction's lane groups mix two lq values) conflict-free for row strides of 28 and 20 groups (simulated:
+    // scripts/lds_bank_sim.py)
+    __host__ __device__ static constexpr int wswz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+};
+
+template <typename Cf, int KT, int STL>
+__device__ __forceinline__ void mny_issue_reads(bf16x8 (&xf)[4], bf16x8 (&wf)[Cf::NB], const bf16_t* patch, const int (&pk)[Cf::NS],
+                                                const bf16_t* wl) {
+    const bf16_t* pl = patch + pk[KT * Cf::KS + STL];
+    lds_read_async_b128<0 * 16 * Cf::KC * 2>(xf[0], pl);
+    lds_read_async_b128<1 * 16 * Cf::KC * 2>(xf[1], pl);
+    lds_read_async_b128<2 * 16 * Cf::KC * 2>(xf[2], pl);
+    lds_read_async_b128<3 * 16 * Cf::KC * 2>(xf[3], pl);
+    lds_read_async_b128<(0 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[0], wl);
+    lds_read_async_b128<(1 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[1], wl);
+    lds_read_async_b128<(2 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[2], wl);
+    lds_read_async_b128<(3 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[3], wl);
+    lds_read_async_b128<(4 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[4], wl);
+    lds_read_async_b128<(5 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[5], wl);
+    if constexpr (Cf::NB > 6) {
+        lds_read_async_b128<(6 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[6], wl);
+        lds_read_async_b128<(7 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[7], wl);
+        lds_read_async_b128<(8 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[8], wl);
+    }
+}
+template <typename Cf>
+__device__ __forceinline__ void mny_mma(f32x4 (&acc)[Cf::NB][4], const bf16x8 (&wf)[Cf::NB], const bf16x8 (&xf)[4]) {
+#pragma unroll
+    for (int b = 0; b < Cf::NB; ++b)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) mma_step(acc[b][ni], wf[b], xf[ni]);
+}
+template <typename Cf, int KT, int STL>
+__device__ __forceinline__ void mny_issue_x(bf16x8 (&xf)[4], const bf16_t* patch, const int (&pk)[Cf::NS]) {
+    const bf16_t* pl = patch + pk[KT * Cf::KS + STL];
+    lds_read_async_b128<0 * 16 * Cf::KC * 2>(xf[0], pl);
+    lds_read_async_b128<1 * 16 * Cf::KC * 2>(xf[1], pl);
+    lds_read_async_b128<2 * 16 * Cf::KC * 2>(xf[2], pl);
+    lds_read_async_b128<3 * 16 * Cf::KC * 2>(xf[3], pl);
+}
+template <typename Cf, int STL, int B>
+__device__ __forceinline__ void mny_issue_w1(bf16x8& wf, const bf16_t* wl) {
+    lds_read_async_b128<(B * 16 * Cf::WG * 8 + STL * 32) * 2>(wf, wl);
+}
+// k-steps STL, STL + 1 of part KT: fragments of STL in (xa, wa) (requested by the caller / the previous pair), STL + 1 goes to (xb, wb)
+template <typename Cf, int KT, int STL, typename Dma>
+__device__ __forceinline__ void mny_steps(f32x4 (&acc)[Cf::NB][4], bf16x8 (&xa)[4], bf16x8 (&wa)[Cf::NB], bf16x8 (&xb)[4],
+                                          bf16x8 (&wb)[Cf::NB], const bf16_t* patch, const int (&pk)[Cf::NS], const bf16_t* wl, Dma dma) {
+    constexpr int N = Cf::ksteps_of_part(KT);
+    if constexpr (STL < N) {
+        if constexpr (STL == 0) mny_issue_reads<Cf, KT, 0>(xa, wa, patch, pk, wl);
+        lds_wait_n<0>();                                     // the fragments of STL have landed
+        if constexpr (STL + 1 < N) mny_issue_reads<Cf, KT, STL + 1>(xb, wb, patch, pk, wl);
+        mny_mma<Cf>(acc, wa, xa);
+        dma(STL);
+        sched_fence();
+        if constexpr (STL + 1 < N) {
+            lds_wait_n<0>();
+            if constexpr (STL + 2 < N) mny_issue_reads<Cf, KT, STL + 2>(xa, wa, patch, pk, wl);
+            mny_mma<Cf>(acc, wb, xb);
+            dma(STL + 1);
+            sched_fence();
+            mny_steps<Cf, KT, STL + 2>(acc, xa, wa, xb, wb, patch, pk, wl, dma);
+        }
+    }
+}
+// the same with ONE set of weight fragments (NY = 3: two sets of 9 beside 144 accumulator registers do not fit 256 VGPRs): the patch
+// fragments of step STL + 1 are requested before the MFMAs of STL, each weight fragment of STL + 1 right after the four MFMAs that
+// consumed its register (the LDS answers long after those have read their operands)
+template <typename Cf, int KT, int STL, int B>
+__device__ __forceinline__ void mny_blocks(f32x4 (&acc)[Cf::NB][4], bf16x8 (&wf)[Cf::NB], const bf16x8 (&xf)[4], const bf16_t* wl) {
+    if constexpr (B < Cf::NB) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) mma_step(acc[B][ni], wf[B], xf[ni]);
+        if constexpr (STL + 1 < Cf::ksteps_of_part(KT)) {
+            sched_fence();
+            mny_issue_w1<Cf, STL + 1, B>(wf[B], wl);
+        }
+        mny_blocks<Cf, KT, STL, B + 1>(acc, wf, xf, wl);
+    }
+}
+template <typename Cf, int KT, int STL, typename Dma>
+__device__ __forceinline__ void mny_steps1w(f32x4 (&acc)[Cf::NB][4], bf16x8 (&xa)[4], bf16x8 (&xb)[4], bf16x8 (&wf)[Cf::NB],
+                                            const bf16_t* patch, const int (&pk)[Cf::NS], const bf16_t* wl, Dma dma) {
+    constexpr int N = Cf::ksteps_of_part(KT);
+    if constexpr (STL < N) {
+        if constexpr (STL == 0) mny_issue_reads<Cf, KT, 0>(xa, wf, patch, pk, wl);
+        lds_wait_n<0>();
+        if constexpr (STL + 1 < N) mny_issue_x<Cf, KT, STL + 1>(xb, patch, pk);
+        mny_blocks<Cf, KT, STL, 0>(acc, wf, xa, wl);
+        dma(STL);
+        sched_fence();
+        mny_steps1w<Cf, KT, STL + 1>(acc, xb, xa, wf, patch, pk, wl, dma);
+    }
+}
+
+// ABL (timing experiments with STAMP, wrong results): 1 no weight LDS-DMA after the first slot, 2 no patch LDS-DMA after the first,
+// 4 epilogue stores predicated off (on a value test, so that the arithmetic stays)
+template <int NY, bool STAMP = false, int ABL = 0>
+__global__ void __launch_bounds__(kBigThreads, 2)
+conv3x3_bf16_mny_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
+                        const float* __restrict__ scale, const float* __restrict__ shift, const bf16_t* __restrict__ zero_page, int Th,
+                        int Fw, int Cin, int Cout, int tiles_t, int tiles_f, int ntiles, unsigned long long* __restrict__ stamps = nullptr) {
+    typedef ConvMny<NY> Cf;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tk0 = 0, tr0 = 0, tlast = 0;
+    auto stamp = [&](int k) {
+        if constexpr (STAMP) {
+            const unsigned long long now = clock_cycles();
+            tacc[k] += now - tlast;
+            tlast = now;
+        }
+    };
+    if constexpr (STAMP) {
+        tk0 = tlast = clock_cycles();
+        tr0 = clock_100mhz();
+    }
+    bf16_t* patch = reinterpret_cast<bf16_t*>(alsep_smem);
+    bf16_t* wring = patch + (size_t)Cf::PGROUPS * 8;
+    float* ss = reinterpret_cast<float*>(alsep_smem + Cf::ring_bytes);
+    bf16_t* const scratch = reinterpret_cast<bf16_t*>(alsep_smem + Cf::lds_bytes - 1024);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int nq = Cin / Cf::KC;
+    for (int i = tid; i < Cf::ROWS; i += kBigThreads) {
+        ss[i] = scale[i];
+        ss[Cf::ROWS + i] = shift[i];
+    }
+    __syncthreads();
+
+    // per-lane LDS element offsets, computed once: patch pixel (row = wave, col = l15) + k-group 4 st + lq of every k-step;
+    // weight row l15 + this lane's swizzled group position
+    int pk[Cf::NS];
+#pragma unroll
+    for (int st = 0; st < Cf::NS; ++st) {
+        const int grp = 4 * st + lq;
+        const int gc = grp < Cf::NG ? grp : Cf::NG - 1;
+        const int tap = gc / Cf::CG, cg = gc % Cf::CG;
+        pk[st] = (wave * Cf::PW + l15) * Cf::KC + ((tap / 3) * Cf::PW + (tap % 3)) * Cf::KC + cg * 8;
+    }
+    const int wl_off = (l15 * Cf::WG + (lq ^ Cf::wswz(l15))) * 8;
+
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nstage = my_tiles * nq * Cf::PARTS;
+    auto tile_coords = [&](int k, int& t0, int& f0, int64_t& b) {
+        int tile = (int)blockIdx.x + k * (int)gridDim.x;
+        const int tf = tile % tiles_f;  tile /= tiles_f;
+        const int tt = tile % tiles_t;
+        b = tile / tiles_t;
+        t0 = tt * Cf::TH;
+        f0 = tf * Cf::TW;
+    };
+    // LDS-DMA descriptors of the halo patch (see conv3x3_bf16_big_kernel)
+    constexpr int PJ = (Cf::PINST + 7) / 8;
+    int prel[PJ];
+    unsigned pflags = 0;
+    bool plast_ok = true;
+#pragma unroll
+    for (int j = 0; j < PJ; ++j) {
+        const int gidx = (wave + 8 * j) * 64 + lane;
+        const int gi = gidx < Cf::PGROUPS ? gidx : Cf::PGROUPS - 1;
+        const int pix = gi / Cf::CG, g = gi % Cf::CG;
+        const int dt = pix / Cf::PW - 1, df = pix % Cf::PW - 1;
+        prel[j] = (dt * Fw + df) * Cin + g * 8;
+        pflags |= (unsigned)((dt < 0) | ((dt >= Cf::TH) << 1) | ((df < 0) << 2) | ((df >= Cf::TW) << 3)) << (4 * j);
+        if (j == PJ - 1) plast_ok = gidx < Cf::PGROUPS;
+    }
+    auto issue_patch = [&](int ps) {
+        int t0, f0; int64_t b;
+        tile_coords(ps / nq, t0, f0, b);
+        const bf16_t* xb = X + ((b * Th + t0) * (int64_t)Fw + f0) * Cin + (ps % nq) * Cf::KC;
+        const unsigned border = (unsigned)(t0 == 0) | ((unsigned)(t0 + Cf::TH >= Th) << 1) | ((unsigned)(f0 == 0) << 2) |
+                                ((unsigned)(f0 + Cf::TW >= Fw) << 3);
+#pragma unroll
+        for (int j = 0; j < PJ; ++j) {
+            const int i = wave + 8 * j;
+            if (j < PJ - 1 || i < Cf::PINST) {
+                const bool out = (pflags & (border << (4 * j))) != 0;
+                const bf16_t* src = out ? zero_page : xb + prel[j];
+                if (j < PJ - 1 || plast_ok) glds16(src, patch + (size_t)i * 64 * 8);
+            }
+        }
+    };
+    // weight slot of stage s: part (q, kt) of the image [q][kt][ROWS][WG][8]; WJ LDS-DMA pieces per wave, branch-free (a wave
+    // without a last piece copies piece 0 into the scratch: see conv3x3_bf16_big_kernel)
+    const bf16_t* wsrc_next = Wp;
+    bf16_t* wdst_next = wring;
+    auto weights_prep = [&](int s) {
+        const int kt = s % Cf::PARTS, q = (s / Cf::PARTS) % nq;
+        wsrc_next = Wp + ((int64_t)q * Cf::PARTS + kt) * (Cf::WGROUPS * 8);
+        wdst_next = wring + (size_t)(s & 1) * Cf::WGROUPS * 8;
+    };
+    auto weights_one = [&](int j) {
+        const int i = wave + 8 * j;
+        const bool real = i < Cf::WINST;
+        glds16(wsrc_next + ((size_t)(real ? i : 0) * 64 + lane) * 8, real ? wdst_next + (size_t)i * 64 * 8 : scratch);
+    };
+    auto dma_of_step = [&](int st, int n) {                 // the WJ pieces spread over the n k-steps of a part
+        if constexpr ((ABL & 1) != 0) return;
+        if (n >= Cf::WJ) {
+            if (st < Cf::WJ) weights_one(st);
+        } else {                                             // fewer k-steps than pieces (NY = 3, last part): two pieces per step
+            if (2 * st < Cf::WJ) weights_one(2 * st);
+            if (2 * st + 1 < Cf::WJ) weights_one(2 * st + 1);
+        }
+    };
+
+    constexpr int ST = 4 * (Cf::Big::NPAIR + Cf::NB % 2);    // epilogue stores per wave
+    f32x4 acc[Cf::NB][4];
+    if (nstage > 0) {
+        issue_patch(0);
+        weights_prep(0);
+#pragma unroll
+        for (int j = 0; j < Cf::WJ; ++j) weights_one(j);
+    }
+    for (int s = 0; s < nstage; ++s) {
+        const int kt = s % Cf::PARTS, ps = s / Cf::PARTS, q = ps % nq;
+        const bool after_epilogue = kt == 0 && q == 0 && s > 0;
+        if (after_epilogue) wait_vmcnt<ST>();
+        else wait_vmcnt<0>();
+        stamp(0);
+        barrier_nodrain();
+        stamp(1);
+        weights_prep(s + 1);                                 // (the DMA of the last stage refills the free slot once more: branch-free loop)
+        if (q == 0 && kt == 0) {
+#pragma unroll
+            for (int b = 0; b < Cf::NB; ++b)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[b][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        {
+            const bf16_t* wl = wring + (size_t)(s & 1) * Cf::WGROUPS * 8 + wl_off;
+            if constexpr (Cf::NB <= 6) {
+                bf16x8 xa[4], wa[Cf::NB], xb[4], wb[Cf::NB];
+#pragma unroll
+                for (int k = 0; k < Cf::PARTS; ++k) {
+                    if (k == kt) {
+                        if (k == 0) mny_steps<Cf, 0, 0>(acc, xa, wa, xb, wb, patch, pk, wl, [&](int st) { dma_of_step(st, Cf::ksteps_of_part(0)); });
+                        if (k == 1) mny_steps<Cf, 1, 0>(acc, xa, wa, xb, wb, patch, pk, wl, [&](int st) { dma_of_step(st, Cf::ksteps_of_part(1)); });
+                    }
+                }
+            } else {
+                bf16x8 xa[4], xb[4], wf[Cf::NB];
+#pragma unroll
+                for (int k = 0; k < Cf::PARTS; ++k) {
+                    if (k == kt) {
+                        if (k == 0) mny_steps1w<Cf, 0, 0>(acc, xa, xb, wf, patch, pk, wl, [&](int st) { dma_of_step(st, Cf::ksteps_of_part(0)); });
+                        if (k == 1) mny_steps1w<Cf, 1, 0>(acc, xa, xb, wf, patch, pk, wl, [&](int st) { dma_of_step(st, Cf::ksteps_of_part(1)); });
+                        if (k == 2) mny_steps1w<Cf, 2, 0>(acc, xa, xb, wf, patch, pk, wl, [&](int st) { dma_of_step(st, Cf::ksteps_of_part(2)); });
+                    }
+                }
+            }
+        }
+        stamp(2);
+        if (kt == Cf::PARTS - 1) {
+            barrier_nodrain();                               // every wave has left the patch: it may be refilled
+            stamp(3);
+            if (s + 1 < nstage && !(ABL & 2)) issue_patch(ps + 1);
+            stamp(4);
+            if (q == nq - 1) {
+                int t0, f0; int64_t b;
+                tile_coords(ps / nq, t0, f0, b);
+                bf16_t* yb = Y + ((b * Th + t0 + wave) * (int64_t)Fw + f0) * Cout;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    bf16_t* yp = yb + (int64_t)(ni * 16 + l15) * Cout;
+#pragma unroll
+                    for (int j = 0; j < Cf::Big::NPAIR; ++j) {       // blocks 2 j, 2 j + 1: channels 32 j + 8 lq + [0, 8) (ConvBig::channel_of_row)
+                        const int co = j * 32 + lq * 8;
+                        float y[8];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const f32x4 scv = *reinterpret_cast<const f32x4*>(ss + co + 4 * h);
+                            const f32x4 shv = *reinterpret_cast<const f32x4*>(ss + Cf::ROWS + co + 4 * h);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) y[4 * h + r] = fmaxf(fmaf(acc[2 * j + h][ni][r], scv[r], shv[r]), 0.f);
+                        }
+                        if (!(ABL & 4) || y[0] == 12345.678f) store8(yp + co, y);
+                    }
+                    if constexpr (Cf::NB % 2 == 1) {
+                        constexpr int bb = Cf::NB - 1;
+                        const int co = bb * 16 + lq * 4;
+                        const f32x4 scv = *reinterpret_cast<const f32x4*>(ss + co);
+                        const f32x4 shv = *reinterpret_cast<const f32x4*>(ss + Cf::ROWS + co);
+                        float y[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[bb][ni][r], scv[r], shv[r]), 0.f);
+                        store4(yp + co, y);
+                    }
+                }
+                stamp(5);
+            }
+        }
+    }
+    wait_vmcnt<0>();                                         // the surplus LDS-DMA of the last stage lands before the wave ends
+    if constexpr (STAMP) {
+        if (lane == 0 && stamps) {
+            unsigned long long* o = stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+            for (int k = 0; k < 6; ++k) o[k] = tacc[k];
+            o[6] = clock_cycles() - tk0;
+            o[7] = clock_100mhz() - tr0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 3x3 convolution, level 1 (c = 96): everything double-buffered.
+// Stamps of the merged kernel (profiles/r02_big_conv_stamps.txt): with its k-loop at 89 % of the MFMA issue floor, 17 % of the launch is
+// the halo patch's LDS-DMA (62 KB after a barrier, at the ~18 B/clk a CU's LDS-DMA path delivers) with nothing to overlap it --
+// a second 63 KB patch does not fit beside two 43 KB weight slots.  Cutting the input channels into chunks of 32 instead of 48 makes
+// both fit: patch 10 x 66 pixels x 64 B = 42 KB (x 2), weight slot 96 rows x 5 taps x 64 B = 30 KB (x 2), 147 KB in all.  A chunk's
+// nine taps are nine k-steps of exactly one tap each (no padded k-groups: 648 instead of 672 MFMAs per tile and wave), run as two
+// stages of 5 + 4 taps; the next patch and the next weight slot arrive by LDS-DMA spread over the k-steps; ONE barrier per stage,
+// none per patch.  64-byte pixel records: k-group cg of pixel P sits at position cg ^ (((P >> 2) & 1) << 1), which makes the
+// ds_read_b128 of 16 consecutive pixels x {lq, lq ^ 1} conflict-free (scripts/lds_bank_sim.py).  The k order inside a layer differs from
+// the 48-channel kernels' (chunks of 32 channels, tap-major inside): same products, another fp32 summation order -- equal to them up
+// to flipped bf16 roundings, not bit-identical.
+// ------------------------------------------------------------------------------------------
+struct ConvMq {
+    static constexpr int NY = 2, TW = 64, TH = 8, KC = 32, CG = 4, NS = 9, PW = TW + 2, PH = TH + 2;
+    static constexpr int PARTS = 2, KS = 5;                 // taps 0..4, 5..8
+    static constexpr int WG = 4 * KS, ROWS = 96, NB = 6, NPAIR = 3;
+    static constexpr int PGROUPS = PH * PW * CG, PINST = (PGROUPS + 63) / 64, PJ = (PINST + 7) / 8;       // 2640, 42, 6
+    static constexpr int WGROUPS = ROWS * WG, WINST = WGROUPS / 64, WJ = (WINST + 7) / 8;                 // 1920, 30, 4
+    static constexpr int PBUF = PINST * 64;                 // a patch buffer holds whole LDS-DMA instructions (48 dead units at its end)
+    static constexpr size_t ring_bytes = 16 * (size_t)(2 * PBUF + 2 * WGROUPS);
+    static constexpr size_t lds_bytes = ring_bytes + 2 * ROWS * sizeof(float) + 1024;   // + 1 KiB scratch (surplus DMA pieces)
+    static_assert(lds_bytes <= 160 * 1024, "ConvMq: LDS budget");
+    __host__ __device__ static constexpr int ksteps_of_part(int pt) { return pt == 0 ? KS : NS - KS; }
+    __host__ __device__ static constexpr int wswz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+    __host__ __device__ static constexpr int pswz(int pix) { return ((pix >> 2) & 1) << 1; }
+};
+
+template <int TAP, int STL>
+__device__ __forceinline__ void mq_issue_reads(bf16x8 (&xf)[4], bf16x8 (&wf)[6], const bf16_t* patch, const int (&pk)[9], const bf16_t* wl) {
+    typedef ConvMq Cf;
+    const bf16_t* pl = patch + pk[TAP];
+    lds_read_async_b128<0 * 16 * Cf::KC * 2>(xf[0], pl);
+    lds_read_async_b128<1 * 16 * Cf::KC * 2>(xf[1], pl);
+    lds_read_async_b128<2 * 16 * Cf::KC * 2>(xf[2], pl);
+    lds_read_async_b128<3 * 16 * Cf::KC * 2>(xf[3], pl);
+    lds_read_async_b128<(0 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[0], wl);
+    lds_read_async_b128<(1 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[1], wl);
+    lds_read_async_b128<(2 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[2], wl);
+    lds_read_async_b128<(3 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[3], wl);
+    lds_read_async_b128<(4 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[4], wl);
+    lds_read_async_b128<(5 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[5], wl);
+}
+__device__ __forceinline__ void mq_mma(f32x4 (&acc)[6][4], const bf16x8 (&wf)[6], const bf16x8 (&xf)[4]) {
+#pragma unroll
+    for (int b = 0; b < 6; ++b)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) mma_step(acc[b][ni], wf[b], xf[ni]);
+}
+// PRIO: a wave's issue priority falls as it advances through a stage (3, 2, 1, 0, 0): of the two waves of a SIMD the one that is behind
+// wins the arbitration, so they alternate k-step by k-step instead of the older one running ahead and the younger one finishing alone
+// with its stalls exposed (in-kernel stamps: k-loops of 2,970 / 4,780 cycles per stage for waves 0-3 / 4-7)
+template <int PRIO, int STL>
+__device__ __forceinline__ void mq_prio() {
+    if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(STL < 3 ? 3 - STL : 0);
+}
+template <int PT, int STL, int PRIO, typename Dma>
+__device__ __forceinline__ void mq_steps(f32x4 (&acc)[6][4], bf16x8 (&xa)[4], bf16x8 (&wa)[6], bf16x8 (&xb)[4], bf16x8 (&wb)[6],
+                                         const bf16_t* patch, const int (&pk)[9], const bf16_t* wl, Dma dma) {
+    constexpr int N = ConvMq::ksteps_of_part(PT), T0 = PT * ConvMq::KS;
+    if constexpr (STL < N) {
+        if constexpr (STL == 0) mq_issue_reads<T0, 0>(xa, wa, patch, pk, wl);
+        mq_prio<PRIO, STL>();
+        lds_wait_n<0>();
+        if constexpr (STL + 1 < N) mq_issue_reads<T0 + STL + 1, STL + 1>(xb, wb, patch, pk, wl);
+        mq_mma(acc, wa, xa);
+        dma(STL);
+        sched_fence();
+        if constexpr (STL + 1 < N) {
+            mq_prio<PRIO, STL + 1>();
+            lds_wait_n<0>();
+            if constexpr (STL + 2 < N) mq_issue_reads<T0 + STL + 2, STL + 2>(xa, wa, patch, pk, wl);
+            mq_mma(acc, wb, xb);
+            dma(STL + 1);
+            sched_fence();
+            mq_steps<PT, STL + 2, PRIO>(acc, xa, wa, xb, wb, patch, pk, wl, dma);
+        }
+    }
+}
+
+template <bool STAMP = false, int PRIO = 0>
+__global__ void __launch_bounds__(kBigThreads, 2)
+conv3x3_bf16_mq_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp, const float* __restrict__ scale,
+                       const float* __restrict__ shift, const bf16_t* __restrict__ zero_page, int Th, int Fw, int Cin, int Cout, int tiles_t,
+                       int tiles_f, int ntiles, unsigned long long* __restrict__ stamps = nullptr) {
+    typedef ConvMq Cf;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tk0 = 0, tr0 = 0, tlast = 0;
+    auto stamp = [&](int k) {
+        if constexpr (STAMP) {
+            const unsigned long long now = clock_cycles();
+            tacc[k] += now - tlast;
+            tlast = now;
+        }
+    };
+    if constexpr (STAMP) {
+        tk0 = tlast = clock_cycles();
+        tr0 = clock_100mhz();
+    }
+    bf16_t* const patch0 = reinterpret_cast<bf16_t*>(alsep_smem);
+    bf16_t* const wring = patch0 + (size_t)2 * Cf::PBUF * 8;
+    float* ss = reinterpret_cast<float*>(alsep_smem + Cf::ring_bytes);
+    bf16_t* const scratch = reinterpret_cast<bf16_t*>(alsep_smem + Cf::lds_bytes - 1024);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int nq = Cin / Cf::KC;
+    for (int i = tid; i < Cf::ROWS; i += kBigThreads) {
+        ss[i] = scale[i];
+        ss[Cf::ROWS + i] = shift[i];
+    }
+    __syncthreads();
+
+    // per-lane LDS element offsets of the nine taps (pixel row = wave + dy, column = l15 + dx; + 16 pixels per ni: an immediate)
+    int pk[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int P = (wave + tap / 3) * Cf::PW + (tap % 3) + l15;
+        pk[tap] = (P * Cf::CG + (lq ^ Cf::pswz(P))) * 8;
+    }
+    const int wl_off = (l15 * Cf::WG + (lq ^ Cf::wswz(l15))) * 8;
+
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int npatch = my_tiles * nq, nstage = npatch * Cf::PARTS;
+    auto tile_coords = [&](int k, int& t0, int& f0, int64_t& b) {
+        int tile = (int)blockIdx.x + k * (int)gridDim.x;
+        const int tf = tile % tiles_f;  tile /= tiles_f;
+        const int tt = tile % tiles_t;
+        b = tile / tiles_t;
+        t0 = tt * Cf::TH;
+        f0 = tf * Cf::TW;
+    };
+    // LDS-DMA descriptors of a halo patch, computed once: lane -> 16-byte unit u of the patch image -> (pixel, position) -> channel group
+    int prel[Cf::PJ];
+    unsigned pflags = 0;
+#pragma unroll
+    for (int j = 0; j < Cf::PJ; ++j) {
+        const int u = (wave + 8 * j) * 64 + lane;
+        const int uu = u < Cf::PGROUPS ? u : Cf::PGROUPS - 1;
+        const int P = uu / Cf::CG, cg = (uu % Cf::CG) ^ Cf::pswz(P);
+        const int dt = P / Cf::PW - 1, df = P % Cf::PW - 1;
+        prel[j] = (dt * Fw + df) * Cin + cg * 8;
+        // the dead units at the end of the buffer (u >= PGROUPS) read the zero page: flagged as outside on every side
+        pflags |= (u < Cf::PGROUPS ? (unsigned)((dt < 0) | ((dt >= Cf::TH) << 1) | ((df < 0) << 2) | ((df >= Cf::TW) << 3)) : 16u) << (5 * j);
+    }
+    // patch ps (tile ps / nq, chunk ps % nq) -> buffer ps & 1; piece j of this wave.  Past the last patch the last one is fetched again
+    // into the free buffer (keeps the per-stage LDS-DMA count constant: the vmcnt waits below count instructions)
+    const bf16_t* psrc = X;
+    unsigned pborder = 0;
+    bf16_t* pdst = patch0;
+    auto patch_prep = [&](int ps) {
+        const int pc = ps < npatch ? ps : npatch - 1;
+        int t0, f0; int64_t b;
+        tile_coords(pc / nq, t0, f0, b);
+        psrc = X + ((b * Th + t0) * (int64_t)Fw + f0) * Cin + (pc % nq) * Cf::KC;
+        pborder = (unsigned)(t0 == 0) | ((unsigned)(t0 + Cf::TH >= Th) << 1) | ((unsigned)(f0 == 0) << 2) | ((unsigned)(f0 + Cf::TW >= Fw) << 3);
+        pdst = patch0 + (size_t)(ps & 1) * Cf::PBUF * 8;
+    };
+    auto patch_one = [&](int j) {                            // 5 flag bits per piece: the four borders + "dead unit"
+        const int i = wave + 8 * j;
+        const bool out = (pflags & ((pborder | 16u) << (5 * j))) != 0;
+        const bool real = j < Cf::PJ - 1 || i < Cf::PINST;   // instructions 40, 41: waves 0 and 1 only
+        const bf16_t* src = (out || !real) ? zero_page : psrc + prel[j];
+        glds16(src, real ? pdst + (size_t)i * 64 * 8 : scratch);
+    };
+    const bf16_t* wsrc_next = Wp;
+    bf16_t* wdst_next = wring;
+    auto weights_prep = [&](int s) {
+        const int pt = s % Cf::PARTS, q = (s / Cf::PARTS) % nq;
+        wsrc_next = Wp + ((int64_t)q * Cf::PARTS + pt) * (Cf::WGROUPS * 8);
+        wdst_next = wring + (size_t)(s & 1) * Cf::WGROUPS * 8;
+    };
+    auto weights_one = [&](int j) {
+        const int i = wave + 8 * j;
+        const bool real = i < Cf::WINST;
+        glds16(wsrc_next + ((size_t)(real ? i : 0) * 64 + lane) * 8, real ? wdst_next + (size_t)i * 64 * 8 : scratch);
+    };
+
+    constexpr int ST = 4 * Cf::NPAIR;                        // epilogue stores per wave
+    f32x4 acc[Cf::NB][4];
+    if (nstage > 0) {
+        patch_prep(0);
+#pragma unroll
+        for (int j = 0; j < Cf::PJ; ++j) patch_one(j);
+        weights_prep(0);
+#pragma unroll
+        for (int j = 0; j < Cf::WJ; ++j) weights_one(j);
+    }
+    for (int s = 0; s < nstage; ++s) {
+        const int pt = s % Cf::PARTS, ps = s / Cf::PARTS, q = ps % nq;
+        // In flight, oldest first: [this stage's weights (and patch)] [part 1: the PJ pieces of the next patch] [after an epilogue: ST stores]
+        if (pt == 1) wait_vmcnt<Cf::PJ>();
+        else if (q == 0 && s > 0) wait_vmcnt<ST>();
+        else wait_vmcnt<0>();
+        stamp(0);
+        barrier_nodrain();
+        stamp(1);
+        weights_prep(s + 1);
+        if (pt == 0) patch_prep(ps + 1);
+        if (q == 0 && pt == 0) {
+#pragma unroll
+            for (int b = 0; b < Cf::NB; ++b)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[b][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        {
+            const bf16_t* patch = patch0 + (size_t)(ps & 1) * Cf::PBUF * 8;
+            const bf16_t* wl = wring + (size_t)(s & 1) * Cf::WGROUPS * 8 + wl_off;
+            bf16x8 xa[4], wa[Cf::NB], xb[4], wb[Cf::NB];
+#pragma unroll
+            for (int k = 0; k < Cf::PARTS; ++k) {
+                if (k == pt) {
+                    // LDS-DMA schedule.  Part 0 (5 taps): the next weight slot first, then the WHOLE next patch (not needed before
+                    // the stage after next: still in flight at the next stage's vmcnt(PJ)); part 1 (4 taps): only its weights, early
+                    if (k == 0)
+                        mq_steps<0, 0, PRIO>(acc, xa, wa, xb, wb, patch, pk, wl, [&](int st) {
+                            if (st == 0) { weights_one(0); weights_one(1); }
+                            if (st == 1) { weights_one(2); weights_one(3); }
+                            if (st == 2) { patch_one(0); patch_one(1); }
+                            if (st == 3) { patch_one(2); patch_one(3); }
+                            if (st == 4) { patch_one(4); patch_one(5); }
+                        });
+                    if (k == 1)
+                        mq_steps<1, 0, PRIO>(acc, xa, wa, xb, wb, patch, pk, wl, [&](int st) {
+                            if (st == 0) { weights_one(0); weights_one(1); }
+                            if (st == 1) { weights_one(2); weights_one(3); }
+                        });
+                }
+            }
+        }
+        if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(0);
+        stamp(2);
+        if (pt == Cf::PARTS - 1 && q == nq - 1) {
+            int t0, f0; int64_t b;
+            tile_coords(ps / nq, t0, f0, b);
+            bf16_t* yb = Y + ((b * Th + t0 + wave) * (int64_t)Fw + f0) * Cout;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                bf16_t* yp = yb + (int64_t)(ni * 16 + l15) * Cout;
+#pragma unroll
+                for (int j = 0; j < Cf::NPAIR; ++j) {            // blocks 2 j, 2 j + 1: channels 32 j + 8 lq + [0, 8) (ConvBig::channel_of_row)
+                    const int co = j * 32 + lq * 8;
+                    float y[8];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 scv = *reinterpret_cast<const f32x4*>(ss + co + 4 * h);
+                        const f32x4 shv = *reinterpret_cast<const f32x4*>(ss + Cf::ROWS + co + 4 * h);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[4 * h + r] = fmaxf(fmaf(acc[2 * j + h][ni][r], scv[r], shv[r]), 0.f);
+                    }
+                    store8(yp + co, y);
+                }
+            }
+            stamp(5);
+        }
+    }
+    wait_vmcnt<0>();                                         // the surplus LDS-DMA of the last stages lands before the wave ends
     if constexpr (STAMP) {
         if (lane == 0 && stamps) {
             unsigned long long* o = stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
@@ -1986,6 +2589,8 @@ struct DevBuf {
 struct ConvLayer {       // 3x3
     DevBuf w, scale, shift;
     DevBuf w_big;            // conv3x3_bf16_big_kernel's image (c = 96 / 144): rows in ConvBig::channel_of_row order
+    DevBuf w_mny;            // conv3x3_bf16_mny_kernel's image (c = 96 / 144)
+    DevBuf w_mq;             // conv3x3_bf16_mq_kernel's image (c = 96)
     int cin = 0, cout = 0;
     bool dma_path = false;   // packed for conv3x3_bf16_kernel (swizzled, unpadded)
 };
@@ -2106,6 +2711,52 @@ std::vector<bf16_t> pack_conv3x3_big(const std::vector<float>& w, int cin) {
     return pack_conv3x3_dma(wp, cin, cout);
 }
 
+// image of conv3x3_bf16_mny_kernel<NY>: [q][kt][48 NY rows][WG groups][8]; row R holds output channel ConvBig::channel_of_row(R);
+// group (k-step stl of part kt, lq) sits at 4 stl + (lq ^ wswz(R)) and holds k-group 4 (kt KS + stl) + lq of the chunk (tap-major,
+// 6 groups of 8 input channels per tap; groups >= 54 are zero)
+template <int NY>
+std::vector<bf16_t> pack_conv3x3_mny(const std::vector<float>& w, int cin) {
+    typedef ConvMny<NY> Cf;
+    const int nq = cin / Cf::KC;
+    std::vector<bf16_t> out((size_t)nq * Cf::PARTS * Cf::WGROUPS * 8, host_cast<bf16_t>(0.f));
+    for (int q = 0; q < nq; ++q)
+        for (int kt = 0; kt < Cf::PARTS; ++kt)
+            for (int R = 0; R < Cf::ROWS; ++R)
+                for (int stl = 0; stl < Cf::ksteps_of_part(kt); ++stl)
+                    for (int lq = 0; lq < 4; ++lq) {
+                        const int grp = 4 * (kt * Cf::KS + stl) + lq;
+                        if (grp >= Cf::NG) continue;
+                        const int tap = grp / Cf::CG, cg = grp % Cf::CG, co = ConvBig<NY>::channel_of_row(R);
+                        const size_t dst = ((((size_t)q * Cf::PARTS + kt) * Cf::ROWS + R) * Cf::WG + 4 * stl + (lq ^ Cf::wswz(R))) * 8;
+                        for (int e = 0; e < 8; ++e) {
+                            const int ci = q * Cf::KC + cg * 8 + e;
+                            out[dst + e] = host_cast<bf16_t>(w[(((size_t)co * cin + ci) * 3 + tap / 3) * 3 + tap % 3]);
+                        }
+                    }
+    return out;
+}
+
+// image of conv3x3_bf16_mq_kernel (c_out = 96): [q][part][96 rows][20 groups][8]; k-step stl of part pt is tap 5 pt + stl, its group lq
+// (input channels 32 q + 8 lq ..) sits at 4 stl + (lq ^ wswz(R)); row R holds output channel ConvBig<2>::channel_of_row(R)
+std::vector<bf16_t> pack_conv3x3_mq(const std::vector<float>& w, int cin) {
+    typedef ConvMq Cf;
+    const int nq = cin / Cf::KC;
+    std::vector<bf16_t> out((size_t)nq * Cf::PARTS * Cf::WGROUPS * 8, host_cast<bf16_t>(0.f));
+    for (int q = 0; q < nq; ++q)
+        for (int pt = 0; pt < Cf::PARTS; ++pt)
+            for (int R = 0; R < Cf::ROWS; ++R)
+                for (int stl = 0; stl < Cf::ksteps_of_part(pt); ++stl)
+                    for (int lq = 0; lq < 4; ++lq) {
+                        const int tap = pt * Cf::KS + stl, co = ConvBig<2>::channel_of_row(R);
+                        const size_t dst = ((((size_t)q * Cf::PARTS + pt) * Cf::ROWS + R) * Cf::WG + 4 * stl + (lq ^ Cf::wswz(R))) * 8;
+                        for (int e = 0; e < 8; ++e) {
+                            const int ci = q * Cf::KC + lq * 8 + e;
+                            out[dst + e] = host_cast<bf16_t>(w[(((size_t)co * cin + ci) * 3 + tap / 3) * 3 + tap % 3]);
+                        }
+                    }
+    return out;
+}
+
 template <typename T> constexpr bool is_bf16() { return false; }
 template <> constexpr bool is_bf16<bf16_t>() { return true; }
 
@@ -2124,6 +2775,14 @@ int make_conv(alsep_net* net, const TensorMap& tm, const std::string& p, int c, 
         if (!rc && (c == 96 || c == 144)) {                  // a second image for the big-tile kernel (its own output-channel order)
             auto pb = c == 96 ? pack_conv3x3_big<2>(*w, c) : pack_conv3x3_big<3>(*w, c);
             rc = upload(net, pb.data(), pb.size() * sizeof(bf16_t), &L->w_big);
+            if (!rc) {
+                auto pm = c == 96 ? pack_conv3x3_mny<2>(*w, c) : pack_conv3x3_mny<3>(*w, c);
+                rc = upload(net, pm.data(), pm.size() * sizeof(bf16_t), &L->w_mny);
+            }
+            if (!rc && c == 96) {
+                auto pq = pack_conv3x3_mq(*w, c);
+                rc = upload(net, pq.data(), pq.size() * sizeof(bf16_t), &L->w_mq);
+            }
         }
     } else if (conv_uses_main<T>(c, c)) {
         auto pk = pack_conv3x3<T, ConvSel<T>::KC, ConvSel<T>::BN>(*w, c, c);
@@ -2408,6 +3067,33 @@ int launch_conv_pipe(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t
     return ALSEP_OK;
 }
 
+#ifndef ALSEP_CPU_EMUL
+// timing experiments: print the per-phase cycle sums a stamped conv kernel left in dbuf [workgroup][wave][8]
+int report_stamps(alsep_ctx* ctx, unsigned long long* dbuf, int gx, int stages, long long ntiles, const char* label) {
+    const size_t n = (size_t)256 * 8 * 8;
+    ALSEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned long long> h(n);
+    ALSEP_HIP(ctx, hipMemcpy(h.data(), dbuf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double mean[8] = {0};
+    for (int w = 0; w < gx * 8; ++w)
+        for (int k = 0; k < 8; ++k) mean[k] += (double)h[(size_t)w * 8 + k] / (gx * 8);
+    fprintf(stderr, "[%s stamp] tiles %lld grid %d stages/wg %d | cycles/wave: vmwait %.0f barrier %.0f kloop %.0f pbarrier %.0f pissue %.0f "
+                    "epilogue %.0f total %.0f | %.2f GHz | per stage: vmwait %.0f barrier %.0f kloop %.0f (MFMA floor %d)\n", label, ntiles,
+            gx, stages, mean[0], mean[1], mean[2], mean[3], mean[4], mean[5], mean[6], mean[6] / (mean[7] * 10.0), mean[0] / stages,
+            mean[1] / stages, mean[2] / stages, 2 * 14 * 12 * 16);
+    for (int w : {0, 4, 7})
+        fprintf(stderr, "    wg0 wave %d: vmwait %llu barrier %llu kloop %llu pbarrier %llu pissue %llu epilogue %llu total %llu\n", w,
+                h[w * 8 + 0], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5], h[w * 8 + 6]);
+    return ALSEP_OK;
+}
+unsigned long long* stamp_buffer(alsep_ctx* ctx) {
+    static unsigned long long* dbuf = nullptr;
+    if (!dbuf && hipMalloc(&dbuf, (size_t)256 * 8 * 8 * sizeof(unsigned long long)) != hipSuccess) dbuf = nullptr;
+    if (dbuf) (void)hipMemsetAsync(dbuf, 0, (size_t)256 * 8 * 8 * sizeof(unsigned long long), ctx->stream);
+    return dbuf;
+}
+#endif
+
 template <int NY>
 int launch_conv_big(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zero_page, int64_t B,
                     int Th, int Fw) {
@@ -2432,30 +3118,38 @@ int launch_conv_big(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     static int stamp_left = [] { const char* e = getenv("ALSEP_CONV_BIG_STAMP"); return e ? atoi(e) : 0; }();
     if (stamp_left > 0) {
         --stamp_left;
-        static unsigned long long* dbuf = nullptr;
-        const size_t n = (size_t)256 * 8 * 8;
-        if (!dbuf) ALSEP_HIP(ctx, hipMalloc(&dbuf, n * sizeof(unsigned long long)));
-        ALSEP_HIP(ctx, hipMemsetAsync(dbuf, 0, n * sizeof(unsigned long long), ctx->stream));
-        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_big_kernel<NY, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)Cf::lds_bytes));
-        hipLaunchKernelGGL((conv3x3_bf16_big_kernel<NY, false, true>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
-                           (const bf16_t*)L.w_big.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
-                           L.cout, tiles_t, tiles_f, (int)ntiles, dbuf);
+        unsigned long long* dbuf = stamp_buffer(ctx);
+        if (!dbuf) return alsep_fail(ctx, ALSEP_ERR_NOMEM, "stamp buffer");
+        static const int abl = [] { const char* e = getenv("ALSEP_CONV_BIG_ABL"); return e ? atoi(e) : 0; }();
+        auto go = [&](auto kern) -> int {
+            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
+            hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y, (const bf16_t*)L.w_big.p,
+                               (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin, L.cout, tiles_t, tiles_f, (int)ntiles,
+                               dbuf);
+            return ALSEP_OK;
+        };
+        int grc = ALSEP_OK;
+        if (NY != 2 || abl == 0) grc = go(conv3x3_bf16_big_kernel<NY, false, true, 0>);
+        else if constexpr (NY == 2) {
+            switch (abl) {
+                case 1: grc = go(conv3x3_bf16_big_kernel<2, false, true, 1>); break;
+                case 2: grc = go(conv3x3_bf16_big_kernel<2, false, true, 2>); break;
+                case 4: grc = go(conv3x3_bf16_big_kernel<2, false, true, 4>); break;
+                case 6: grc = go(conv3x3_bf16_big_kernel<2, false, true, 6>); break;
+                case 7: grc = go(conv3x3_bf16_big_kernel<2, false, true, 7>); break;
+                case 8: grc = go(conv3x3_bf16_big_kernel<2, false, true, 8>); break;
+                case 16: grc = go(conv3x3_bf16_big_kernel<2, false, true, 16>); break;
+                case 32: grc = go(conv3x3_bf16_big_kernel<2, false, true, 32>); break;
+                case 100: grc = go(conv3x3_bf16_big_kernel<2, true, true, 0>); break;      // the software-pipelined loop, stamped
+                default: return alsep_fail(ctx, ALSEP_ERR_ARG, "ALSEP_CONV_BIG_ABL: 1, 2, 4, 6, 7, 8, 16, 32 or 100");
+            }
+        }
+        if (grc) return grc;
         ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_big_kernel");
-        ALSEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        std::vector<unsigned long long> h(n);
-        ALSEP_HIP(ctx, hipMemcpy(h.data(), dbuf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        double mean[8] = {0};
-        for (int w = 0; w < gx * 8; ++w)
-            for (int k = 0; k < 8; ++k) mean[k] += (double)h[(size_t)w * 8 + k] / (gx * 8);
         const int stages = (int)((ntiles + gx - 1) / gx) * NY * (L.cin / Cf::KC);
-        fprintf(stderr, "[big<%d> stamp] tiles %lld grid %d stages/wg %d | cycles/wave: vmwait %.0f barrier %.0f kloop %.0f pbarrier %.0f pissue %.0f "
-                        "epilogue %.0f total %.0f | %.2f GHz | per stage: vmwait %.0f barrier %.0f kloop %.0f (MFMA floor %d)\n", NY,
-                (long long)ntiles, gx, stages, mean[0], mean[1], mean[2], mean[3], mean[4], mean[5], mean[6], mean[6] / (mean[7] * 10.0) ,
-                mean[0] / stages, mean[1] / stages, mean[2] / stages, 2 * 14 * 12 * 16);
-        for (int w : {0, 4, 7})
-            fprintf(stderr, "    wg0 wave %d: vmwait %llu barrier %llu kloop %llu pbarrier %llu pissue %llu epilogue %llu total %llu\n", w,
-                    h[w * 8 + 0], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5], h[w * 8 + 6]);
+        char label[64];
+        snprintf(label, sizeof label, "big<%d> abl %d", NY, abl);
+        if (int rrc = report_stamps(ctx, dbuf, gx, stages, (long long)ntiles, label)) return rrc;
         note_launch(ctx, NY == 3 ? "conv3x3_bf16_big_kernel<3>" : "conv3x3_bf16_big_kernel<2>");
         return ALSEP_OK;
     }
@@ -2474,6 +3168,112 @@ int launch_conv_big(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     note_launch(ctx, NY == 3 ? "conv3x3_bf16_big_kernel<3>" : "conv3x3_bf16_big_kernel<2>");
     ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_big_kernel");
     return ALSEP_OK;
+}
+
+template <int NY>
+int launch_conv_mny(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zero_page, int64_t B, int Th, int Fw) {
+    typedef ConvMny<NY> Cf;
+    const int tiles_t = Th / Cf::TH, tiles_f = Fw / Cf::TW;
+    const int64_t ntiles = B * tiles_t * tiles_f;
+    if (ntiles > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "conv3x3: too many tiles");
+    if (!L.w_mny.p) return alsep_fail(ctx, ALSEP_ERR_STATE, "conv3x3: no merged-kernel weight image for this layer");
+    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_mny_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
+    const int gx = ntiles < 256 ? (int)ntiles : 256;
+    ProfScope prof(ctx, NY == 3 ? ALSEP_PROF_CONV3X3_BIG3 : ALSEP_PROF_CONV3X3_BIG);
+#ifndef ALSEP_CPU_EMUL
+    static int stamp_left = [] { const char* e = getenv("ALSEP_CONV_BIG_STAMP"); return e ? atoi(e) : 0; }();
+    if (stamp_left > 0) {
+        --stamp_left;
+        unsigned long long* dbuf = stamp_buffer(ctx);
+        if (!dbuf) return alsep_fail(ctx, ALSEP_ERR_NOMEM, "stamp buffer");
+        static const int abl = [] { const char* e = getenv("ALSEP_CONV_BIG_ABL"); return e ? atoi(e) : 0; }();
+        auto go = [&](auto kern) -> int {
+            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
+            hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y, (const bf16_t*)L.w_mny.p,
+                               (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin, L.cout, tiles_t, tiles_f, (int)ntiles,
+                               dbuf);
+            return ALSEP_OK;
+        };
+        int grc = ALSEP_OK;
+        switch (abl) {
+            case 1: grc = go(conv3x3_bf16_mny_kernel<NY, true, 1>); break;
+            case 2: grc = go(conv3x3_bf16_mny_kernel<NY, true, 2>); break;
+            case 3: grc = go(conv3x3_bf16_mny_kernel<NY, true, 3>); break;
+            case 4: grc = go(conv3x3_bf16_mny_kernel<NY, true, 4>); break;
+            case 7: grc = go(conv3x3_bf16_mny_kernel<NY, true, 7>); break;
+            default: grc = go(conv3x3_bf16_mny_kernel<NY, true, 0>); break;
+        }
+        if (grc) return grc;
+        ALSEP_LAUNCH_CHECK(ctx, NY == 3 ? "conv3x3_bf16_mny_kernel<3>" : "conv3x3_bf16_mny_kernel<2>");
+        char label[64];
+        snprintf(label, sizeof label, "mny<%d> abl %d", NY, abl);
+        return report_stamps(ctx, dbuf, gx, (int)((ntiles + gx - 1) / gx) * Cf::PARTS * (L.cin / Cf::KC), (long long)ntiles, label);
+    }
+#endif
+    hipLaunchKernelGGL((conv3x3_bf16_mny_kernel<NY>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                       (const bf16_t*)L.w_mny.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin, L.cout, tiles_t,
+                       tiles_f, (int)ntiles);
+    ALSEP_LAUNCH_CHECK(ctx, NY == 3 ? "conv3x3_bf16_mny_kernel<3>" : "conv3x3_bf16_mny_kernel<2>");
+    return ALSEP_OK;
+}
+
+int launch_conv_mq(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zero_page, int64_t B, int Th, int Fw) {
+    typedef ConvMq Cf;
+    const int tiles_t = Th / Cf::TH, tiles_f = Fw / Cf::TW;
+    const int64_t ntiles = B * tiles_t * tiles_f;
+    if (ntiles > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "conv3x3: too many tiles");
+    if (!L.w_mq.p || L.cout != Cf::ROWS || L.cin % Cf::KC) return alsep_fail(ctx, ALSEP_ERR_STATE, "conv3x3: no mq weight image for this layer");
+    const int gx = ntiles < 256 ? (int)ntiles : 256;
+    ProfScope prof(ctx, ALSEP_PROF_CONV3X3_BIG);
+#ifndef ALSEP_CPU_EMUL
+    static int stamp_left = [] { const char* e = getenv("ALSEP_CONV_BIG_STAMP"); return e ? atoi(e) : 0; }();
+    if (stamp_left > 0) {
+        --stamp_left;
+        unsigned long long* dbuf = stamp_buffer(ctx);
+        if (!dbuf) return alsep_fail(ctx, ALSEP_ERR_NOMEM, "stamp buffer");
+        static const int sprio = [] { const char* e = getenv("ALSEP_CONV_MQ_PRIO"); return e ? atoi(e) : 0; }();
+        if (sprio) {
+            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_mq_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
+            hipLaunchKernelGGL((conv3x3_bf16_mq_kernel<true, 1>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                               (const bf16_t*)L.w_mq.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin, L.cout, tiles_t,
+                               tiles_f, (int)ntiles, dbuf);
+        } else {
+            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_mq_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
+            hipLaunchKernelGGL((conv3x3_bf16_mq_kernel<true, 0>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                               (const bf16_t*)L.w_mq.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin, L.cout, tiles_t,
+                               tiles_f, (int)ntiles, dbuf);
+        }
+        ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_mq_kernel");
+        return report_stamps(ctx, dbuf, gx, (int)((ntiles + gx - 1) / gx) * Cf::PARTS * (L.cin / Cf::KC), (long long)ntiles, sprio ? "mq prio" : "mq");
+    }
+#endif
+    static const int prio = [] { const char* e = getenv("ALSEP_CONV_MQ_PRIO"); return e ? atoi(e) : 0; }();
+    if (prio) {
+        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_mq_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
+        hipLaunchKernelGGL((conv3x3_bf16_mq_kernel<false, 1>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                           (const bf16_t*)L.w_mq.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin, L.cout, tiles_t,
+                           tiles_f, (int)ntiles, nullptr);
+    } else {
+        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_mq_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
+        hipLaunchKernelGGL((conv3x3_bf16_mq_kernel<false, 0>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                           (const bf16_t*)L.w_mq.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin, L.cout, tiles_t,
+                           tiles_f, (int)ntiles, nullptr);
+    }
+    ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_mq_kernel");
+    return ALSEP_OK;
+}
+
+// ALSEP_CONV_MQ (default 1): level-1 convs (c = 96) on the fully double-buffered kernel.  Same-box A/B at the bench shape
+// (profiles/r02_conv_level1_ab.txt): big-tile 316 us -> merged 262 us -> this 210-219 us per launch (1.13 PFLOP/s = 45 % of 2.5 PF)
+int conv_mq_enabled() {
+    static const int v = [] { const char* e = getenv("ALSEP_CONV_MQ"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
+// ALSEP_CONV_MNY: bit 0 the merged kernel at c = 96, bit 1 at c = 144 (default: see run_conv_dma)
+int conv_mny_enabled() {
+    static const int v = [] { const char* e = getenv("ALSEP_CONV_MNY"); return e ? atoi(e) : 0; }();
+    return v;
 }
 
 int conv_big_enabled() {
@@ -2507,8 +3307,12 @@ int run_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y,
     if (conv_big_enabled() && Th % 8 == 0 && Fw % 64 == 0 && L.cin == L.cout &&
         (conv_big_enabled() >= 2 || B * (Th / 8) * (Fw / 64) >= 96)) {       // =2: no minimum tile count (tests)
         switch (L.cout / 48) {
-            case 2: return launch_conv_big<2>(ctx, L, X, Y, zp, B, Th, Fw);
+            case 2:
+                if (conv_mq_enabled()) return launch_conv_mq(ctx, L, X, Y, zp, B, Th, Fw);
+                if (conv_mny_enabled() & 1) return launch_conv_mny<2>(ctx, L, X, Y, zp, B, Th, Fw);
+                return launch_conv_big<2>(ctx, L, X, Y, zp, B, Th, Fw);
             case 3:                                          // 8 VGPRs spill, outside the MFMA loops (ALSEP_CONV_BIG3=0: plain kernel)
+                if (conv_mny_enabled() & 2) return launch_conv_mny<3>(ctx, L, X, Y, zp, B, Th, Fw);
                 if (conv_big3_enabled()) return launch_conv_big<3>(ctx, L, X, Y, zp, B, Th, Fw);
                 break;
             default: break;                                  // NY = 4 spills heavily at 2 waves/SIMD with ROCm 7.2

@@ -177,6 +177,7 @@ static inline emul_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, 
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline void __builtin_amdgcn_s_barrier() { emul::sync_block(); }
 static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // callers pass wave-uniform values only
 // lanes are separate fibers here: a wave-level ordering point must actually rendezvous
 static inline void __builtin_amdgcn_wave_barrier() { emul::wave_sync(); }

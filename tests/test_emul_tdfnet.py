@@ -72,7 +72,7 @@ def test_net_bf16_persistent_conv_two_chunks(emul, monkeypatch):
     pipelined kernel for Cout = 96 / 144 (level 1: 9*4*4 = 144 tiles >= 128; level 2 falls back)."""
     import subprocess, sys, os
     code = (
-        "import os, sys, torch; sys.path.insert(0, %r); os.environ['ALSEP_CONV_REGW']='2'; os.environ['ALSEP_CONV_PIPE']='2'; os.environ['ALSEP_CONV_BIG']=sys.argv[1]\n"
+        "import os, sys, torch; sys.path.insert(0, %r); os.environ['ALSEP_CONV_REGW']='2'; os.environ['ALSEP_CONV_PIPE']='2'; os.environ['ALSEP_CONV_BIG']=sys.argv[1]; os.environ['ALSEP_CONV_MNY']=sys.argv[2]; os.environ['ALSEP_CONV_MQ']=sys.argv[3]\n"
         "from audiolab_amd import _lib\n"
         "_lib._LIB=_lib.bind(%r); _lib.DEVICE_TYPE='cpu'\n"
         "from audiolab_amd.synth import synthetic_state_dict\n"
@@ -86,8 +86,10 @@ def test_net_bf16_persistent_conv_two_chunks(emul, monkeypatch):
         "got=net.forward_nhwc(x.permute(0,3,2,1).contiguous()).float().permute(0,3,2,1)\n"
         "rel=float((got-want).norm()/want.norm()); print('rel', rel); assert rel < 8e-2\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpu_emul", "libalsep_emul.so"))
-    for big in ("0", "2"):        # 0: pipelined 4-wave kernel at level 1; 2: big-tile 8-wave kernel at level 1
-        r = subprocess.run([sys.executable, "-c", code, big], capture_output=True, text=True, timeout=600)
+    # 0: pipelined 4-wave kernel at level 1; 2: big-tile 8-wave kernel at level 1; 2 + MNY: its merged form
+    # ... 2 + MQ: the fully double-buffered level-1 kernel
+    for big, mny, mq in (("0", "0", "0"), ("2", "0", "0"), ("2", "3", "0"), ("2", "0", "1")):
+        r = subprocess.run([sys.executable, "-c", code, big, mny, mq], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
 
 
