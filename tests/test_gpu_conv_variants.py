@@ -32,7 +32,9 @@ np.save(sys.argv[1], np.stack(outs))
 
 def run_mode(mode, path, **extra):
     regw, pipe, big = mode
-    env = dict(os.environ, ALSEP_CONV_REGW=str(regw), ALSEP_CONV_PIPE=str(pipe), ALSEP_CONV_BIG=str(big), **extra)
+    # ALSEP_CONV_MQ=0 unless asked for: the default level-1 kernel sums in another order (not bit-identical with the kernels compared here)
+    env = dict(os.environ, ALSEP_CONV_REGW=str(regw), ALSEP_CONV_PIPE=str(pipe), ALSEP_CONV_BIG=str(big))
+    env.update({"ALSEP_CONV_MQ": "0", **extra})
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}, path], env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]
     return np.load(path)
