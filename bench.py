@@ -393,36 +393,45 @@ def main() -> None:
 
     # per-stage HBM rooflines (outside the timed region): STFT and iSTFT over this rank's windows
     stages = {}
-    plan = preds[0].model_.plan
-    nb = min(w_hi - w_lo, 52)
-    pad_len = plan.trim * 2 + nb * gen + plan.chunk_size
-    buf = torch.zeros((2, pad_len), device=device)
-    buf[:, plan.trim:plan.trim + min(n_samples, pad_len - 2 * plan.trim)] = mix[:, :min(n_samples, pad_len - 2 * plan.trim)]
-    spec = plan.stft_strided(buf, pad_len, gen, nb, dtype, _lib.LAYOUT_NHWC)
-    outb = torch.empty((2, nb * gen), device=device)
-    torch.cuda.synchronize()
-    for name, cat in (("stft", _lib.PROF_STFT), ("istft", _lib.PROF_ISTFT)):
-        reps = 10
-        ctx.profile_begin(cat)
-        for _ in range(reps):
+
+    def fft_stage_lines(plan, tag):
+        """STFT / iSTFT of `plan` over this rank's windows of the track: HIP-event time of 10 launches each"""
+        p_gen = plan.chunk_size - 2 * plan.trim
+        nb = min(n_samples // p_gen + 1, 52)
+        pad_len = plan.trim * 2 + nb * p_gen + plan.chunk_size
+        buf = torch.zeros((2, pad_len), device=device)
+        buf[:, plan.trim:plan.trim + min(n_samples, pad_len - 2 * plan.trim)] = mix[:, :min(n_samples, pad_len - 2 * plan.trim)]
+        spec = plan.stft_strided(buf, pad_len, p_gen, nb, dtype, _lib.LAYOUT_NHWC)
+        outb = torch.empty((2, nb * p_gen), device=device)
+        torch.cuda.synchronize()
+        for name, cat in (("stft", _lib.PROF_STFT), ("istft", _lib.PROF_ISTFT)):
+            reps = 10
+            ctx.profile_begin(cat)
+            for _ in range(reps):
+                if name == "stft":
+                    plan.stft_strided(buf, pad_len, p_gen, nb, dtype, _lib.LAYOUT_NHWC, out=spec)
+                else:
+                    plan.istft_strided(spec, _lib.LAYOUT_NHWC, outb, nb * p_gen, p_gen, plan.trim, plan.chunk_size - plan.trim, nb * p_gen)
+            ms, launches = ctx.profile_end()
+            spec_bytes = 4 * plan.dim_f * plan.dim_t * es
             if name == "stft":
-                plan.stft_strided(buf, pad_len, gen, nb, dtype, _lib.LAYOUT_NHWC, out=spec)
+                alg = 2 * plan.chunk_size * 4 + spec_bytes                     # SURVEY 8(d): PCM read + spec write
             else:
-                plan.istft_strided(spec, _lib.LAYOUT_NHWC, outb, nb * gen, gen, plan.trim, plan.chunk_size - plan.trim, nb * gen)
-        ms, launches = ctx.profile_end()
-        spec_bytes = 4 * cfg.dim_f * cfg.dim_t * es
-        if name == "stft":
-            alg = 2 * plan.chunk_size * 4 + spec_bytes                     # PCM read + spec write
-        else:
-            alg = spec_bytes + 3 * 2 * plan.chunk_size * 4                 # spec read + acc/div read-modify-write
-        gbs = alg * nb * reps / (ms * 1e-3) / 1e9
-        # PMC HBM bytes per launch of the stage's kernel, scaled to this launch's chunk count (the committed pass ran
-        # the same 52-chunk launches; traffic is linear in the chunk count)
-        tr = pmc_traffic("stft_r16_kernel" if name == "stft" else "istft_r16_kernel") if cfg.n_fft in (4096, 6144) else None
-        stages[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(gbs / PEAK_HBM_GBS, 4), "bytes_per_chunk": alg, "chunks_per_launch": nb,
-                        "us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
-                        "traffic": None if tr is None else tr * nb / 52.0, "algorithmic_bytes_per_launch": alg * nb}
+                alg = spec_bytes + 3 * 2 * plan.chunk_size * 4                 # spec read + acc/div read-modify-write
+            gbs = alg * nb * reps / (ms * 1e-3) / 1e9
+            # PMC HBM bytes per launch of the stage's kernel, scaled to this launch's chunk count (the committed pass ran
+            # the same 52-chunk launches; traffic is linear in the chunk count)
+            tr = pmc_traffic("stft_r16_kernel" if name == "stft" else "istft_r16_kernel") if (not tag and plan.n_fft in (4096, 6144)) else None
+            stages[name + tag] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": round(gbs / PEAK_HBM_GBS, 4), "n_fft": plan.n_fft, "dim_f": plan.dim_f,
+                                  "bytes_per_chunk": alg, "chunks_per_launch": nb,
+                                  "us_per_launch": round(ms * 1e3 / max(launches, 1), 2), "us_per_chunk": round(ms * 1e3 / max(launches, 1) / nb, 3),
+                                  "traffic": None if tr is None else tr * nb / 52.0, "algorithmic_bytes_per_launch": alg * nb}
+
+    fft_stage_lines(preds[0].model_.plan, "")
+    if cfg.n_fft != 7680:                                    # the geometry of the reference's own vocal models (Voc_FT, Kim_Vocal_*: n_fft 7680, dim_f 3072)
+        from audiolab_amd.mdx import StftPlan
+        fft_stage_lines(StftPlan(ctx, 7680, 1024, 3072, 256), "_7680")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
