@@ -1693,6 +1693,237 @@ conv3x3_bf16_mq_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, con
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 3x3 convolution, level 0 (c = 48), in the structure of conv3x3_bf16_mq_kernel: 8 waves, 8 x 48-pixel tiles (one row of three
+// 16-pixel blocks per wave), the 43 KB weight block resident in LDS for the life of the workgroup (loaded once: no weight stream at
+// all), two 48 KB halo patches (the next tile's arrives by LDS-DMA during this tile's k-loop), one barrier per tile, no VALU in the
+// k-loop (per-lane LDS bases + immediates, asm reads one k-step ahead), 16- and 8-byte epilogue stores.  Against the register-weight
+// kernel: halo 1.30 x instead of 1.59 x through the LDS-DMA path, 126 MFMAs per barrier instead of 84, descriptors computed once.
+// Same k order as every 48-channel kernel: bit-identical to the plain kernel.
+// ------------------------------------------------------------------------------------------
+struct ConvM0 {
+    static constexpr int TW = 48, TH = 8, KC = 48, CG = 6, NG = 54, NS = 14, WGRP = 56, NI = 3, NB = 3, ROWS = 48;
+    static constexpr int PW = TW + 2, PH = TH + 2;
+    static constexpr int PGROUPS = PH * PW * CG, PINST = (PGROUPS + 63) / 64, PJ = (PINST + 7) / 8, PBUF = PINST * 64;   // 3000, 47, 6, 3008
+    static constexpr int WGROUPS = ROWS * WGRP, WINST = WGROUPS / 64;                                                  // 2688, 42
+    static constexpr size_t ring_bytes = 16 * (size_t)(2 * PBUF + WGROUPS);
+    static constexpr size_t lds_bytes = ring_bytes + 2 * ROWS * sizeof(float) + 1024;   // + 1 KiB scratch (surplus DMA pieces)
+    static_assert(lds_bytes <= 160 * 1024, "ConvM0: LDS budget");
+};
+
+template <int ST>
+__device__ __forceinline__ void m0_issue_reads(bf16x8 (&xf)[3], bf16x8 (&wf)[3], const bf16_t* patch, const int (&pk)[14], const bf16_t* we,
+                                               const bf16_t* wo) {
+    typedef ConvM0 Cf;
+    const bf16_t* pl = patch + pk[ST];
+    lds_read_async_b128<0 * 16 * Cf::KC * 2>(xf[0], pl);
+    lds_read_async_b128<1 * 16 * Cf::KC * 2>(xf[1], pl);
+    lds_read_async_b128<2 * 16 * Cf::KC * 2>(xf[2], pl);
+    const bf16_t* wl = (ST & 1) ? wo : we;
+    lds_read_async_b128<(0 * 16 * Cf::WGRP * 8 + ST * 32) * 2>(wf[0], wl);
+    lds_read_async_b128<(1 * 16 * Cf::WGRP * 8 + ST * 32) * 2>(wf[1], wl);
+    lds_read_async_b128<(2 * 16 * Cf::WGRP * 8 + ST * 32) * 2>(wf[2], wl);
+}
+__device__ __forceinline__ void m0_mma(f32x4 (&acc)[3][3], const bf16x8 (&wf)[3], const bf16x8 (&xf)[3]) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int ni = 0; ni < 3; ++ni) mma_step(acc[b][ni], wf[b], xf[ni]);
+}
+template <int ST, typename Dma>
+__device__ __forceinline__ void m0_steps(f32x4 (&acc)[3][3], bf16x8 (&xa)[3], bf16x8 (&wa)[3], bf16x8 (&xb)[3], bf16x8 (&wb)[3],
+                                         const bf16_t* patch, const int (&pk)[14], const bf16_t* we, const bf16_t* wo, Dma dma) {
+    constexpr int N = ConvM0::NS;
+    if constexpr (ST < N) {
+        if constexpr (ST == 0) m0_issue_reads<0>(xa, wa, patch, pk, we, wo);
+        lds_wait_n<0>();
+        if constexpr (ST + 1 < N) m0_issue_reads<ST + 1>(xb, wb, patch, pk, we, wo);
+        m0_mma(acc, wa, xa);
+        dma(ST);
+        sched_fence();
+        if constexpr (ST + 1 < N) {
+            lds_wait_n<0>();
+            if constexpr (ST + 2 < N) m0_issue_reads<ST + 2>(xa, wa, patch, pk, we, wo);
+            m0_mma(acc, wb, xb);
+            dma(ST + 1);
+            sched_fence();
+            m0_steps<ST + 2>(acc, xa, wa, xb, wb, patch, pk, we, wo, dma);
+        }
+    }
+}
+
+template <bool STAMP = false, bool DEFER = false>
+__global__ void __launch_bounds__(kBigThreads, 2)
+conv3x3_bf16_m0_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp, const float* __restrict__ scale,
+                       const float* __restrict__ shift, const bf16_t* __restrict__ zero_page, int Th, int Fw, int Cin, int Cout, int tiles_t,
+                       int tiles_f, int ntiles, unsigned long long* __restrict__ stamps = nullptr) {
+    typedef ConvM0 Cf;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tk0 = 0, tr0 = 0, tlast = 0;
+    auto stamp = [&](int k) {
+        if constexpr (STAMP) {
+            const unsigned long long now = clock_cycles();
+            tacc[k] += now - tlast;
+            tlast = now;
+        }
+    };
+    if constexpr (STAMP) {
+        tk0 = tlast = clock_cycles();
+        tr0 = clock_100mhz();
+    }
+    bf16_t* const patch0 = reinterpret_cast<bf16_t*>(alsep_smem);
+    bf16_t* const wts = patch0 + (size_t)2 * Cf::PBUF * 8;
+    float* ss = reinterpret_cast<float*>(alsep_smem + Cf::ring_bytes);
+    bf16_t* const scratch = reinterpret_cast<bf16_t*>(alsep_smem + Cf::lds_bytes - 1024);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    for (int i = tid; i < Cf::ROWS; i += kBigThreads) {
+        ss[i] = scale[i];
+        ss[Cf::ROWS + i] = shift[i];
+    }
+    // the weight block, once: 42 LDS-DMA instructions (waves 0, 1: six; the others five + one into the scratch)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int i = wave + 8 * j;
+        const bool real = i < Cf::WINST;
+        glds16(Wp + ((size_t)(real ? i : 0) * 64 + lane) * 8, real ? wts + (size_t)i * 64 * 8 : scratch);
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+
+    int pk[Cf::NS];
+#pragma unroll
+    for (int st = 0; st < Cf::NS; ++st) {
+        const int grp = 4 * st + lq;
+        const int gc = grp < Cf::NG ? grp : Cf::NG - 1;
+        const int tap = gc / Cf::CG, cg = gc % Cf::CG;
+        pk[st] = ((wave + tap / 3) * Cf::PW + (tap % 3) + l15) * Cf::KC + cg * 8;
+    }
+    // weight row l15, swizzled group of an even / odd k-step (see conv3x3_bf16_big_kernel)
+    const int wswz = l15 >> 1;
+    const int b32 = (wswz >> 2) * 32, c8 = (lq ^ (wswz & 3)) * 8;
+    const bf16_t* const we = wts + l15 * Cf::WGRP * 8 + c8 + b32;
+    const bf16_t* const wo = wts + l15 * Cf::WGRP * 8 + c8 - b32;
+
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    auto tile_coords = [&](int k, int& t0, int& f0, int64_t& b) {
+        int tile = (int)blockIdx.x + k * (int)gridDim.x;
+        const int tf = tile % tiles_f;  tile /= tiles_f;
+        const int tt = tile % tiles_t;
+        b = tile / tiles_t;
+        t0 = tt * Cf::TH;
+        f0 = tf * Cf::TW;
+    };
+    int prel[Cf::PJ];
+    unsigned pflags = 0;
+#pragma unroll
+    for (int j = 0; j < Cf::PJ; ++j) {
+        const int u = (wave + 8 * j) * 64 + lane;
+        const int uu = u < Cf::PGROUPS ? u : Cf::PGROUPS - 1;
+        const int P = uu / Cf::CG, cg = uu % Cf::CG;
+        const int dt = P / Cf::PW - 1, df = P % Cf::PW - 1;
+        prel[j] = (dt * Fw + df) * Cin + cg * 8;
+        pflags |= (u < Cf::PGROUPS ? (unsigned)((dt < 0) | ((dt >= Cf::TH) << 1) | ((df < 0) << 2) | ((df >= Cf::TW) << 3)) : 16u) << (5 * j);
+    }
+    const bf16_t* psrc = X;
+    unsigned pborder = 0;
+    bf16_t* pdst = patch0;
+    auto patch_prep = [&](int k) {                           // tile k of this workgroup -> buffer k & 1 (past the last one: the last again)
+        const int kc = k < my_tiles ? k : my_tiles - 1;
+        int t0, f0; int64_t b;
+        tile_coords(kc, t0, f0, b);
+        psrc = X + ((b * Th + t0) * (int64_t)Fw + f0) * Cin;
+        pborder = (unsigned)(t0 == 0) | ((unsigned)(t0 + Cf::TH >= Th) << 1) | ((unsigned)(f0 == 0) << 2) | ((unsigned)(f0 + Cf::TW >= Fw) << 3);
+        pdst = patch0 + (size_t)(k & 1) * Cf::PBUF * 8;
+    };
+    auto patch_one = [&](int j) {
+        const int i = wave + 8 * j;
+        const bool out = (pflags & ((pborder | 16u) << (5 * j))) != 0;
+        const bool real = j < Cf::PJ - 1 || i < Cf::PINST;
+        const bf16_t* src = (out || !real) ? zero_page : psrc + prel[j];
+        glds16(src, real ? pdst + (size_t)i * 64 * 8 : scratch);
+    };
+
+    constexpr int ST = 2 * Cf::NI;                           // epilogue stores per wave and tile
+    f32x4 acc[3][3];
+    if (my_tiles > 0) {
+        patch_prep(0);
+#pragma unroll
+        for (int j = 0; j < Cf::PJ; ++j) patch_one(j);
+    }
+    // DEFER (experiment, off): the epilogue of the younger half of the workgroup (waves 4-7) behind the next tile's barrier.  The older
+    // wave of a SIMD wins every arbitration: waves 0-3 leave the k-loop ~2,000 cycles before waves 4-7 and store their rows while those
+    // still compute; waves 4-7's stores sit on the critical path in front of the barrier (stamps: 15-18 % of the launch).  Deferred they
+    // were meant to overlap the older half's next k-loop -- measured: their 6 stores then take 2,900 instead of 1,000 cycles per tile
+    // (issued beside the older half's LDS-DMA burst) and the launch goes from 233 to 265 us.
+    auto epilogue = [&](int k) {
+        int t0, f0; int64_t b;
+        tile_coords(k, t0, f0, b);
+        bf16_t* yb = Y + ((b * Th + t0 + wave) * (int64_t)Fw + f0) * Cout;
+#pragma unroll
+        for (int ni = 0; ni < Cf::NI; ++ni) {
+            bf16_t* yp = yb + (int64_t)(ni * 16 + l15) * Cout;
+            {                                                // blocks 0, 1: channels 8 lq + [0, 8) (ConvBig<1>::channel_of_row)
+                const int co = lq * 8;
+                float y[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 scv = *reinterpret_cast<const f32x4*>(ss + co + 4 * h);
+                    const f32x4 shv = *reinterpret_cast<const f32x4*>(ss + Cf::ROWS + co + 4 * h);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[4 * h + r] = fmaxf(fmaf(acc[h][ni][r], scv[r], shv[r]), 0.f);
+                }
+                store8(yp + co, y);
+            }
+            {                                                // block 2: channels 32 + 4 lq + [0, 4)
+                const int co = 32 + lq * 4;
+                const f32x4 scv = *reinterpret_cast<const f32x4*>(ss + co);
+                const f32x4 shv = *reinterpret_cast<const f32x4*>(ss + Cf::ROWS + co);
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[2][ni][r], scv[r], shv[r]), 0.f);
+                store4(yp + co, y);
+            }
+        }
+    };
+    const bool late = DEFER && wave >= 4;
+    for (int k = 0; k < my_tiles; ++k) {
+        // in flight, oldest first: [this tile's patch (and, k = 0, the weights)] [waves that store before the barrier: the ST stores of
+        // the previous tile].  A deferring wave's stores were issued before the patch pieces: nothing younger than the patch.
+        if (k > 0 && !late) wait_vmcnt<ST>();
+        else wait_vmcnt<0>();
+        stamp(0);
+        barrier_nodrain();
+        stamp(1);
+        if (late && k > 0) epilogue(k - 1);
+        stamp(3);
+        patch_prep(k + 1);
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int ni = 0; ni < 3; ++ni) acc[b][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const bf16_t* patch = patch0 + (size_t)(k & 1) * Cf::PBUF * 8;
+            bf16x8 xa[3], wa[3], xb[3], wb[3];
+            m0_steps<0>(acc, xa, wa, xb, wb, patch, pk, we, wo, [&](int st) {
+                if (st < Cf::PJ) patch_one(st);              // the next tile's patch, one piece per k-step
+            });
+        }
+        stamp(2);
+        if (!late) epilogue(k);
+        stamp(5);
+    }
+    if (late && my_tiles > 0) epilogue(my_tiles - 1);
+    wait_vmcnt<0>();
+    if constexpr (STAMP) {
+        if (lane == 0 && stamps) {
+            unsigned long long* o = stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+            for (int k = 0; k < 6; ++k) o[k] = tacc[k];
+            o[6] = clock_cycles() - tk0;
+            o[7] = clock_100mhz() - tr0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // generic tile GEMM: 64 weight rows x 128 activation columns per workgroup, BK = 8 k-groups.
 // ------------------------------------------------------------------------------------------
 template <typename T>
@@ -2784,6 +3015,10 @@ int make_conv(alsep_net* net, const TensorMap& tm, const std::string& p, int c, 
                 rc = upload(net, pq.data(), pq.size() * sizeof(bf16_t), &L->w_mq);
             }
         }
+        if (!rc && c == 48) {                                // level 0: the LDS-resident-weight kernel's image (its own output-channel order)
+            auto p0 = pack_conv3x3_big<1>(*w, c);
+            rc = upload(net, p0.data(), p0.size() * sizeof(bf16_t), &L->w_big);
+        }
     } else if (conv_uses_main<T>(c, c)) {
         auto pk = pack_conv3x3<T, ConvSel<T>::KC, ConvSel<T>::BN>(*w, c, c);
         rc = upload(net, pk.data(), pk.size() * sizeof(T), &L->w);
@@ -3265,6 +3500,59 @@ int launch_conv_mq(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* 
 
 // ALSEP_CONV_MQ (default 1): level-1 convs (c = 96) on the fully double-buffered kernel.  Same-box A/B at the bench shape
 // (profiles/r02_conv_level1_ab.txt): big-tile 316 us -> merged 262 us -> this 210-219 us per launch (1.13 PFLOP/s = 45 % of 2.5 PF)
+int launch_conv_m0(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zero_page, int64_t B, int Th, int Fw) {
+    typedef ConvM0 Cf;
+    const int tiles_t = Th / Cf::TH, tiles_f = Fw / Cf::TW;
+    const int64_t ntiles = B * tiles_t * tiles_f;
+    if (ntiles > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "conv3x3: too many tiles");
+    if (!L.w_big.p || L.cout != Cf::ROWS || L.cin != Cf::KC) return alsep_fail(ctx, ALSEP_ERR_STATE, "conv3x3: no m0 weight image for this layer");
+    const int gx = ntiles < 256 ? (int)ntiles : 256;
+    static const int defer = [] { const char* e = getenv("ALSEP_CONV_M0_DEFER"); return e ? atoi(e) : 0; }();
+    ProfScope prof(ctx, ALSEP_PROF_CONV3X3_REGW);
+#ifndef ALSEP_CPU_EMUL
+    static int stamp_left = [] { const char* e = getenv("ALSEP_CONV_M0_STAMP"); return e ? atoi(e) : 0; }();
+    if (stamp_left > 0) {
+        --stamp_left;
+        unsigned long long* dbuf = stamp_buffer(ctx);
+        if (!dbuf) return alsep_fail(ctx, ALSEP_ERR_NOMEM, "stamp buffer");
+        if (defer) {
+            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_m0_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
+            hipLaunchKernelGGL((conv3x3_bf16_m0_kernel<true, true>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                               (const bf16_t*)L.w_big.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin, L.cout, tiles_t,
+                               tiles_f, (int)ntiles, dbuf);
+        } else {
+            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_m0_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
+            hipLaunchKernelGGL((conv3x3_bf16_m0_kernel<true, false>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                               (const bf16_t*)L.w_big.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin, L.cout, tiles_t,
+                               tiles_f, (int)ntiles, dbuf);
+        }
+        ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_m0_kernel");
+        return report_stamps(ctx, dbuf, gx, (int)((ntiles + gx - 1) / gx), (long long)ntiles, defer ? "m0 defer" : "m0");
+    }
+#endif
+    if (defer) {
+        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_m0_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
+        hipLaunchKernelGGL((conv3x3_bf16_m0_kernel<false, true>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                           (const bf16_t*)L.w_big.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin, L.cout, tiles_t,
+                           tiles_f, (int)ntiles, nullptr);
+    } else {
+        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_m0_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
+        hipLaunchKernelGGL((conv3x3_bf16_m0_kernel<false, false>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                           (const bf16_t*)L.w_big.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin, L.cout, tiles_t,
+                           tiles_f, (int)ntiles, nullptr);
+    }
+    ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_m0_kernel");
+    return ALSEP_OK;
+}
+
+// ALSEP_CONV_M0 (default 1): level-0 convs (c = 48, T % 8 == 0, F % 48 == 0, >= 256 tiles) on the LDS-resident-weight kernel; same-box
+// A/B at the bench shape (profiles/r02_conv_level0_ab.txt): register-weight kernel 268.5 us -> 233 us per 1.12 GB launch (4.8 TB/s = 60 % of 8
+// TB/s).  ALSEP_CONV_M0_DEFER=1 (waves 4-7 store behind the next barrier) measured slower (265 us): off.
+int conv_m0_enabled() {
+    static const int v = [] { const char* e = getenv("ALSEP_CONV_M0"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 int conv_mq_enabled() {
     static const int v = [] { const char* e = getenv("ALSEP_CONV_MQ"); return e ? atoi(e) : 1; }();
     return v;
@@ -3299,6 +3587,9 @@ int conv_regw_enabled() {
 }
 
 int run_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zp, int64_t B, int Th, int Fw) {
+    if (conv_m0_enabled() && L.cin == 48 && L.cout == 48 && Th % 8 == 0 && Fw % 48 == 0 &&
+        (conv_m0_enabled() >= 2 || B * (Th / 8) * (Fw / 48) >= 256))          // =2: no minimum tile count (tests)
+        return launch_conv_m0(ctx, L, X, Y, zp, B, Th, Fw);
     if (conv_regw_enabled() && Th % 4 == 0 && Fw % 64 == 0 && L.cin == L.cout) {
         if (L.cin == 48 && conv_regw_enabled() == 3) return launch_conv_regw<1>(ctx, L, X, Y, zp, B, Th, Fw);   // one workgroup per CU
         if (L.cin == 48) return launch_conv_regw<1, 3, 2, 32>(ctx, L, X, Y, zp, B, Th, Fw);   // 4 x 32 tiles, two workgroups per CU

@@ -333,7 +333,8 @@ def main() -> None:
     big_name = next((n for n in ("conv3x3_bf16_mq_kernel", "conv3x3_bf16_mny_kernel<2>") if ctx.launch_count(n) > 0),
                     "conv3x3_bf16_big_kernel<2>")
     big3_name = "conv3x3_bf16_mny_kernel<3>" if ctx.launch_count("conv3x3_bf16_mny_kernel<3>") > 0 else "conv3x3_bf16_big_kernel<3>"
-    KCLASS = {"big": (big_name, KCAT["big"]), "big3": (big3_name, KCAT["big3"]), "regw": ("conv3x3_bf16_regw_kernel<1>", KCAT["regw"]),
+    l0_name = "conv3x3_bf16_m0_kernel" if ctx.launch_count("conv3x3_bf16_m0_kernel") > 0 else "conv3x3_bf16_regw_kernel<1>"
+    KCLASS = {"big": (big_name, KCAT["big"]), "big3": (big3_name, KCAT["big3"]), "regw": (l0_name, KCAT["regw"]),
               "plain": ("conv3x3_bf16_kernel<64>" if half else "conv3x3_kernel<f32,16,48,64>", KCAT["plain"])}
     primary = max(share, key=share.get) if share else "plain"
     ctx.profile_begin(KCLASS[primary][1])

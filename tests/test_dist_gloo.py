@@ -96,7 +96,7 @@ def _worker_ola_demucs(rank, world, port, emul_so, out_path):
     cfg = TDFNetConfig(dim_f=64, dim_t=32, n_fft=256, hop=64, num_blocks=3, g=16)
     sd = synthetic_state_dict(cfg, seed=3)
     net = TDFNet(cfg, sd, ctx=ctx, dtype=torch.float32, max_batch=2)
-    mix = synth_mix(4000, seed=31)
+    mix = synth_mix(3000, seed=31)
     got = OlaRunner(net, ctx=ctx, overlap=0.75, compensate=1.02, max_batch=2, sharded=True).demix(torch.from_numpy(mix)).numpy()
     g = mo.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
 

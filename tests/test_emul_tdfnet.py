@@ -72,7 +72,7 @@ def test_net_bf16_persistent_conv_two_chunks(emul, monkeypatch):
     pipelined kernel for Cout = 96 / 144 (level 1: 9*4*4 = 144 tiles >= 128; level 2 falls back)."""
     import subprocess, sys, os
     code = (
-        "import os, sys, torch; sys.path.insert(0, %r); os.environ['ALSEP_CONV_REGW']='2'; os.environ['ALSEP_CONV_PIPE']='2'; os.environ['ALSEP_CONV_BIG']=sys.argv[1]; os.environ['ALSEP_CONV_MNY']=sys.argv[2]; os.environ['ALSEP_CONV_MQ']=sys.argv[3]\n"
+        "import os, sys, torch; sys.path.insert(0, %r); os.environ['ALSEP_CONV_REGW']='2'; os.environ['ALSEP_CONV_PIPE']='2'; os.environ['ALSEP_CONV_BIG']=sys.argv[1]; os.environ['ALSEP_CONV_MNY']=sys.argv[2]; os.environ['ALSEP_CONV_MQ']=sys.argv[3]; os.environ['ALSEP_CONV_M0']=sys.argv[4]\n"
         "from audiolab_amd import _lib\n"
         "_lib._LIB=_lib.bind(%r); _lib.DEVICE_TYPE='cpu'\n"
         "from audiolab_amd.synth import synthetic_state_dict\n"
@@ -88,8 +88,9 @@ def test_net_bf16_persistent_conv_two_chunks(emul, monkeypatch):
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpu_emul", "libalsep_emul.so"))
     # 0: pipelined 4-wave kernel at level 1; 2: big-tile 8-wave kernel at level 1; 2 + MNY: its merged form
     # ... 2 + MQ: the fully double-buffered level-1 kernel
-    for big, mny, mq in (("0", "0", "0"), ("2", "0", "0"), ("2", "3", "0"), ("2", "0", "1")):
-        r = subprocess.run([sys.executable, "-c", code, big, mny, mq], capture_output=True, text=True, timeout=600)
+    # the last: + the LDS-resident-weight level-0 kernel (48-pixel tiles: dim_f 256 is not a multiple of 48 -> it needs its own shape below)
+    for big, mny, mq, m0 in (("0", "0", "0", "0"), ("2", "3", "0", "0"), ("2", "0", "1", "2")):
+        r = subprocess.run([sys.executable, "-c", code, big, mny, mq, m0], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
 
 
@@ -154,3 +155,33 @@ def test_net_f16_g48_vs_storage_oracle(emul):
         r = lambda a, b: float((a - b).norm() / b.norm())
         print(f"f16 num_blocks={nb}: vs storage oracle {r(got, wst):.3e}, vs fp32 oracle {r(got, w32):.3e}")
         assert r(got, wst) < 1e-3 and r(got, w32) < 3e-3
+
+
+def test_level0_lds_weight_kernel_bit_identical_on_emulation(emul, tmp_path):
+    """conv3x3_bf16_m0_kernel (8 x 48-pixel tiles, weights resident in LDS, double-buffered patches) against the register-weight kernel on
+    the same one-block network: same k order, so the outputs must be bit-identical (the GPU twin: tests/test_gpu_conv_variants.py)"""
+    import subprocess, sys, os
+    code = (
+        "import os, sys, torch, numpy as np; sys.path.insert(0, %r); os.environ['ALSEP_CONV_M0']=sys.argv[1]\n"
+        "from audiolab_amd import _lib\n"
+        "_lib._LIB=_lib.bind(%r); _lib.DEVICE_TYPE='cpu'\n"
+        "from audiolab_amd.synth import synthetic_state_dict\n"
+        "from audiolab_amd.tdfnet import TDFNet, TDFNetConfig\n"
+        "cfg=TDFNetConfig(dim_f=192, dim_t=16, n_fft=512, hop=64, num_blocks=1, g=48)\n"
+        "sd=synthetic_state_dict(cfg, calib_frames=16)\n"
+        "ctx=_lib.Context('cpu')\n"
+        "net=TDFNet(cfg, sd, ctx=ctx, dtype=torch.bfloat16, max_batch=3)\n"
+        "x=(torch.randn((3,16,192,4), generator=torch.Generator().manual_seed(3))*4).to(torch.bfloat16)\n"
+        "y=net.forward_nhwc(x).float().numpy()\n"
+        "print('m0 launches', ctx.launch_count('conv3x3_bf16_m0_kernel'))\n"
+        "np.save(sys.argv[2], y)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpu_emul", "libalsep_emul.so"))
+    outs = []
+    for m0 in ("0", "2"):
+        path = str(tmp_path / f"y{m0}.npy")
+        r = subprocess.run([sys.executable, "-c", code, m0, path], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert ("m0 launches 3" in r.stdout) == (m0 == "2"), r.stdout
+        outs.append(np.load(path))
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 1e-3
+    assert np.array_equal(outs[0], outs[1]), f"max diff {np.abs(outs[0] - outs[1]).max()}"

@@ -18,7 +18,7 @@ from audiolab_amd import _lib
 from audiolab_amd.synth import synthetic_state_dict
 from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
 ctx = _lib.Context("cuda:0")
-cfg = TDFNetConfig(dim_f=1024, dim_t=128, n_fft=2048, hop=256, num_blocks=7, g=48)
+cfg = TDFNetConfig(dim_f=1536, dim_t=128, n_fft=4096, hop=256, num_blocks=7, g=48)      # 1536: a multiple of 64 and of 48 (the level-0 tiles)
 sd = synthetic_state_dict(cfg, seed=1, calib_frames=32)
 net = TDFNet(cfg, sd, ctx=ctx, dtype=torch.bfloat16, max_batch=6)
 outs = []
@@ -34,7 +34,7 @@ def run_mode(mode, path, **extra):
     regw, pipe, big = mode
     # ALSEP_CONV_MQ=0 unless asked for: the default level-1 kernel sums in another order (not bit-identical with the kernels compared here)
     env = dict(os.environ, ALSEP_CONV_REGW=str(regw), ALSEP_CONV_PIPE=str(pipe), ALSEP_CONV_BIG=str(big))
-    env.update({"ALSEP_CONV_MQ": "0", **extra})
+    env.update({"ALSEP_CONV_MQ": "0", "ALSEP_CONV_M0": "0", **extra})
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}, path], env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]
     return np.load(path)
@@ -64,7 +64,7 @@ def test_dispatch_orders_and_prefetch_bit_identical(tmp_path):
     base = run_mode((1, 0, 1), str(tmp_path / "d0.npy"))
     assert np.isfinite(base).all() and np.abs(base).max() > 1e-3
     for extra in (dict(ALSEP_CONV_NYFAST="0"), dict(ALSEP_TDF_YFAST="0"), dict(ALSEP_CONV_BIG3="0"), dict(ALSEP_TDF_RPF="0"),
-                  dict(ALSEP_CONV_BIG_SWP="0"), dict(ALSEP_CONV_BIG_SWP="2"), dict(ALSEP_CONV_MNY="0"), dict(ALSEP_CONV_MNY="3"), dict(ALSEP_CONV_MQ="0"),   # rolled k-loop / software-pipelined also at NY = 3
+                  dict(ALSEP_CONV_BIG_SWP="0"), dict(ALSEP_CONV_BIG_SWP="2"), dict(ALSEP_CONV_MNY="0"), dict(ALSEP_CONV_MNY="3"), dict(ALSEP_CONV_MQ="0"), dict(ALSEP_CONV_M0="2"),   # rolled k-loop / software-pipelined also at NY = 3
                   dict(ALSEP_CONV_NYFAST="0", ALSEP_TDF_YFAST="0", ALSEP_CONV_BIG3="0", ALSEP_TDF_RPF="0")):
         got = run_mode((1, 0, 1), str(tmp_path / "d1.npy"), **extra)
         assert np.array_equal(base, got), f"{extra}: max diff {np.abs(base - got).max()}"

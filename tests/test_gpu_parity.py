@@ -211,14 +211,14 @@ def test_net_bf16_vs_torch_reference(ctx):
         assert rel < tol
 
 
-@pytest.mark.parametrize("g,kernel", [(96, "conv3x3_bf16_mq_kernel"), (144, "conv3x3_bf16_big_kernel<3>"),
-                                      (48, "conv3x3_bf16_regw_kernel")])
-def test_big_tile_conv_kernels_vs_oracle(ctx, g, kernel):
+@pytest.mark.parametrize("g,kernel,dim_f", [(96, "conv3x3_bf16_mq_kernel", 512), (144, "conv3x3_bf16_big_kernel<3>", 512),
+                                            (48, "conv3x3_bf16_regw_kernel", 512), (48, "conv3x3_bf16_m0_kernel", 768)])
+def test_big_tile_conv_kernels_vs_oracle(ctx, g, kernel, dim_f):
     """Per-kernel oracle check of the production 3x3 kernels at shapes that DISPATCH them (not variant-vs-variant): a
     one-block network (first 1x1 conv, three c -> c 3x3 convs, TDF, final 1x1) with c = 96 / 144 / 48 channels, so
     every 3x3 launch is the double-buffered 8-wave kernel (c = 96), the big-tile kernel (NY = 3) resp. the persistent register-weight kernel -- asserted
     through alsep_launch_count -- against the torch fp32 oracle on the same bf16-rounded input."""
-    kw = dict(dim_f=512, dim_t=64, n_fft=1024, hop=256, num_blocks=1, g=g)
+    kw = dict(dim_f=dim_f, dim_t=64, n_fft=2048, hop=256, num_blocks=1, g=g)     # 768 = 16 x 48: 2 x 8 x 16 = 256 level-0 tiles of 8 x 48
     ctx.launch_counts_reset()
     got, want, *_ = _net_case(ctx, kw, torch.bfloat16, 2)      # one forward of B = 2: 128 8x64 tiles (>= 96: the big-tile dispatch rule)
     assert ctx.launch_count(kernel) == 3, {k: ctx.launch_count(k) for k in (kernel, "conv3x3_bf16_kernel<64>")}
@@ -291,13 +291,13 @@ def test_full_size_mdx_bf16_vs_oracle(ctx):
     args = types.SimpleNamespace(margin=44100, chunks=0, denoise=False, dim_f=cfg.dim_f, dim_t=8, n_fft=cfg.n_fft)
     ctx.launch_counts_reset()
     got = Predictor(args, net, ctx=ctx).demix(torch.from_numpy(c["mix"]).cuda()).cpu().numpy()
-    counts = {k: ctx.launch_count(k) for k in ("stft_r16_kernel", "istft_r16_kernel", "conv3x3_bf16_regw_kernel",
+    counts = {k: ctx.launch_count(k) for k in ("stft_r16_kernel", "istft_r16_kernel", "conv3x3_bf16_m0_kernel",
                                                "conv3x3_bf16_mq_kernel", "conv3x3_bf16_big_kernel<3>", "conv3x3_bf16_kernel<64>",
                                                "tdf_bf16_wide_kernel<nores>", "tdf_bf16_wide_kernel<res>", "tdf_bf16_kernel",
                                                "ds_stream_kernel", "us_stream_kernel", "pix_gemm_kernel")}
     print("launches:", counts)
     assert counts["stft_r16_kernel"] == 1 and counts["istft_r16_kernel"] == 1
-    assert counts["conv3x3_bf16_regw_kernel"] == 6 and counts["conv3x3_bf16_mq_kernel"] == 6      # levels 0 / 1: 2 blocks x 3
+    assert counts["conv3x3_bf16_m0_kernel"] == 6 and counts["conv3x3_bf16_mq_kernel"] == 6      # levels 0 / 1: 2 blocks x 3
     assert counts["conv3x3_bf16_big_kernel<3>"] == 6 and counts["conv3x3_bf16_kernel<64>"] >= 6       # level 2; levels 3, 4
     assert counts["tdf_bf16_wide_kernel<nores>"] == 4 and counts["tdf_bf16_wide_kernel<res>"] == 4     # levels 0-1, both linears
     assert counts["ds_stream_kernel"] == 3 and counts["us_stream_kernel"] == 3                        # levels 0<->1<->2<->3
@@ -339,7 +339,7 @@ def test_full_size_mdx_f16_vs_oracle(ctx):
     args = types.SimpleNamespace(margin=44100, chunks=0, denoise=False, dim_f=cfg.dim_f, dim_t=8, n_fft=cfg.n_fft)
     ctx.launch_counts_reset()
     got = Predictor(args, net, ctx=ctx).demix(torch.from_numpy(c["mix"]).cuda()).cpu().numpy()
-    assert ctx.launch_count("conv3x3_bf16_mq_kernel") == 6 and ctx.launch_count("conv3x3_bf16_regw_kernel") == 6   # same kernels, f16 build
+    assert ctx.launch_count("conv3x3_bf16_mq_kernel") == 6 and ctx.launch_count("conv3x3_bf16_m0_kernel") == 6   # same kernels, f16 build
     assert np.isfinite(got).all()
 
     def model_run_f16(spek):
