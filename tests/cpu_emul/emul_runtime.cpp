@@ -9,8 +9,10 @@
 #include <hip/hip_runtime.h>
 
 #include <ucontext.h>
+#include <unistd.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <chrono>
 #include <mutex>
 #include <thread>
@@ -26,11 +28,42 @@
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 alignas(256) thread_local char alsep_smem[160 * 1024];
 
+#if !defined(EMUL_ASAN) && defined(__x86_64__)
+// Plain builds switch fibers with a hand-rolled callee-saved-register swap: glibc's swapcontext makes two rt_sigprocmask system calls
+// per switch, and a 512-thread workgroup switches ~10^5 times per barrier-heavy kernel (the CPU suite spent more time in the kernel than
+// in user code).  The AddressSanitizer build keeps ucontext (its fiber annotations are written against it).
+#define EMUL_FAST_SWITCH 1
+extern "C" void emul_swap(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl emul_swap
+.type emul_swap,@function
+emul_swap:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size emul_swap, .-emul_swap
+)");
+#endif
+
 namespace {
 constexpr size_t kStack = 256 * 1024;
 
 struct Fiber {
     ucontext_t ctx;
+    void* sp = nullptr;                                      // EMUL_FAST_SWITCH: saved stack pointer
     char* stack = nullptr;
     bool done = false;
     dim3 tidx;
@@ -39,8 +72,10 @@ struct Fiber {
 
 struct Worker {
     ucontext_t sched;
+    void* sched_sp = nullptr;
     std::vector<Fiber> fibers;
-    std::vector<char> stacks;
+    char* stacks = nullptr;                                  // nt * kStack bytes, NOT zero-filled (a vector<char> of 128 MB per worker and
+    size_t stacks_cap = 0;                                   // launch cost more than the kernels), kept by the pool's thread across launches
     const std::function<void()>* body = nullptr;
     int nt = 0, cur = 0, alive = 0;
     int block_arrived = 0;
@@ -62,7 +97,11 @@ void switch_to_sched(Worker& w, Fiber& f, bool dying) {
     __sanitizer_start_switch_fiber(dying ? nullptr : &f.fake, w.sched_bottom, w.sched_size);
 #endif
     (void)dying;
+#ifdef EMUL_FAST_SWITCH
+    emul_swap(&f.sp, w.sched_sp);
+#else
     swapcontext(&f.ctx, &w.sched);
+#endif
 #ifdef EMUL_ASAN
     __sanitizer_finish_switch_fiber(f.fake, &w.sched_bottom, &w.sched_size);
 #endif
@@ -100,11 +139,21 @@ void run_block(Worker& w) {
     for (int t = 0; t < nt; ++t) {
         Fiber& f = w.fibers[t];
         f.done = false;
+#ifdef EMUL_FAST_SWITCH
+        // initial frame for emul_swap: six callee-saved registers, then fiber_main as the return address; fiber_main must find
+        // rsp = 8 mod 16, as after a call
+        uintptr_t top = (((uintptr_t)f.stack + kStack) & ~(uintptr_t)15) - 8;
+        void** sp = reinterpret_cast<void**>(top) - 7;
+        for (int i = 0; i < 6; ++i) sp[i] = nullptr;
+        sp[6] = reinterpret_cast<void*>(&fiber_main);
+        f.sp = sp;
+#else
         getcontext(&f.ctx);
         f.ctx.uc_stack.ss_sp = f.stack;
         f.ctx.uc_stack.ss_size = kStack;
         f.ctx.uc_link = nullptr;
         makecontext(&f.ctx, (void (*)())fiber_main, 0);
+#endif
     }
     int remaining = nt;
     while (remaining > 0) {
@@ -117,7 +166,11 @@ void run_block(Worker& w) {
 #ifdef EMUL_ASAN
             __sanitizer_start_switch_fiber(&w.sched_fake, f.stack, kStack);
 #endif
+#ifdef EMUL_FAST_SWITCH
+            emul_swap(&w.sched_sp, f.sp);
+#else
             swapcontext(&w.sched, &f.ctx);
+#endif
 #ifdef EMUL_ASAN
             __sanitizer_finish_switch_fiber(w.sched_fake, nullptr, nullptr);
 #endif
@@ -131,6 +184,99 @@ void run_block(Worker& w) {
             std::abort();
         }
     }
+}
+}  // namespace
+
+namespace {
+// Persistent worker threads: one set per process (re-created after a fork), each keeps its fiber stacks across launches.
+struct Pool {
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::vector<std::thread> threads;
+    pid_t pid = 0;
+    unsigned long gen = 0;
+    int active = 0;
+    // the current job
+    dim3 grid, block;
+    int nt = 0;
+    size_t nblocks = 0;
+    const std::function<void()>* body = nullptr;
+    std::atomic<size_t> next{0};
+};
+Pool* g_pool = nullptr;
+std::mutex g_launch_mu;                                      // one launch at a time (streams are synchronous here)
+
+void pool_thread(Pool* P) {
+    Worker w;
+    unsigned long seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(P->mu);
+            P->cv_job.wait(lk, [&] { return P->gen != seen; });
+            seen = P->gen;
+        }
+        const int nt = P->nt;
+        const dim3 grid = P->grid, block = P->block;
+        w.nt = nt;
+        w.body = P->body;
+        w.fibers.resize(nt);
+        if ((size_t)nt * kStack > w.stacks_cap) {
+            std::free(w.stacks);
+            w.stacks_cap = (size_t)nt * kStack;
+            w.stacks = static_cast<char*>(std::malloc(w.stacks_cap));
+            if (!w.stacks) { std::fprintf(stderr, "emul: out of memory for fiber stacks\n"); std::abort(); }
+        }
+        const int nw = nt / 64;
+        w.wave_arrived.assign(nw, 0);
+        w.wave_alive.assign(nw, 64);
+        w.wave_gen.assign(nw, 0);
+        w.block_gen = 0;
+        w.slabs.assign((size_t)nw * 64 * 256, 0);
+        for (int t = 0; t < nt; ++t) {
+            w.fibers[t].stack = w.stacks + (size_t)t * kStack;
+            w.fibers[t].tidx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+        }
+        tw = &w;
+        blockDim = block;
+        gridDim = grid;
+        for (;;) {
+            const size_t b = P->next.fetch_add(1);
+            if (b >= P->nblocks) break;
+            blockIdx = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((size_t)grid.x * grid.y)));
+            run_block(w);
+        }
+        tw = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(P->mu);
+            if (--P->active == 0) P->cv_done.notify_all();
+        }
+    }
+}
+
+void pool_run(dim3 grid, dim3 block, int nt, size_t nblocks, const std::function<void()>& body) {
+    std::lock_guard<std::mutex> launch_lock(g_launch_mu);
+    if (!g_pool || g_pool->pid != getpid()) {                // first launch, or a forked child (the parent's threads do not exist here)
+        g_pool = new Pool();
+        g_pool->pid = getpid();
+        unsigned hw = std::thread::hardware_concurrency();
+        const unsigned n = hw ? hw : 4;
+        for (unsigned i = 0; i < n; ++i) {
+            g_pool->threads.emplace_back(pool_thread, g_pool);
+            g_pool->threads.back().detach();
+        }
+    }
+    Pool* P = g_pool;
+    std::unique_lock<std::mutex> lk(P->mu);
+    P->grid = grid;
+    P->block = block;
+    P->nt = nt;
+    P->nblocks = nblocks;
+    P->body = &body;
+    P->next.store(0);
+    P->active = (int)P->threads.size();
+    P->gen++;
+    P->cv_job.notify_all();
+    P->cv_done.wait(lk, [&] { return P->active == 0; });
 }
 }  // namespace
 
@@ -170,39 +316,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
     }
     const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
     if (nblocks == 0) return;
-    unsigned hw = std::thread::hardware_concurrency();
-    const size_t nworkers = std::min<size_t>(nblocks, hw ? hw : 4);
-    std::atomic<size_t> next{0};
-    auto work = [&]() {
-        Worker w;
-        w.nt = nt;
-        w.body = &body;
-        w.fibers.resize(nt);
-        w.stacks.resize((size_t)nt * kStack);
-        const int nw = nt / 64;
-        w.wave_arrived.assign(nw, 0);
-        w.wave_alive.assign(nw, 64);
-        w.wave_gen.assign(nw, 0);
-        w.slabs.assign((size_t)nw * 64 * 256, 0);
-        for (int t = 0; t < nt; ++t) {
-            w.fibers[t].stack = w.stacks.data() + (size_t)t * kStack;
-            w.fibers[t].tidx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-        }
-        tw = &w;
-        blockDim = block;
-        gridDim = grid;
-        for (;;) {
-            const size_t b = next.fetch_add(1);
-            if (b >= nblocks) break;
-            blockIdx = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y),
-                            (unsigned)(b / ((size_t)grid.x * grid.y)));
-            run_block(w);
-        }
-        tw = nullptr;
-    };
-    std::vector<std::thread> th;
-    for (size_t i = 0; i < nworkers; ++i) th.emplace_back(work);
-    for (auto& t : th) t.join();
+    pool_run(grid, block, nt, nblocks, body);
 }
 }  // namespace emul
 

@@ -96,7 +96,7 @@ def _worker_ola_demucs(rank, world, port, emul_so, out_path):
     cfg = TDFNetConfig(dim_f=64, dim_t=32, n_fft=256, hop=64, num_blocks=3, g=16)
     sd = synthetic_state_dict(cfg, seed=3)
     net = TDFNet(cfg, sd, ctx=ctx, dtype=torch.float32, max_batch=2)
-    mix = synth_mix(3000, seed=31)
+    mix = synth_mix(4000, seed=31)
     got = OlaRunner(net, ctx=ctx, overlap=0.75, compensate=1.02, max_batch=2, sharded=True).demix(torch.from_numpy(mix)).numpy()
     g = mo.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
 
@@ -108,7 +108,7 @@ def _worker_ola_demucs(rank, world, port, emul_so, out_path):
                              t_heads=4, segment_samples=2560, samplerate=4000)
     hsd = ho.synthetic_state_dict(ocfg, 5)
     hnet = HTDemucs(HTDemucsConfig(**dataclasses.asdict(ocfg)), hsd, ctx=ctx)
-    hm = torch.randn(2, 3500, generator=torch.Generator().manual_seed(8)) * 0.2      # two segments + the shift
+    hm = torch.randn(2, 5000, generator=torch.Generator().manual_seed(8)) * 0.2
     out = DemucsRunner(hnet, shifts=1, overlap=0.25, seed=0, sharded=True).separate(hm)
     hw = ho.separate(ocfg, hsd, hm, shifts=1, overlap=0.25, seed=0).numpy()
     errs.append(float(max(np.max(np.abs(out[k].numpy() - hw[i])) for i, k in enumerate(ocfg.sources))))

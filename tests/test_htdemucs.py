@@ -82,8 +82,8 @@ def test_odd_lengths_pad_the_time_branch(dev):
 @pytest.mark.parametrize("shifts,n", [(0, 7000), (2, 6001), (1, 1500)])
 def test_runner_vs_oracle(dev, shifts, n):
     from audiolab_amd.htdemucs import DemucsRunner
-    if dev.device.type == "cpu":
-        pytest.skip("runner cases run on the GPU; tests/test_dist_gloo.py runs a multi-segment, shifted one on the emulation")
+    if dev.device.type == "cpu" and shifts != 2:
+        pytest.skip("emulated suite keeps one runner case (the others run on the GPU)")
     ocfg = small_cfg()
     net, sd = build(dev, ocfg, seed=7)
     mix = torch.randn(2, n, generator=torch.Generator().manual_seed(11)) * 0.2 + 0.01
