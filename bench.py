@@ -187,7 +187,11 @@ def other_workload(args) -> None:
         seconds = args.seconds if args.seconds != TRACK_SECONDS else 180
         n = seconds * SR
         tracks = [torch.from_numpy(synth_mix(n, seed=1000 + rank * 100 + k)).to(device) for k in range(args.tracks)]
-        eng = Separator(ctx=ctx, dtype=torch.bfloat16, allow_synthetic=True, max_batch=args.batch)
+        from audiolab_amd.engine import MODEL_ROSTER
+        # configs[3] is "MDX+Demucs": the roster is cut to the MDX-Net files and htdemucs, so that the first two ensemble members the
+        # orchestrator finds are the reference's MDX-Net vocal models (with the full roster they are its two Roformers, fp32)
+        mdx_demucs = {k: v for k, v in MODEL_ROSTER.items() if k.endswith(".onnx") or v[0] == "demucs"}
+        eng = Separator(ctx=ctx, dtype=torch.bfloat16, allow_synthetic=True, max_batch=args.batch, roster=mdx_demucs)
         model = EnsembleDemucsMDXMusicSeparationModel({"ensemble_strength": 2, "vocals_only": False}, separator=eng)
         stems, audio_s, sr = 7, args.tracks * world * n / SR, SR
         desc = (f"{args.tracks} tracks x {seconds} s per GPU: 2 MDX-Net vocal models (n_fft 7680, bf16) blended + de-bleed, then "
