@@ -7,3 +7,7 @@ CXX="${ALSEP_HOST_CXX:-/opt/rocm/lib/llvm/bin/clang++}"
 RT="$($CXX -print-file-name=libclang_rt.asan-x86_64.so)"
 cd /tmp
 ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 LD_PRELOAD="$RT" python "$HERE/asan_cases.py"
+# the round-2 conv kernels at shapes where every class dispatches (about 4 minutes per mode)
+for m in mq mny big; do
+  ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 LD_PRELOAD="$RT" python "$HERE/asan_cases_conv.py" $m
+done
