@@ -101,6 +101,151 @@ nn_bgemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float*
     }
 }
 
+// The same product for the common layout -- A [M][K] and B [N][K] both K-contiguous (activations x Linear weights, Q K^T), K % 16 == 0,
+// rows 16-byte aligned -- as an LDS-tiled kernel: a workgroup computes 128 x 128 of C, four waves as 2 x 2 (64 x 64 each: 16
+// accumulator blocks), K in slices of 16 staged through LDS as the rows lie (global float4 -> ds_write_b128; rows padded to 24 floats:
+// the ds_read_b128 of 16 rows x {lq, lq + 1} is conflict-free, scripts/lds_bank_sim.py), the next slice's global loads in flight during
+// the 64 MFMAs of the current one.  A lane reads ONE float4 per operand row and slice and feeds element s of it to MFMA step s, i.e. the
+// four k of a v_mfma_f32_16x16x4_f32 are {s, 4 + s, 8 + s, 12 + s} of the slice instead of four consecutive ones: the same products in
+// another fp32 summation order than nn_bgemm_kernel (both are valid orders of the reference's sum; the oracles' tolerances hold for both).
+// CT: C is row-major with N contiguous -- the operands swap MFMA roles so that a lane owns four consecutive columns (float4 stores).
+constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 16, kGemmLD = 24;
+template <bool CT>
+__global__ void __launch_bounds__(kNnThreads)
+nn_gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int nb2, int M, int N, int K,
+                  GemmStrides sa, GemmStrides sb, GemmStrides sc, float alpha, const float* __restrict__ bias, int act) {
+    float* As = reinterpret_cast<float*>(alsep_smem);                       // [2][128][24]
+    float* Bs = As + 2 * kGemmBM * kGemmLD;                                  // [2][128][24]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b1 = blockIdx.z / nb2, b2 = blockIdx.z % nb2;
+    const float* a = A + b1 * sa.b1 + b2 * sa.b2;
+    const float* b = B + b1 * sb.b1 + b2 * sb.b2;
+    float* c = C + b1 * sc.b1 + b2 * sc.b2;
+    const int m0 = blockIdx.y * kGemmBM, n0 = blockIdx.x * kGemmBN;
+    // staging duty: two float4 per operand and slice: rows (tid >> 2) and (tid >> 2) + 64, k-quad tid & 3
+    const int sr = tid >> 2, sq = tid & 3;
+    const float* ga[2];
+    const float* gb[2];
+    bool va[2], vb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int ra = m0 + sr + 64 * h, rb = n0 + sr + 64 * h;
+        va[h] = ra < M;
+        vb[h] = rb < N;
+        ga[h] = a + (int64_t)(va[h] ? ra : 0) * sa.r + 4 * sq;
+        gb[h] = b + (int64_t)(vb[h] ? rb : 0) * sb.r + 4 * sq;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 ra_[2], rb_[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            ra_[h] = va[h] ? *reinterpret_cast<const f32x4*>(ga[h] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rb_[h] = vb[h] ? *reinterpret_cast<const f32x4*>(gb[h] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<f32x4*>(As + ((size_t)buf * kGemmBM + sr + 64 * h) * kGemmLD + 4 * sq) = ra_[h];
+            *reinterpret_cast<f32x4*>(Bs + ((size_t)buf * kGemmBN + sr + 64 * h) * kGemmLD + 4 * sq) = rb_[h];
+        }
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int nk = K / kGemmBK;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * kGemmBK);
+        f32x4 af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i] = *reinterpret_cast<const f32x4*>(As + ((size_t)buf * kGemmBM + wm * 64 + i * 16 + l15) * kGemmLD + 4 * lq);
+            bf[i] = *reinterpret_cast<const f32x4*>(Bs + ((size_t)buf * kGemmBN + wn * 64 + i * 16 + l15) * kGemmLD + 4 * lq);
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (CT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][s4], af[i][s4], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s4], bf[j][s4], acc[i][j], 0, 0, 0);
+                }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue.  CT: D rows = n (4 lq + r), D columns = m (l15): C[m][n .. n + 3] is one float4
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (CT) {
+                const int row = m0 + wm * 64 + i * 16 + l15, col = n0 + wn * 64 + j * 16 + 4 * lq;
+                if (row < M && col < N) {                        // N % 4 == 0 on this path: the four columns are all inside
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t = alpha * acc[i][j][r];
+                        if (bias) t += bias[col + r];
+                        if (act == 3) t = gelu_erf(t);
+                        else if (act == 5) t = tanhf(t);
+                        v[r] = t;
+                    }
+                    *reinterpret_cast<f32x4*>(c + (int64_t)row * sc.r + col) = v;
+                }
+            } else {
+                const int col = n0 + wn * 64 + j * 16 + l15;
+                if (col < N) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = m0 + wm * 64 + i * 16 + 4 * lq + r;
+                        if (row < M) {
+                            float t = alpha * acc[i][j][r];
+                            if (bias) t += bias[col];
+                            if (act == 3) t = gelu_erf(t);
+                            else if (act == 5) t = tanhf(t);
+                            c[(int64_t)row * sc.r + (int64_t)col * sc.k] = t;
+                        }
+                    }
+                }
+            }
+        }
+}
+
+static bool gemm_tn_ok(const float* A, const float* B, int M, int N, int K, const GemmStrides& a, const GemmStrides& b) {
+    static const int on = [] { const char* e = getenv("ALSEP_NN_GEMM_TN"); return e ? atoi(e) : 1; }();
+    return on && a.k == 1 && b.k == 1 && K % kGemmBK == 0 && a.r % 4 == 0 && b.r % 4 == 0 && a.b1 % 4 == 0 && a.b2 % 4 == 0 && b.b1 % 4 == 0 &&
+           b.b2 % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (int64_t)M * N >= 64 * 64;
+}
+static bool gemm_ct_ok(const float* C, int N, const GemmStrides& c) {
+    return c.k == 1 && c.r % 4 == 0 && c.b1 % 4 == 0 && c.b2 % 4 == 0 && N % 4 == 0 && ((uintptr_t)C & 15) == 0;
+}
+static int launch_gemm(alsep_ctx* ctx, const float* A, const float* B, float* C, int nb, int nb2, int M, int N, int K, GemmStrides a,
+                       GemmStrides b, GemmStrides c, float alpha, const float* bias, int act) {
+    if (gemm_tn_ok(A, B, M, N, K, a, b)) {
+        const dim3 grid((unsigned)ceil_div64(N, kGemmBN), (unsigned)ceil_div64(M, kGemmBM), (unsigned)nb);
+        const size_t lds = 2 * (size_t)(kGemmBM + kGemmBN) * kGemmLD * sizeof(float);
+        if (gemm_ct_ok(C, N, c))
+            hipLaunchKernelGGL(nn_gemm_tn_kernel<true>, grid, dim3(kNnThreads), lds, ctx->stream, A, B, C, nb2, M, N, K, a, b, c, alpha, bias, act);
+        else
+            hipLaunchKernelGGL(nn_gemm_tn_kernel<false>, grid, dim3(kNnThreads), lds, ctx->stream, A, B, C, nb2, M, N, K, a, b, c, alpha, bias, act);
+        ALSEP_LAUNCH_CHECK(ctx, "nn_gemm_tn_kernel");
+        return ALSEP_OK;
+    }
+    hipLaunchKernelGGL(nn_bgemm_kernel, dim3((unsigned)ceil_div64(N, 128), (unsigned)ceil_div64(M, 64), (unsigned)nb), dim3(kNnThreads), 0,
+                       ctx->stream, A, B, C, nb2, M, N, K, a, b, c, alpha, bias, act);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_bgemm_kernel");
+    return ALSEP_OK;
+}
+
 // softmax over the last dimension, in place; one workgroup per row
 __global__ void __launch_bounds__(kNnThreads)
 nn_softmax_rows_kernel(float* __restrict__ x, int n) {
@@ -574,10 +719,7 @@ extern "C" int alsep_nn_bgemm(alsep_ctx* ctx, const float* A, const float* B, fl
     NN_ARG(ctx && A && B && C && sa && sb && sc && nb1 > 0 && nb2 > 0 && M > 0 && N > 0 && K > 0 && (int64_t)nb1 * nb2 <= 65535,
            "alsep_nn_bgemm");
     GemmStrides a{sa[0], sa[1], sa[2], sa[3]}, b{sb[0], sb[1], sb[2], sb[3]}, c{sc[0], sc[1], sc[2], sc[3]};
-    hipLaunchKernelGGL(nn_bgemm_kernel, dim3((unsigned)ceil_div64(N, 128), (unsigned)ceil_div64(M, 64), (unsigned)(nb1 * nb2)),
-                       dim3(kNnThreads), 0, ctx->stream, A, B, C, nb2, M, N, K, a, b, c, alpha, (const float*)nullptr, 0);
-    ALSEP_LAUNCH_CHECK(ctx, "nn_bgemm_kernel");
-    return ALSEP_OK;
+    return launch_gemm(ctx, A, B, C, nb1 * nb2, nb2, M, N, K, a, b, c, alpha, nullptr, 0);
 }
 
 extern "C" int alsep_nn_bgemm_bias(alsep_ctx* ctx, const float* A, const float* B, float* C, int nb1, int nb2, int M, int N, int K,
@@ -587,10 +729,7 @@ extern "C" int alsep_nn_bgemm_bias(alsep_ctx* ctx, const float* A, const float* 
                (act == 0 || act == 3 || act == 5),
            "alsep_nn_bgemm_bias");
     GemmStrides a{sa[0], sa[1], sa[2], sa[3]}, b{sb[0], sb[1], sb[2], sb[3]}, c{sc[0], sc[1], sc[2], sc[3]};
-    hipLaunchKernelGGL(nn_bgemm_kernel, dim3((unsigned)ceil_div64(N, 128), (unsigned)ceil_div64(M, 64), (unsigned)(nb1 * nb2)),
-                       dim3(kNnThreads), 0, ctx->stream, A, B, C, nb2, M, N, K, a, b, c, alpha, bias, act);
-    ALSEP_LAUNCH_CHECK(ctx, "nn_bgemm_kernel");
-    return ALSEP_OK;
+    return launch_gemm(ctx, A, B, C, nb1 * nb2, nb2, M, N, K, a, b, c, alpha, bias, act);
 }
 
 extern "C" int alsep_nn_softmax_rows(alsep_ctx* ctx, float* x, int64_t rows, int n) {

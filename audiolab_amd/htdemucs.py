@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -102,6 +103,17 @@ class HTDemucs:
         self._ws: Optional[torch.Tensor] = None
         self.dtype = torch.float32
         _ = dev
+
+    def on_stream(self, ctx: Context) -> "HTDemucs":
+        """A view of this network that launches on another context (= another HIP stream of the same device): the weights are shared
+        (read-only device tensors), the per-call caches (FFT plans, workspace, position tables) are the view's own."""
+        import copy
+        if ctx.device != self.ctx.device:
+            raise AlsepError("HTDemucs.on_stream: the other context must be on the same device")
+        v = copy.copy(self)
+        v.ctx = ctx
+        v._plans, v._pos, v._ws = {}, {}, None
+        return v
 
     # -- parameters ---------------------------------------------------------------------------------------
     def _vec(self, t: torch.Tensor) -> torch.Tensor:
@@ -437,10 +449,26 @@ class DemucsRunner:
     """``demucs.apply.apply_model(model, mix, shifts, split=True, overlap)`` inside DemucsSeparator's whole-track normalisation
     (audio_separator defaults: shifts 2, overlap 0.25, segments of the model's training length), on the device."""
 
-    def __init__(self, net: HTDemucs, shifts: int = 2, overlap: float = 0.25, seed: int = 0, sharded: bool = False, group=None):
+    def __init__(self, net: HTDemucs, shifts: int = 2, overlap: float = 0.25, seed: int = 0, sharded: bool = False, group=None,
+                 lanes: Optional[int] = None):
+        """``lanes``: (shift, segment) units in flight at once, each on a HIP stream of its own (default: 3 on a GPU, 1 elsewhere).  One
+        segment of htdemucs_6s is ~450 launches of mostly small kernels (grids of 42-170 workgroups on 256 CUs): units are independent,
+        so running a few side by side fills the chip; the weighted sums are kept per lane and added at the end."""
         self.net, self.ctx = net, net.ctx
         self.shifts, self.overlap, self.seed = shifts, overlap, seed
         self.sharded, self.group = sharded, group
+        if lanes is None:
+            lanes = int(os.environ.get("ALSEP_DEMUCS_LANES", "3")) if self.ctx.device.type == "cuda" else 1
+        self.lanes = max(1, int(lanes)) if self.ctx.device.type == "cuda" else 1
+        self._lane_nets: List[tuple] = []                      # [(HTDemucs view, torch stream)], built on first use
+
+    def _lanes(self):
+        if not self._lane_nets:
+            self._lane_nets = [(self.net, None)]
+            for _ in range(1, self.lanes):
+                st = torch.cuda.Stream(device=self.ctx.device)
+                self._lane_nets.append((self.net.on_stream(Context(self.ctx.device, stream=st.cuda_stream)), st))
+        return self._lane_nets
 
     def units(self, length: int):
         """[(root offset of the view, view length, chunk offset in the view, chunk length, out offset)] over all shifts"""
@@ -481,20 +509,41 @@ class DemucsRunner:
         if self.sharded:
             import torch.distributed as tdist
             rank, world = tdist.get_rank(self.group), tdist.get_world_size(self.group)
-        acc = [ctx.zeros((S * 2, L + max_shift)) for _ in range(n_pass)]           # one weighted sum per shift pass (view coordinates)
         from . import dist as adist
         lo, hi = adist.window_range(len(units), world, rank)
-        for (p, offset, view_len, off, cl) in units[lo:hi]:
+        lanes = self._lanes()[: max(1, min(self.lanes, hi - lo))]
+        # one weighted sum per (lane, shift pass), view coordinates; lane 0 runs on this context's stream, the others on their own
+        accs = [[ctx.zeros((S * 2, L + max_shift)) for _ in range(n_pass)] for _ in lanes]
+        main = torch.cuda.current_stream(ctx.device) if len(lanes) > 1 else None
+        for _, st in lanes[1:]:
+            st.wait_stream(main)                                 # root, weight and the zeroed sums are ready
+
+        def run_unit(lane_net, lane_acc, unit):
+            p, offset, view_len, off, cl = unit
+            lctx = lane_net.ctx
             delta = seg - cl
             start = offset + off - delta // 2
             end = start + seg
             cs, ce = max(0, start), min(total, end)
-            chunk = ctx.zeros((2, seg))
+            chunk = lctx.zeros((2, seg))
             chunk[:, cs - start: cs - start + (ce - cs)] = root[:, cs:ce]
-            y = net.forward(chunk)                                                   # [S, 2, seg]
+            y = lane_net.forward(chunk)                                              # [S, 2, seg]
             src = C.c_void_p(y.data_ptr() + 4 * (delta // 2))
-            dst = C.c_void_p(acc[p].data_ptr() + 4 * off)
-            ctx.check(lib.alsep_nn_vec_fma(h, dst, src, _lib.ptr(weight), S * 2, cl, L + max_shift, seg), "alsep_nn_vec_fma")
+            dst = C.c_void_p(lane_acc[p].data_ptr() + 4 * off)
+            lctx.check(lctx.lib.alsep_nn_vec_fma(lctx.handle, dst, src, _lib.ptr(weight), S * 2, cl, L + max_shift, seg), "alsep_nn_vec_fma")
+
+        for i, unit in enumerate(units[lo:hi]):
+            lane_net, st = lanes[i % len(lanes)]
+            if st is None:
+                run_unit(lane_net, accs[0], unit)
+            else:
+                with torch.cuda.stream(st):                      # torch's allocator ties the lane's temporaries to its stream
+                    run_unit(lane_net, accs[i % len(lanes)], unit)
+        acc = accs[0]
+        for k, (_, st) in enumerate(lanes[1:], start=1):
+            main.wait_stream(st)
+            for p in range(n_pass):
+                ctx.check(lib.alsep_axpby(h, 1.0, _lib.ptr(accs[k][p]), 1.0, _lib.ptr(acc[p]), acc[p].numel()), "alsep_axpby")
         if self.sharded and world > 1:
             acc = [adist.all_reduce_partial(a, self.group) for a in acc]
         # per pass: divide by the summed weights of that pass, cut the view back to the track, average the passes

@@ -267,15 +267,44 @@ class Roformer:
     __call__ = forward
 
 
+def view_on_stream(net, ctx: Context):
+    """A view of a network object that launches on another context (= another HIP stream of the same device): shared read-only
+    weights, its own per-call caches (every ``_plans`` / ``_ws`` / ``_pos`` attribute is reset)."""
+    import copy
+    if ctx.device != net.ctx.device:
+        raise AlsepError("view_on_stream: the other context must be on the same device")
+    v = copy.copy(net)
+    v.ctx = ctx
+    for name, fresh in (("_plans", {}), ("_pos", {}), ("_ws", None)):
+        if hasattr(v, name):
+            setattr(v, name, fresh)
+    return v
+
+
 class RoformerRunner:
     """chunked inference (``demix_track`` of the training project the checkpoints come from): mix [2, L] -> {label: [2, L]}"""
 
-    def __init__(self, net, labels: Tuple[str, ...]):
+    def __init__(self, net, labels: Tuple[str, ...], lanes: Optional[int] = None):
         """``net``: a Roformer, or any network of the same training project with ``cfg.chunk_size / num_overlap / num_stems`` and
-        ``forward([2, chunk]) -> [num_stems, 2, chunk]`` (MDX23C)"""
+        ``forward([2, chunk]) -> [num_stems, 2, chunk]`` (MDX23C).  ``lanes``: chunks in flight at once, each on a HIP stream of its
+        own (default ``ALSEP_RUNNER_LANES`` or 2 on a GPU, 1 elsewhere); per-lane weighted sums are added at the end."""
         self.net, self.ctx, self.labels = net, net.ctx, labels
         if len(labels) != net.cfg.num_stems:
             raise AlsepError("one label per stem")
+        import os
+        gpu = self.ctx.device.type == "cuda"
+        if lanes is None:
+            lanes = int(os.environ.get("ALSEP_RUNNER_LANES", "2")) if gpu else 1
+        self.lanes = max(1, int(lanes)) if gpu else 1
+        self._lane_nets: List[tuple] = []
+
+    def _lanes(self):
+        if not self._lane_nets:
+            self._lane_nets = [(self.net, None)]
+            for _ in range(1, self.lanes):
+                st = torch.cuda.Stream(device=self.ctx.device)
+                self._lane_nets.append((view_on_stream(self.net, Context(self.ctx.device, stream=st.cuda_stream)), st))
+        return self._lane_nets
 
     def demix(self, mix: torch.Tensor) -> torch.Tensor:
         ctx, net = self.ctx, self.net
@@ -301,25 +330,45 @@ class RoformerRunner:
         w_mid[:fade] *= fin
         wins = [w.to(ctx.device) for w in (w_start, w_mid, w_fin)]
         S = cfg.num_stems
-        result = ctx.zeros((S * 2, total))
+        starts = list(range(0, total, step))
+        lanes = self._lanes()[: max(1, min(self.lanes, len(starts)))]
+        results = [ctx.zeros((S * 2, total)) for _ in lanes]     # one weighted sum per lane (lane 0: this context's stream)
         counter = torch.zeros(total)
-        for i in range(0, total, step):
+        main = torch.cuda.current_stream(ctx.device) if len(lanes) > 1 else None
+        for _, st in lanes[1:]:
+            st.wait_stream(main)
+
+        def run_chunk(lane_net, res, i):
+            lctx = lane_net.ctx
             length = min(Cn, total - i)
             part = mix[:, i:i + length]
             if length < Cn:
-                chunk = ctx.zeros((2, Cn))
+                chunk = lctx.zeros((2, Cn))
                 if length > Cn // 2 + 1:                                   # F.pad(mode="reflect") on the right
                     piece = part.contiguous()
-                    ctx.check(lib.alsep_nn_reflect_pad(h, _lib.ptr(piece), _lib.ptr(chunk), 2, length, 0, Cn - length), "alsep_nn_reflect_pad")
+                    lctx.check(lctx.lib.alsep_nn_reflect_pad(lctx.handle, _lib.ptr(piece), _lib.ptr(chunk), 2, length, 0, Cn - length),
+                               "alsep_nn_reflect_pad")
                 else:
                     chunk[:, :length] = part
             else:
                 chunk = part.contiguous()
-            y = net.forward(chunk)                                           # [S, 2, Cn]
+            y = lane_net.forward(chunk)                                      # [S, 2, Cn]
             k = 0 if i == 0 else (2 if i + step >= total else 1)
-            ctx.check(lib.alsep_nn_vec_fma(h, C.c_void_p(result.data_ptr() + 4 * i), _lib.ptr(y), _lib.ptr(wins[k]), S * 2, length, total, Cn),
-                      "alsep_nn_vec_fma")
+            lctx.check(lctx.lib.alsep_nn_vec_fma(lctx.handle, C.c_void_p(res.data_ptr() + 4 * i), _lib.ptr(y), _lib.ptr(wins[k]), S * 2,
+                                                 length, total, Cn), "alsep_nn_vec_fma")
             counter[i:i + length] += (w_start, w_mid, w_fin)[k][:length]
+
+        for n, i in enumerate(starts):
+            lane_net, st = lanes[n % len(lanes)]
+            if st is None:
+                run_chunk(lane_net, results[0], i)
+            else:
+                with torch.cuda.stream(st):
+                    run_chunk(lane_net, results[n % len(lanes)], i)
+        result = results[0]
+        for k, (_, st) in enumerate(lanes[1:], start=1):
+            main.wait_stream(st)
+            ctx.check(lib.alsep_axpby(h, 1.0, _lib.ptr(results[k]), 1.0, _lib.ptr(result), result.numel()), "alsep_axpby")
         cnt = counter.to(ctx.device)
         ctx.check(lib.alsep_nn_vec_div(h, _lib.ptr(result), _lib.ptr(cnt), S * 2, total), "alsep_nn_vec_div")
         out = result.view(S, 2, total)
