@@ -451,14 +451,14 @@ class DemucsRunner:
 
     def __init__(self, net: HTDemucs, shifts: int = 2, overlap: float = 0.25, seed: int = 0, sharded: bool = False, group=None,
                  lanes: Optional[int] = None):
-        """``lanes``: (shift, segment) units in flight at once, each on a HIP stream of its own (default: 3 on a GPU, 1 elsewhere).  One
+        """``lanes``: (shift, segment) units in flight at once, each on a HIP stream of its own (default: 4 on a GPU, 1 elsewhere).  One
         segment of htdemucs_6s is ~450 launches of mostly small kernels (grids of 42-170 workgroups on 256 CUs): units are independent,
         so running a few side by side fills the chip; the weighted sums are kept per lane and added at the end."""
         self.net, self.ctx = net, net.ctx
         self.shifts, self.overlap, self.seed = shifts, overlap, seed
         self.sharded, self.group = sharded, group
         if lanes is None:
-            lanes = int(os.environ.get("ALSEP_DEMUCS_LANES", "3")) if self.ctx.device.type == "cuda" else 1
+            lanes = int(os.environ.get("ALSEP_DEMUCS_LANES", "4")) if self.ctx.device.type == "cuda" else 1
         self.lanes = max(1, int(lanes)) if self.ctx.device.type == "cuda" else 1
         self._lane_nets: List[tuple] = []                      # [(HTDemucs view, torch stream)], built on first use
 

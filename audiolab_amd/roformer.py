@@ -287,14 +287,14 @@ class RoformerRunner:
     def __init__(self, net, labels: Tuple[str, ...], lanes: Optional[int] = None):
         """``net``: a Roformer, or any network of the same training project with ``cfg.chunk_size / num_overlap / num_stems`` and
         ``forward([2, chunk]) -> [num_stems, 2, chunk]`` (MDX23C).  ``lanes``: chunks in flight at once, each on a HIP stream of its
-        own (default ``ALSEP_RUNNER_LANES`` or 2 on a GPU, 1 elsewhere); per-lane weighted sums are added at the end."""
+        own (default ``ALSEP_RUNNER_LANES`` or 4 on a GPU, 1 elsewhere); per-lane weighted sums are added at the end."""
         self.net, self.ctx, self.labels = net, net.ctx, labels
         if len(labels) != net.cfg.num_stems:
             raise AlsepError("one label per stem")
         import os
         gpu = self.ctx.device.type == "cuda"
         if lanes is None:
-            lanes = int(os.environ.get("ALSEP_RUNNER_LANES", "2")) if gpu else 1
+            lanes = int(os.environ.get("ALSEP_RUNNER_LANES", "4")) if gpu else 1
         self.lanes = max(1, int(lanes)) if gpu else 1
         self._lane_nets: List[tuple] = []
 
