@@ -568,6 +568,33 @@ nn_chan_stats_partial_kernel(const float* __restrict__ x, int64_t P, int C, int 
     part[((int64_t)blockIdx.y * C + c) * 2] = s;
     part[((int64_t)blockIdx.y * C + c) * 2 + 1] = q;
 }
+// the same for C <= 256 with 256 % C == 0: the workgroup's 256 threads cover 256 / C pixels at a time (thread = (pixel group, channel):
+// still one contiguous run of channels per pixel) instead of leaving 256 - C threads idle behind a C-thread serial loop; the pixel
+// groups' fp64 partials meet in LDS in a fixed order
+__global__ void __launch_bounds__(kNnThreads)
+nn_chan_stats_partial_small_kernel(const float* __restrict__ x, int64_t P, int C, int nb, double* __restrict__ part) {
+    double* red = reinterpret_cast<double*>(alsep_smem);      // [256][2]
+    const int c = threadIdx.x % C, g = threadIdx.x / C, G = kNnThreads / C;
+    const int64_t chunk = (P + nb - 1) / nb;
+    const int64_t lo = (int64_t)blockIdx.y * chunk, hi = lo + chunk < P ? lo + chunk : P;
+    double s = 0.0, q = 0.0;
+    for (int64_t p = lo + g; p < hi; p += G) {
+        const double v = (double)x[p * C + c];
+        s += v;
+        q += v * v;
+    }
+    red[2 * threadIdx.x] = s;
+    red[2 * threadIdx.x + 1] = q;
+    __syncthreads();
+    if (g == 0) {
+        for (int k = 1; k < G; ++k) {
+            s += red[2 * (k * C + c)];
+            q += red[2 * (k * C + c) + 1];
+        }
+        part[((int64_t)blockIdx.y * C + c) * 2] = s;
+        part[((int64_t)blockIdx.y * C + c) * 2 + 1] = q;
+    }
+}
 __global__ void nn_chan_stats_final_kernel(const double* __restrict__ part, int nb, int64_t P, int C, float eps, float* __restrict__ stats) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -975,8 +1002,12 @@ extern "C" int alsep_nn_instnorm(alsep_ctx* ctx, const float* x, float* y, const
     if (nb > 256) nb = 256;
     double* part = reinterpret_cast<double*>(workspace);
     float* stats = reinterpret_cast<float*>(part + 2 * (int64_t)C * nb);
-    hipLaunchKernelGGL(nn_chan_stats_partial_kernel, dim3((unsigned)ceil_div64(C, kNnThreads), (unsigned)nb), dim3(kNnThreads), 0, ctx->stream, x, P,
-                       C, (int)nb, part);
+    if (C < kNnThreads && kNnThreads % C == 0)
+        hipLaunchKernelGGL(nn_chan_stats_partial_small_kernel, dim3(1, (unsigned)nb), dim3(kNnThreads), 2 * kNnThreads * sizeof(double), ctx->stream,
+                           x, P, C, (int)nb, part);
+    else
+        hipLaunchKernelGGL(nn_chan_stats_partial_kernel, dim3((unsigned)ceil_div64(C, kNnThreads), (unsigned)nb), dim3(kNnThreads), 0, ctx->stream, x,
+                           P, C, (int)nb, part);
     hipLaunchKernelGGL(nn_chan_stats_final_kernel, dim3((unsigned)ceil_div64(C, 64)), dim3(64), 0, ctx->stream, (const double*)part, (int)nb, P, C,
                        eps, stats);
     hipLaunchKernelGGL(nn_chan_norm_apply_kernel, dim3(ew_grid(P * C)), dim3(kNnThreads), 0, ctx->stream, x, y, gamma, beta, (const float*)stats,

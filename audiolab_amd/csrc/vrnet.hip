@@ -100,31 +100,36 @@ vr_conv2d_kernel(const float* __restrict__ x, const float* __restrict__ w, const
 // The same convolution as an LDS-tiled implicit GEMM for Cin % 16 == 0 (every layer but the networks' first ones): M = output pixels,
 // N = output channels, K = (tap, ci) -- a K-slice of 16 is sixteen consecutive input channels of one tap, i.e. 64 contiguous bytes per
 // pixel.  A workgroup computes 128 pixels x 128 channels, four waves as 2 x 2 (64 x 64 each: 16 accumulator blocks); per slice the
-// activation rows go global float4 -> LDS [pixel][16 + 8 pad] (conflict-free ds_read_b128) and the weights [16 k][128 co + 16 pad]
-// (ds_read_b32 per k: 16 consecutive channels x two k rows fall on disjoint banks); the next slice's global loads are in flight during
+// activation rows go global float4 -> LDS [pixel][16 + 8 pad] (conflict-free ds_read_b128) and the weights [16 k][co + 4 pad]
+// (ds_read_b32 per k: 16 consecutive channels x two k rows, four apart, fall on disjoint banks); the next slice's global loads are in flight during
 // the 64 MFMAs of the current one.  The weights are the MFMA's row operand, so a lane ends up with four consecutive output channels
 // of one pixel: float4 epilogue stores into the channel slice.  As nn_gemm_tn_kernel, the four k of one v_mfma_f32_16x16x4_f32 are
 // {s, 4 + s, 8 + s, 12 + s} of the slice: another fp32 summation order than vr_conv2d_kernel's (the oracles' tolerances hold for both).
-constexpr int kCvBM = 128, kCvBN = 128, kCvBK = 16, kCvLDA = 24, kCvLDB = 144;
+constexpr int kCvBK = 16, kCvLDA = 24;
+// WB: 16-row blocks per wave along pixels and along channels (4: the 128 x 128 tile; 2: a 64 x 64 tile for layers whose 128 x 128 grid
+// would leave most CUs idle -- the deep levels of the U-Nets: a few hundred pixels x many channels, a long K loop on a dozen workgroups)
+template <int WB>
 __global__ void __launch_bounds__(kVrThreads)
 nn_conv2d_tiled_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
                        const float* __restrict__ shift, float* __restrict__ y, int64_t npix, int H, int W, int Cin, int Cout, int Ho, int Wo,
                        int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int act, int y_ct, int y_c0,
                        int vec_store) {
-    float* As = reinterpret_cast<float*>(alsep_smem);                       // [2][128][24]
-    float* Bs = As + 2 * kCvBM * kCvLDA;                                     // [2][16][144]
+    constexpr int BM = 32 * WB, BN = 32 * WB, LDB = BN + 4;                // lanes lq, lq + 1 read k rows 4 apart: 4 LDB = 16 mod 32 banks
+    constexpr int NA = BM * 4 / kVrThreads, NBQ = kCvBK * (BN / 4) / kVrThreads;      // float4 per thread and slice: 2 / 1
+    float* As = reinterpret_cast<float*>(alsep_smem);                       // [2][BM][24]
+    float* Bs = As + 2 * BM * kCvLDA;                                        // [2][16][LDB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-    const int64_t m0 = (int64_t)blockIdx.y * kCvBM;
-    const int n0 = blockIdx.x * kCvBN;
-    // staging duty.  A: pixels (tid >> 2) and + 64, channel quad tid & 3 of the slice; B: k rows (tid >> 5) and + 8, channel quad tid & 31
+    const int64_t m0 = (int64_t)blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    // staging duty.  A: pixels (tid >> 2) (+ 64), channel quad tid & 3 of the slice; B: k rows tid / (BN / 4) (+ 8), channel quad tid % (BN / 4)
     const int sr = tid >> 2, sq = tid & 3;
-    const float* xb[2];
-    int oy[2], ox[2];
-    bool pv[2];
+    const float* xb[NA];
+    int oy[NA], ox[NA];
+    bool pv[NA];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NA; ++h) {
         const int64_t p = m0 + sr + 64 * h;
         pv[h] = p < npix;
         const int64_t pp = pv[h] ? p : 0;
@@ -132,32 +137,34 @@ nn_conv2d_tiled_kernel(const float* __restrict__ x, const float* __restrict__ w,
         oy[h] = (int)((pp / Wo) % Ho) * stride_h - pad_h;
         xb[h] = x + (pp / ((int64_t)Wo * Ho)) * (int64_t)H * W * Cin + 4 * sq;
     }
-    const int bk = tid >> 5, bq = tid & 31;
+    constexpr int QN = BN / 4;
+    const int bk = tid / QN, bq = tid % QN;
     const bool bv = n0 + 4 * bq < Cout;                                      // Cout % 4 == 0 on this path
     const float* wb = w + n0 + 4 * bq;
-    f32x4 acc[4][4];
+    f32x4 acc[WB][WB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WB; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 ra[2], rb[2];
+        for (int j = 0; j < WB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[NA], rb[NBQ];
     auto gload = [&](int k0) {
         const int tap = k0 / Cin, ci0 = k0 - tap * Cin;
         const int dy = (tap / KW) * dil_h, dx = (tap % KW) * dil_w;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NA; ++h) {
             const int iy = oy[h] + dy, ix = ox[h] + dx;
             const bool in = pv[h] && iy >= 0 && iy < H && ix >= 0 && ix < W;
             ra[h] = in ? *reinterpret_cast<const f32x4*>(xb[h] + ((int64_t)iy * W + ix) * Cin + ci0) : f32x4{0.f, 0.f, 0.f, 0.f};
-            rb[h] = bv ? *reinterpret_cast<const f32x4*>(wb + (int64_t)(k0 + bk + 8 * h) * Cout) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+#pragma unroll
+        for (int h = 0; h < NBQ; ++h)
+            rb[h] = bv ? *reinterpret_cast<const f32x4*>(wb + (int64_t)(k0 + bk + (kCvBK / NBQ) * h) * Cout) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            *reinterpret_cast<f32x4*>(As + ((size_t)buf * kCvBM + sr + 64 * h) * kCvLDA + 4 * sq) = ra[h];
-            *reinterpret_cast<f32x4*>(Bs + ((size_t)buf * kCvBK + bk + 8 * h) * kCvLDB + 4 * bq) = rb[h];
-        }
+        for (int h = 0; h < NA; ++h) *reinterpret_cast<f32x4*>(As + ((size_t)buf * BM + sr + 64 * h) * kCvLDA + 4 * sq) = ra[h];
+#pragma unroll
+        for (int h = 0; h < NBQ; ++h) *reinterpret_cast<f32x4*>(Bs + ((size_t)buf * kCvBK + bk + (kCvBK / NBQ) * h) * LDB + 4 * bq) = rb[h];
     };
     const int nk = KH * KW * Cin / kCvBK;
     gload(0);
@@ -166,32 +173,32 @@ nn_conv2d_tiled_kernel(const float* __restrict__ x, const float* __restrict__ w,
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload((kt + 1) * kCvBK);
-        f32x4 af[4];
+        f32x4 af[WB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + ((size_t)buf * kCvBM + wm * 64 + i * 16 + l15) * kCvLDA + 4 * lq);
-        const float* bl = Bs + ((size_t)buf * kCvBK + 4 * lq) * kCvLDB + wn * 64 + l15;
+        for (int i = 0; i < WB; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + ((size_t)buf * BM + wm * 16 * WB + i * 16 + l15) * kCvLDA + 4 * lq);
+        const float* bl = Bs + ((size_t)buf * kCvBK + 4 * lq) * LDB + wn * 16 * WB + l15;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            float bf[4];
+            float bf[WB];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = bl[s4 * kCvLDB + j * 16];
+            for (int j = 0; j < WB; ++j) bf[j] = bl[s4 * LDB + j * 16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < WB; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i][s4], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i][s4], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
     // D rows = channel (4 lq + r), D columns = pixel (l15)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t p = m0 + wm * 64 + i * 16 + l15;
+    for (int i = 0; i < WB; ++i) {
+        const int64_t p = m0 + wm * 16 * WB + i * 16 + l15;
         if (p >= npix) continue;
         float* yp = y + p * y_ct + y_c0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int co = n0 + wn * 64 + j * 16 + 4 * lq;
+        for (int j = 0; j < WB; ++j) {
+            const int co = n0 + wn * 16 * WB + j * 16 + 4 * lq;
             if (co >= Cout) continue;
             f32x4 v;
 #pragma unroll
@@ -213,11 +220,19 @@ static bool conv_tiled_ok(const float* x, const float* w, int Cin, int Cout, int
 static void launch_conv_tiled(alsep_ctx* ctx, const float* x, const float* w, const float* scale, const float* shift, float* y, int64_t npix,
                               int H, int W, int Cin, int Cout, int Ho, int Wo, int KH, int KW, int stride_h, int stride_w, int pad_h,
                               int pad_w, int dil_h, int dil_w, int act, int y_ct, int y_c0) {
-    const size_t lds = (2 * (size_t)kCvBM * kCvLDA + 2 * (size_t)kCvBK * kCvLDB) * sizeof(float);
     const int vec = (y_ct % 4 == 0 && y_c0 % 4 == 0 && ((uintptr_t)y & 15) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(nn_conv2d_tiled_kernel, dim3((unsigned)((Cout + kCvBN - 1) / kCvBN), (unsigned)ceil_div64(npix, kCvBM)), dim3(kVrThreads),
-                       lds, ctx->stream, x, w, scale, shift, y, npix, H, W, Cin, Cout, Ho, Wo, KH, KW, stride_h, stride_w, pad_h, pad_w, dil_h,
-                       dil_w, act, y_ct, y_c0, vec);
+    const int64_t big = ((Cout + 127) / 128) * ceil_div64(npix, 128);
+    if (big >= 192) {                                        // enough 128 x 128 tiles for the chip
+        const size_t lds = (2 * (size_t)128 * kCvLDA + 2 * (size_t)kCvBK * (128 + 4)) * sizeof(float);
+        hipLaunchKernelGGL(nn_conv2d_tiled_kernel<4>, dim3((unsigned)((Cout + 127) / 128), (unsigned)ceil_div64(npix, 128)), dim3(kVrThreads), lds,
+                           ctx->stream, x, w, scale, shift, y, npix, H, W, Cin, Cout, Ho, Wo, KH, KW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w,
+                           act, y_ct, y_c0, vec);
+    } else {
+        const size_t lds = (2 * (size_t)64 * kCvLDA + 2 * (size_t)kCvBK * (64 + 4)) * sizeof(float);
+        hipLaunchKernelGGL(nn_conv2d_tiled_kernel<2>, dim3((unsigned)((Cout + 63) / 64), (unsigned)ceil_div64(npix, 64)), dim3(kVrThreads), lds,
+                           ctx->stream, x, w, scale, shift, y, npix, H, W, Cin, Cout, Ho, Wo, KH, KW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w,
+                           act, y_ct, y_c0, vec);
+    }
 }
 
 // depthwise KHxKW (groups = C), stride 1: x [B,H,W,C], w [C][KH][KW], y [B,H,W,C]
