@@ -92,6 +92,7 @@ _SIGNATURES = {
     "alsep_nn_bgemm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 +
                        [C.POINTER(C.c_int64)] * 3 + [C.c_float]),
     "alsep_nn_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+    "alsep_nn_softmax_rows_ld": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
     "alsep_nn_stats_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "alsep_nn_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_float,
                                 C.c_int, C.c_void_p]),

@@ -110,12 +110,16 @@ nn_bgemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float*
 // another fp32 summation order than nn_bgemm_kernel (both are valid orders of the reference's sum; the oracles' tolerances hold for both).
 // CT: C is row-major with N contiguous -- the operands swap MFMA roles so that a lane owns four consecutive columns (float4 stores).
 constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 16, kGemmLD = 24;
-template <bool CT>
+// BNN: B is [K][N] with N contiguous (the `P V` product: B = V as it lies) -- staged [16 k][128 n + 4] and read one float per k.
+// K need not be a multiple of 16: the last slice's loads are cut at K (A rows must be readable up to K rounded up to 4: the launcher
+// checks the row stride), so a softmax matrix with 801 columns in rows of 804 floats takes this path.
+template <bool CT, bool BNN>
 __global__ void __launch_bounds__(kNnThreads)
 nn_gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int nb2, int M, int N, int K,
                   GemmStrides sa, GemmStrides sb, GemmStrides sc, float alpha, const float* __restrict__ bias, int act) {
+    constexpr int LDBN = kGemmBN + 4;
     float* As = reinterpret_cast<float*>(alsep_smem);                       // [2][128][24]
-    float* Bs = As + 2 * kGemmBM * kGemmLD;                                  // [2][128][24]
+    float* Bs = As + 2 * kGemmBM * kGemmLD;                                  // [2][128][24], or BNN: [2][16][132]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
@@ -124,18 +128,26 @@ nn_gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, floa
     const float* b = B + b1 * sb.b1 + b2 * sb.b2;
     float* c = C + b1 * sc.b1 + b2 * sc.b2;
     const int m0 = blockIdx.y * kGemmBM, n0 = blockIdx.x * kGemmBN;
-    // staging duty: two float4 per operand and slice: rows (tid >> 2) and (tid >> 2) + 64, k-quad tid & 3
+    // staging duty: two float4 per operand and slice.  K-contiguous operand: rows (tid >> 2) and + 64, k-quad tid & 3;
+    // BNN: k rows (tid >> 5) and + 8, column quad tid & 31
     const int sr = tid >> 2, sq = tid & 3;
+    const int bk = tid >> 5, bq = tid & 31;
     const float* ga[2];
     const float* gb[2];
     bool va[2], vb[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int ra = m0 + sr + 64 * h, rb = n0 + sr + 64 * h;
+        const int ra = m0 + sr + 64 * h;
         va[h] = ra < M;
-        vb[h] = rb < N;
         ga[h] = a + (int64_t)(va[h] ? ra : 0) * sa.r + 4 * sq;
-        gb[h] = b + (int64_t)(vb[h] ? rb : 0) * sb.r + 4 * sq;
+        if (BNN) {
+            vb[h] = n0 + 4 * bq < N;                             // N % 4 == 0 on this path
+            gb[h] = b + (int64_t)(bk + 8 * h) * sb.k + n0 + 4 * bq;
+        } else {
+            const int rb = n0 + sr + 64 * h;
+            vb[h] = rb < N;
+            gb[h] = b + (int64_t)(vb[h] ? rb : 0) * sb.r + 4 * sq;
+        }
     }
     f32x4 acc[4][4];
 #pragma unroll
@@ -143,24 +155,39 @@ nn_gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, floa
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 ra_[2], rb_[2];
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto cut = [&](f32x4 v, int kq) {                         // zero the elements at k >= K of the quad starting at kq
+        if (kq + 4 <= K) return v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (kq + e >= K) v[e] = 0.f;
+        return v;
+    };
     auto gload = [&](int k0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            ra_[h] = va[h] ? *reinterpret_cast<const f32x4*>(ga[h] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-            rb_[h] = vb[h] ? *reinterpret_cast<const f32x4*>(gb[h] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int kq = k0 + 4 * sq;
+            ra_[h] = (va[h] && kq < K) ? cut(*reinterpret_cast<const f32x4*>(ga[h] + k0), kq) : zero4;
+            if (BNN) {
+                const int kr = k0 + bk + 8 * h;
+                rb_[h] = (vb[h] && kr < K) ? *reinterpret_cast<const f32x4*>(gb[h] + (int64_t)k0 * sb.k) : zero4;
+            } else {
+                rb_[h] = (vb[h] && kq < K) ? cut(*reinterpret_cast<const f32x4*>(gb[h] + k0), kq) : zero4;
+            }
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             *reinterpret_cast<f32x4*>(As + ((size_t)buf * kGemmBM + sr + 64 * h) * kGemmLD + 4 * sq) = ra_[h];
-            *reinterpret_cast<f32x4*>(Bs + ((size_t)buf * kGemmBN + sr + 64 * h) * kGemmLD + 4 * sq) = rb_[h];
+            if (BNN) *reinterpret_cast<f32x4*>(Bs + ((size_t)buf * kGemmBK + bk + 8 * h) * LDBN + 4 * bq) = rb_[h];
+            else *reinterpret_cast<f32x4*>(Bs + ((size_t)buf * kGemmBN + sr + 64 * h) * kGemmLD + 4 * sq) = rb_[h];
         }
     };
     gload(0);
     lstore(0);
     __syncthreads();
-    const int nk = K / kGemmBK;
+    const int nk = (K + kGemmBK - 1) / kGemmBK;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload((kt + 1) * kGemmBK);
@@ -168,17 +195,22 @@ nn_gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, floa
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             af[i] = *reinterpret_cast<const f32x4*>(As + ((size_t)buf * kGemmBM + wm * 64 + i * 16 + l15) * kGemmLD + 4 * lq);
-            bf[i] = *reinterpret_cast<const f32x4*>(Bs + ((size_t)buf * kGemmBN + wn * 64 + i * 16 + l15) * kGemmLD + 4 * lq);
+            if (!BNN) bf[i] = *reinterpret_cast<const f32x4*>(Bs + ((size_t)buf * kGemmBN + wn * 64 + i * 16 + l15) * kGemmLD + 4 * lq);
         }
+        const float* bl = Bs + ((size_t)buf * kGemmBK + 4 * lq) * LDBN + wn * 64 + l15;
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
+        for (int s4 = 0; s4 < 4; ++s4) {
+            float bs[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bs[j] = BNN ? bl[s4 * LDBN + j * 16] : bf[j][s4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (CT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][s4], af[i][s4], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s4], bf[j][s4], acc[i][j], 0, 0, 0);
+                    if (CT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bs[j], af[i][s4], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s4], bs[j], acc[i][j], 0, 0, 0);
                 }
+        }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
@@ -220,23 +252,33 @@ nn_gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, floa
         }
 }
 
-static bool gemm_tn_ok(const float* A, const float* B, int M, int N, int K, const GemmStrides& a, const GemmStrides& b) {
+// 0: not applicable; 1: B [N][K] (K contiguous); 2: B [K][N] (N contiguous).  A is K-contiguous with 16-byte aligned rows that can
+// be read up to K rounded up to 4 (row stride >= that), likewise a K-contiguous B.
+static int gemm_tiled_mode(const float* A, const float* B, int M, int N, int K, const GemmStrides& a, const GemmStrides& b) {
     static const int on = [] { const char* e = getenv("ALSEP_NN_GEMM_TN"); return e ? atoi(e) : 1; }();
-    return on && a.k == 1 && b.k == 1 && K % kGemmBK == 0 && a.r % 4 == 0 && b.r % 4 == 0 && a.b1 % 4 == 0 && a.b2 % 4 == 0 && b.b1 % 4 == 0 &&
-           b.b2 % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (int64_t)M * N >= 64 * 64;
+    const int64_t k4 = (K + 3) / 4 * 4;
+    if (!on || a.k != 1 || a.r % 4 || a.r < k4 || a.b1 % 4 || a.b2 % 4 || b.b1 % 4 || b.b2 % 4 || (((uintptr_t)A | (uintptr_t)B) & 15) ||
+        (int64_t)M * N < 64 * 64 || K < 16)
+        return 0;
+    if (b.k == 1 && b.r % 4 == 0 && b.r >= k4) return 1;
+    if (b.r == 1 && b.k % 4 == 0 && N % 4 == 0) return 2;
+    return 0;
 }
 static bool gemm_ct_ok(const float* C, int N, const GemmStrides& c) {
     return c.k == 1 && c.r % 4 == 0 && c.b1 % 4 == 0 && c.b2 % 4 == 0 && N % 4 == 0 && ((uintptr_t)C & 15) == 0;
 }
 static int launch_gemm(alsep_ctx* ctx, const float* A, const float* B, float* C, int nb, int nb2, int M, int N, int K, GemmStrides a,
                        GemmStrides b, GemmStrides c, float alpha, const float* bias, int act) {
-    if (gemm_tn_ok(A, B, M, N, K, a, b)) {
+    const int mode = gemm_tiled_mode(A, B, M, N, K, a, b);
+    if (mode) {
         const dim3 grid((unsigned)ceil_div64(N, kGemmBN), (unsigned)ceil_div64(M, kGemmBM), (unsigned)nb);
-        const size_t lds = 2 * (size_t)(kGemmBM + kGemmBN) * kGemmLD * sizeof(float);
-        if (gemm_ct_ok(C, N, c))
-            hipLaunchKernelGGL(nn_gemm_tn_kernel<true>, grid, dim3(kNnThreads), lds, ctx->stream, A, B, C, nb2, M, N, K, a, b, c, alpha, bias, act);
-        else
-            hipLaunchKernelGGL(nn_gemm_tn_kernel<false>, grid, dim3(kNnThreads), lds, ctx->stream, A, B, C, nb2, M, N, K, a, b, c, alpha, bias, act);
+        const size_t lds = 2 * (size_t)(kGemmBM + kGemmBN) * kGemmLD * sizeof(float);       // (the [16][132] B image is smaller)
+        const bool ct = gemm_ct_ok(C, N, c);
+#define ALSEP_GEMM_GO(CT_, BNN_)                                                                                                     \
+    hipLaunchKernelGGL((nn_gemm_tn_kernel<CT_, BNN_>), grid, dim3(kNnThreads), lds, ctx->stream, A, B, C, nb2, M, N, K, a, b, c, alpha, bias, act)
+        if (mode == 1) { if (ct) ALSEP_GEMM_GO(true, false); else ALSEP_GEMM_GO(false, false); }
+        else { if (ct) ALSEP_GEMM_GO(true, true); else ALSEP_GEMM_GO(false, true); }
+#undef ALSEP_GEMM_GO
         ALSEP_LAUNCH_CHECK(ctx, "nn_gemm_tn_kernel");
         return ALSEP_OK;
     }
@@ -248,10 +290,10 @@ static int launch_gemm(alsep_ctx* ctx, const float* A, const float* B, float* C,
 
 // softmax over the last dimension, in place; one workgroup per row
 __global__ void __launch_bounds__(kNnThreads)
-nn_softmax_rows_kernel(float* __restrict__ x, int n) {
+nn_softmax_rows_kernel(float* __restrict__ x, int n, int ld) {
     float* red = reinterpret_cast<float*>(alsep_smem);
     double* redd = reinterpret_cast<double*>(alsep_smem + 64);
-    float* row = x + (int64_t)blockIdx.x * n;
+    float* row = x + (int64_t)blockIdx.x * ld;
     float mx = -3.4e38f;
     for (int i = threadIdx.x; i < n; i += kNnThreads) mx = fmaxf(mx, row[i]);
     mx = block_max(mx, red);
@@ -762,7 +804,15 @@ extern "C" int alsep_nn_bgemm_bias(alsep_ctx* ctx, const float* A, const float* 
 extern "C" int alsep_nn_softmax_rows(alsep_ctx* ctx, float* x, int64_t rows, int n) {
     ALSEP_ENTER(ctx);
     NN_ARG(ctx && x && rows > 0 && rows <= 0x7fffffff && n > 0, "alsep_nn_softmax_rows");
-    hipLaunchKernelGGL(nn_softmax_rows_kernel, dim3((unsigned)rows), dim3(kNnThreads), 128, ctx->stream, x, n);
+    hipLaunchKernelGGL(nn_softmax_rows_kernel, dim3((unsigned)rows), dim3(kNnThreads), 128, ctx->stream, x, n, n);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_softmax_rows_kernel");
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_nn_softmax_rows_ld(alsep_ctx* ctx, float* x, int64_t rows, int n, int ld) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && x && rows > 0 && rows <= 0x7fffffff && n > 0 && ld >= n, "alsep_nn_softmax_rows_ld");
+    hipLaunchKernelGGL(nn_softmax_rows_kernel, dim3((unsigned)rows), dim3(kNnThreads), 128, ctx->stream, x, n, ld);
     ALSEP_LAUNCH_CHECK(ctx, "nn_softmax_rows_kernel");
     return ALSEP_OK;
 }

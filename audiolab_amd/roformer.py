@@ -189,16 +189,17 @@ class Roformer:
             n_seq, L, seq_stride, row_stride = nb, T, ld, nb * ld
         else:                                                                 # batch (frame, head); rows are ld apart
             n_seq, L, seq_stride, row_stride = T, nb, nb * ld, ld
-        scores = ctx.empty((n_seq, Hh, L, L))
+        Lp = -(-L // 4) * 4                                                    # score rows padded to 16 bytes: the tiled GEMM's float4 loads
+        scores = ctx.empty((n_seq, Hh, L, Lp))
         base = qkv.data_ptr()
         ctx.check(lib.alsep_nn_bgemm(h, C.c_void_p(base), C.c_void_p(base + 4 * inner), _lib.ptr(scores), n_seq, Hh, L, L, d,
-                                     arr(seq_stride, d, row_stride, 1), arr(seq_stride, d, row_stride, 1), arr(Hh * L * L, L * L, L, 1),
+                                     arr(seq_stride, d, row_stride, 1), arr(seq_stride, d, row_stride, 1), arr(Hh * L * Lp, L * Lp, Lp, 1),
                                      d ** -0.5), "alsep_nn_bgemm")
-        ctx.check(lib.alsep_nn_softmax_rows(h, _lib.ptr(scores), n_seq * Hh * L, L), "alsep_nn_softmax_rows")
+        ctx.check(lib.alsep_nn_softmax_rows_ld(h, _lib.ptr(scores), n_seq * Hh * L, L, Lp), "alsep_nn_softmax_rows_ld")
         att = ctx.empty((rows, inner))
         o_seq, o_row = (inner, nb * inner) if over_time else (nb * inner, inner)
         ctx.check(lib.alsep_nn_bgemm(h, _lib.ptr(scores), C.c_void_p(base + 8 * inner), _lib.ptr(att), n_seq, Hh, L, d, L,
-                                     arr(Hh * L * L, L * L, L, 1), arr(seq_stride, d, 1, row_stride), arr(o_seq, d, o_row, 1), 1.0), "alsep_nn_bgemm")
+                                     arr(Hh * L * Lp, L * Lp, Lp, 1), arr(seq_stride, d, 1, row_stride), arr(o_seq, d, o_row, 1), 1.0), "alsep_nn_bgemm")
         gates = self._dense(xn, rows, P["gates"])
         ctx.check(lib.alsep_nn_gate(h, _lib.ptr(att), _lib.ptr(gates), rows, Hh, d), "alsep_nn_gate")
         a = self._dense(att, rows, P["out"])

@@ -231,6 +231,8 @@ int alsep_nn_bgemm(alsep_ctx* ctx, const float* A, const float* B, float* C, int
                    const int64_t* sb, const int64_t* sc, float alpha);
 /* softmax over the last dimension of x [rows, n], in place */
 int alsep_nn_softmax_rows(alsep_ctx* ctx, float* x, int64_t rows, int n);
+/* the same on rows `ld` floats apart (a score matrix whose rows are padded to a multiple of 4 floats) */
+int alsep_nn_softmax_rows_ld(alsep_ctx* ctx, float* x, int64_t rows, int n, int ld);
 /* bytes of device scratch (8-byte aligned) for alsep_nn_norm / alsep_nn_meanstd over G groups of per_group elements */
 int64_t alsep_nn_stats_workspace_bytes(int64_t G, int64_t per_group);
 /* x [G, R, C]: normalise every group of R rows x C channels to zero mean / unit (biased) variance, y = act(n * gamma[c] + beta[c]):
