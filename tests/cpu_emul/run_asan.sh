@@ -11,3 +11,5 @@ ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 LD_PRELOAD="$RT" pyt
 for m in mq mny big; do
   ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 LD_PRELOAD="$RT" python "$HERE/asan_cases_conv.py" $m
 done
+# the fp32 model families' kernels (tiled GEMM / conv, InstanceNorm statistics, softmax with a leading dimension; about 2 minutes)
+ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 LD_PRELOAD="$RT" python "$HERE/asan_cases_nn.py"
