@@ -130,7 +130,7 @@ class Separator:
     def __init__(self, log_level=logging.INFO, model_file_dir: str = "models/audio_separator", output_dir: Optional[str] = None,
                  invert_using_spec: bool = True, use_autocast: bool = True, ctx: Optional[Context] = None,
                  dtype: Optional[torch.dtype] = None, sample_rate: int = 44100, chunks: int = 0, margin: int = 44100,
-                 denoise: bool = False, max_batch: int = 8, sharded: bool = False, roster: Optional[Dict[str, tuple]] = None,
+                 denoise: bool = False, max_batch: int = 32, sharded: bool = False, roster: Optional[Dict[str, tuple]] = None,
                  chunker: str = "margin", overlap: float = 0.25, compensate: Optional[float] = None,
                  allow_synthetic: bool = False, **_ignored):
         """``allow_synthetic=True`` (bench, tests): a roster name without a weight file gets seeded random-init weights.

@@ -71,11 +71,12 @@ PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 _PMC = None
 
 
-def pmc_traffic(kernel_prefix: str):
+def pmc_traffic(kernel_prefix: str, windows_per_launch=None):
     """HBM bytes per launch of a kernel from the committed PMC summary (profiles/pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command; FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for 16-byte-per-lane streams on gfx950).  The file carries the hash of the kernel sources it was
-    collected from: with any other sources (or no file) the figure is None -- never a stale number."""
+    collected from and the windows per network launch of that run: with any other sources (or no file) the figure is None --
+    never a stale number -- and with another launch size it is scaled (a network kernel's traffic is linear in its windows)."""
     global _PMC
     if _PMC is None:
         _PMC = {}
@@ -86,7 +87,11 @@ def pmc_traffic(kernel_prefix: str):
                 _PMC = d
         except Exception:
             _PMC = {}
-    return _PMC.get(kernel_prefix, {}).get("hbm_bytes_per_launch")
+    v = _PMC.get(kernel_prefix, {}).get("hbm_bytes_per_launch")
+    if v is None or windows_per_launch is None:
+        return v
+    wpl = _PMC.get("_build", {}).get("windows_per_launch")
+    return v * windows_per_launch / wpl if wpl else None
 
 
 def _cpu_model() -> str:
@@ -170,6 +175,8 @@ def other_workload(args) -> None:
     ctx = _lib.Context(device)
     wl = args.workload
     weak = args.scaling == "weak"
+    if args.batch <= 0:
+        args.batch = 32                                        # windows / chunks per network launch of the MDX-Net models here
     if wl == "demucs6":                                       # configs[2]: htdemucs 6-stem, 10 min, overlap 0.25, segments sharded
         seconds = args.seconds if args.seconds != TRACK_SECONDS else 600
         n = seconds * SR * (world if weak else 1)
@@ -260,7 +267,9 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--batch", type=int, default=8, help="model windows per network launch")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="model windows per network launch (0 = all of a rank's windows in one launch, at most 64: 18 GiB of workspace per "
+                         "model at 52 windows; profiles/r02_batch_sweep.txt: 8 -> 220, 16 -> 216, 26 -> 212, 52 -> 207 ms per step)")
     ap.add_argument("--seconds", type=int, default=TRACK_SECONDS, help="audio seconds per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=2)
@@ -303,6 +312,11 @@ def main() -> None:
     mix_np = synth_mix(n_samples)
     mix = torch.from_numpy(mix_np).to(device)
     sds = [synthetic_state_dict(cfg, seed=s) for s in range(N_STEMS)]
+    if args.batch <= 0:                                       # this rank's window count (as computed after the timed region), capped
+        from audiolab_amd.dist import window_range as _wr
+        _gen = cfg.hop * (cfg.dim_t - 1) - cfg.n_fft
+        _lo, _hi = _wr(n_samples // _gen + 1, world, rank)
+        args.batch = max(1, min(_hi - _lo, 64))
     nets = [TDFNet(cfg, sd, ctx=ctx, dtype=dtype, max_batch=args.batch) for sd in sds]
     pargs = types.SimpleNamespace(margin=SR, chunks=0, denoise=False, dim_f=cfg.dim_f, dim_t=8, n_fft=cfg.n_fft)
     preds = [Predictor(pargs, net, ctx=ctx, max_batch=0, sharded=world > 1) for net in nets]
@@ -377,7 +391,7 @@ def main() -> None:
         else:
             e.update({"bound": "mfma", "achieved": round(tfl, 2), "peak": peak, "unit": "TFLOP/s",
                       "frac": round(tfl / peak, 4), "gbs": round(gbs, 1)})
-        e.update({"traffic": pmc_traffic(KCLASS[cls][0]) if dtype == torch.bfloat16 else None,
+        e.update({"traffic": pmc_traffic(KCLASS[cls][0], args.batch) if dtype == torch.bfloat16 else None,
                   "launches": launches, "avg_us": round(ms * 1e3 / max(launches, 1), 2),
                   "flops_per_launch": fl / max(launches, 1), "bytes_per_launch": byts / max(launches, 1),
                   "levels": levels})

@@ -11,7 +11,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 1200 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc/$c -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_$c.log 2>&1
 done
 python scripts/pmc_summary.py gpurun_out/pmc > /dev/null
-python scripts/pmc_traffic.py gpurun_out/pmc/pmc_summary.json gpurun_out/pmc_traffic.json | head -12
+W=$(grep -o 'windows/launch=[0-9]*' gpurun_out/pmc_FETCH_SIZE.log | tail -1 | cut -d= -f2)
+python scripts/pmc_traffic.py gpurun_out/pmc/pmc_summary.json gpurun_out/pmc_traffic.json ${W:-} | head -12
 find gpurun_out/pmc -name "*counter_collection.csv" -delete
 cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json
 timeout -k 10 900 python -u -m pytest tests -m gpu -q --timeout 420 > gpurun_out/pytest_gpu_full.log 2>&1; tail -3 gpurun_out/pytest_gpu_full.log | tee gpurun_out/pytest_gpu.log

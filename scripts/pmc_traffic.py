@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audiolab_amd.buildinfo import source_hash  # noqa: E402
 
 src, dst = sys.argv[1], sys.argv[2]
+wpl = int(sys.argv[3]) if len(sys.argv) > 3 else None       # model windows per network launch of the profiled run (bench.py --batch)
 d = json.load(open(src))
 agg = collections.defaultdict(lambda: {"launches": 0, "fetch_kb": 0.0, "write_kb": 0.0})
 for key, cs in d.items():
@@ -29,7 +30,7 @@ for name, a in agg.items():
     out[name] = {"launches": n, "fetch_size_kb_mean": a["fetch_kb"] / n, "write_size_kb_mean": a["write_kb"] / n,
                  "hbm_bytes_per_launch": (2 * a["fetch_kb"] + a["write_kb"]) / n * 1024,
                  "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, x1024"}
-out["_build"] = {"source_hash": source_hash()}          # bench.py refuses this file for any other kernel source
+out["_build"] = {"source_hash": source_hash(), "windows_per_launch": wpl}    # bench.py refuses this file for any other kernel source
 json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
 del out["_build"]
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:14]:
