@@ -115,3 +115,21 @@ def test_softmax_rows_with_leading_dimension(dev):
     got = host(xd)
     assert np.max(np.abs(got[:, :801] - want)) < 1e-6
     assert np.array_equal(got[:, 801:], x[:, 801:].numpy())     # the padding is left alone
+
+
+@pytest.mark.parametrize("P,Cn,act", [(5000, 16, 3), (777, 128, 0), (3000, 96, 3), (1200, 384, 3)])
+def test_instnorm_vs_torch(dev, P, Cn, act):
+    """InstanceNorm2d (+ GELU) on channels-last data: channel counts that divide 256 take the all-threads statistics kernel, the
+    others the thread-per-channel one"""
+    g = torch.Generator().manual_seed(P + Cn)
+    x = torch.randn(P, Cn, generator=g) * 2 + 0.3
+    gamma, beta = 1 + 0.1 * torch.randn(Cn, generator=g), 0.1 * torch.randn(Cn, generator=g)
+    want = torch.nn.functional.instance_norm(x.double().t()[None], weight=gamma.double(), bias=beta.double(), eps=1e-5)[0].t()
+    if act == 3:
+        want = _gelu(want)
+    ws = dev.empty((int(dev.lib.alsep_nn_instnorm_workspace_bytes(P, Cn)),), torch.uint8)
+    xd, y = on(dev, x), dev.empty((P, Cn))
+    gd, bd = on(dev, gamma), on(dev, beta)
+    dev.check(dev.lib.alsep_nn_instnorm(dev.handle, _lib.ptr(xd), _lib.ptr(y), _lib.ptr(gd), _lib.ptr(bd), P, Cn, 1e-5, act, _lib.ptr(ws)),
+              "alsep_nn_instnorm")
+    assert float((torch.from_numpy(host(y)).double() - want).abs().max()) < 2e-5
