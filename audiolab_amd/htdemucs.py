@@ -289,15 +289,16 @@ class HTDemucs:
         ctx, cfg = self.ctx, self.cfg
         Cd, Hh = cfg.bottom_channels, cfg.t_heads
         dh = Cd // Hh
-        scores = ctx.empty((Hh, Nq, Nk))
+        Np = -(-Nk // 4) * 4                                     # score rows padded to 16 bytes: `P V` then runs on the tiled GEMM
+        scores = ctx.empty((Hh, Nq, Np))
         arr = C.c_int64 * 4
         ctx.check(ctx.lib.alsep_nn_bgemm(ctx.handle, C.c_void_p(q.data_ptr() + 4 * q_off), C.c_void_p(kv.data_ptr() + 4 * k_off), _lib.ptr(scores),
-                                         1, Hh, Nq, Nk, dh, arr(0, dh, q_ld, 1), arr(0, dh, kv_ld, 1), arr(0, Nq * Nk, Nk, 1),
+                                         1, Hh, Nq, Nk, dh, arr(0, dh, q_ld, 1), arr(0, dh, kv_ld, 1), arr(0, Nq * Np, Np, 1),
                                          1.0 / math.sqrt(dh)), "alsep_nn_bgemm")
-        ctx.check(ctx.lib.alsep_nn_softmax_rows(ctx.handle, _lib.ptr(scores), Hh * Nq, Nk), "alsep_nn_softmax_rows")
+        ctx.check(ctx.lib.alsep_nn_softmax_rows_ld(ctx.handle, _lib.ptr(scores), Hh * Nq, Nk, Np), "alsep_nn_softmax_rows_ld")
         out = ctx.empty((Nq, Cd))
         ctx.check(ctx.lib.alsep_nn_bgemm(ctx.handle, _lib.ptr(scores), C.c_void_p(kv.data_ptr() + 4 * v_off), _lib.ptr(out), 1, Hh, Nq, dh, Nk,
-                                         arr(0, Nq * Nk, Nk, 1), arr(0, dh, 1, kv_ld), arr(0, dh, Cd, 1), 1.0), "alsep_nn_bgemm")
+                                         arr(0, Nq * Np, Np, 1), arr(0, dh, 1, kv_ld), arr(0, dh, Cd, 1), 1.0), "alsep_nn_bgemm")
         return out
 
     def _tlayer(self, x: torch.Tensor, N: int, other: Optional[torch.Tensor], No: int, P) -> torch.Tensor:
