@@ -801,10 +801,52 @@ extern "C" int alsep_nn_bgemm_bias(alsep_ctx* ctx, const float* A, const float* 
     return launch_gemm(ctx, A, B, C, nb1 * nb2, nb2, M, N, K, a, b, c, alpha, bias, act);
 }
 
+// rows of at most 64 * kSmxPer elements (the attention matrices: 801 frames, 60 bands, 336 tokens): one WAVE per row, the row in
+// registers between the three steps (max, exp + sum, scale) -- one read and one write of the matrix instead of three reads and two writes
+// and two LDS reductions per row; the sum in fp64 as in the workgroup-per-row kernel (another order of the same additions)
+constexpr int kSmxPer = 16;
+__global__ void __launch_bounds__(kNnThreads)
+nn_softmax_rows_wave_kernel(float* __restrict__ x, int64_t rows, int n, int ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (kNnThreads / 64) + (threadIdx.x >> 6);
+    if (r >= rows) return;                                   // whole waves leave together
+    float* row = x + r * ld;
+    float v[kSmxPer];
+    float mx = -3.4e38f;
+#pragma unroll
+    for (int k = 0; k < kSmxPer; ++k) {
+        const int i = lane + 64 * k;
+        v[k] = i < n ? row[i] : -3.4e38f;
+        mx = fmaxf(mx, v[k]);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < kSmxPer; ++k) {
+        const int i = lane + 64 * k;
+        v[k] = i < n ? expf(v[k] - mx) : 0.f;
+        s += (double)v[k];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float inv = (float)(1.0 / s);
+#pragma unroll
+    for (int k = 0; k < kSmxPer; ++k) {
+        const int i = lane + 64 * k;
+        if (i < n) row[i] = v[k] * inv;
+    }
+}
+static void launch_softmax(alsep_ctx* ctx, float* x, int64_t rows, int n, int ld) {
+    if (n <= 64 * kSmxPer)
+        hipLaunchKernelGGL(nn_softmax_rows_wave_kernel, dim3((unsigned)ceil_div64(rows, kNnThreads / 64)), dim3(kNnThreads), 0, ctx->stream, x, rows,
+                           n, ld);
+    else
+        hipLaunchKernelGGL(nn_softmax_rows_kernel, dim3((unsigned)rows), dim3(kNnThreads), 128, ctx->stream, x, n, ld);
+}
+
 extern "C" int alsep_nn_softmax_rows(alsep_ctx* ctx, float* x, int64_t rows, int n) {
     ALSEP_ENTER(ctx);
     NN_ARG(ctx && x && rows > 0 && rows <= 0x7fffffff && n > 0, "alsep_nn_softmax_rows");
-    hipLaunchKernelGGL(nn_softmax_rows_kernel, dim3((unsigned)rows), dim3(kNnThreads), 128, ctx->stream, x, n, n);
+    launch_softmax(ctx, x, rows, n, n);
     ALSEP_LAUNCH_CHECK(ctx, "nn_softmax_rows_kernel");
     return ALSEP_OK;
 }
@@ -812,7 +854,7 @@ extern "C" int alsep_nn_softmax_rows(alsep_ctx* ctx, float* x, int64_t rows, int
 extern "C" int alsep_nn_softmax_rows_ld(alsep_ctx* ctx, float* x, int64_t rows, int n, int ld) {
     ALSEP_ENTER(ctx);
     NN_ARG(ctx && x && rows > 0 && rows <= 0x7fffffff && n > 0 && ld >= n, "alsep_nn_softmax_rows_ld");
-    hipLaunchKernelGGL(nn_softmax_rows_kernel, dim3((unsigned)rows), dim3(kNnThreads), 128, ctx->stream, x, n, ld);
+    launch_softmax(ctx, x, rows, n, ld);
     ALSEP_LAUNCH_CHECK(ctx, "nn_softmax_rows_kernel");
     return ALSEP_OK;
 }

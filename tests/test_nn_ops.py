@@ -133,3 +133,14 @@ def test_instnorm_vs_torch(dev, P, Cn, act):
     dev.check(dev.lib.alsep_nn_instnorm(dev.handle, _lib.ptr(xd), _lib.ptr(y), _lib.ptr(gd), _lib.ptr(bd), P, Cn, 1e-5, act, _lib.ptr(ws)),
               "alsep_nn_instnorm")
     assert float((torch.from_numpy(host(y)).double() - want).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("rows,n", [(130, 60), (9, 1024), (5, 1500)])
+def test_softmax_rows_sizes(dev, rows, n):
+    """short rows (wave-per-row kernel, also a partial last workgroup), the longest such row, and a longer one (workgroup per row)"""
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, n, generator=g) * 4
+    want = torch.softmax(x.double(), dim=-1).numpy()
+    xd = on(dev, x.clone())
+    dev.check(dev.lib.alsep_nn_softmax_rows(dev.handle, _lib.ptr(xd), rows, n), "alsep_nn_softmax_rows")
+    assert np.max(np.abs(host(xd) - want)) < 1e-6
