@@ -134,18 +134,22 @@ def cpu_baseline(cfg, sd, mix_np, n_windows: int):
             return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)),
                                          cfg.num_blocks, cfg.l, cfg.bn).numpy()
 
+    last = {}
+
     def run(windows: int) -> float:
         n = windows * g.gen_size - 1                     # exactly `windows` model windows (pad = 1)
         t0 = time.perf_counter()
         out = mdx_oracle.demix(mix_np[:, :n], g, model_run, chunks=0, margin=SR, dtype=np.float32)
         dt = time.perf_counter() - t0
         assert out.shape[-1] == n
+        last["out"] = out
         return dt
     warm = run(1)
     reps = 3 if warm * n_windows * 3 <= 45.0 else 1      # keep the default bench run within minutes
     times = [run(n_windows) for _ in range(reps)]
     dt = statistics.median(times)
     seconds = (n_windows * g.gen_size - 1) / SR
+    cpu_baseline.stems = last["out"]                     # the fp32 oracle's stems of the sample: the `accuracy` object's reference
     return {"value": round(seconds / dt, 4), "unit": "stems*x_realtime", "cores": best, "kind": "port",
             "host": f"{_cpu_model()} ({cores} logical cores; {best} torch threads picked by a sweep over one 3x3 conv)",
             "sample": f"1 of {N_STEMS} models, first {n_windows} model windows ({seconds:.2f} s of audio), fp32, "
@@ -272,6 +276,8 @@ def main() -> None:
                          "model at 52 windows; profiles/r02_batch_sweep.txt: 8 -> 220, 16 -> 216, 26 -> 212, 52 -> 207 ms per step)")
     ap.add_argument("--seconds", type=int, default=TRACK_SECONDS, help="audio seconds per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-precision", action="store_true",
+                    help="skip the `precision` / `accuracy` objects (full steps in the other storage types after the timed region; N = 1 only)")
     ap.add_argument("--cpu-windows", type=int, default=2)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: N x --seconds of audio on N GPUs (per-GPU work fixed); strong: --seconds in total")
@@ -445,7 +451,8 @@ def main() -> None:
                                   "frac": round(gbs / PEAK_HBM_GBS, 4), "n_fft": plan.n_fft, "dim_f": plan.dim_f,
                                   "bytes_per_chunk": alg, "chunks_per_launch": nb,
                                   "us_per_launch": round(ms * 1e3 / max(launches, 1), 2), "us_per_chunk": round(ms * 1e3 / max(launches, 1) / nb, 3),
-                                  "traffic": None if tr is None else tr * nb / 52.0, "algorithmic_bytes_per_launch": alg * nb}
+                                  "traffic": None if tr is None else tr * nb / float(_PMC.get("_build", {}).get("windows_per_launch") or 52),
+                                  "algorithmic_bytes_per_launch": alg * nb}
 
     fft_stage_lines(preds[0].model_.plan, "")
     if cfg.n_fft != 7680:                                    # the geometry of the reference's own vocal models (Voc_FT, Kim_Vocal_*: n_fft 7680, dim_f 3072)
@@ -455,6 +462,54 @@ def main() -> None:
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, sds[0], mix_np, args.cpu_windows)
+
+    # `precision`: the same step (4 models x the 5-min track) in every storage type, after the timed region; `accuracy`: model 0 over the
+    # CPU baseline's sample (its first windows) in every storage type against the fp32 oracle's stems of that sample -- so that the
+    # throughput of the mode that meets the north_star's 1e-4 (fp32) and the error of the modes that are faster travel in ONE line.
+    precision, accuracy = None, None
+    if rank == 0 and world == 1 and not args.no_precision:
+        n_acc = args.cpu_windows * gen - 1
+        ref = getattr(cpu_baseline, "stems", None) if cpu is not None else None
+        precision = {args.dtype: {"ms_per_step": round(dt / args.steps * 1e3, 2), "value": round(N_STEMS * (n_samples / SR) * args.steps / dt, 2),
+                                  "steps": args.steps, "windows_per_launch": args.batch}}
+        accuracy = None if ref is None else {
+            "reference": f"oracle/mdx_oracle.demix + oracle/tdfnet_oracle.forward (torch-CPU fp32), model 0 of {N_STEMS}, first "
+                         f"{args.cpu_windows} model windows ({n_acc / SR:.2f} s)", "peak": round(float(np.max(np.abs(ref))), 4)}
+
+        def acc_entry(got):
+            d = (got.astype(np.float64) - ref.astype(np.float64))
+            r = float(np.sqrt((d ** 2).sum() / (ref.astype(np.float64) ** 2).sum()))
+            return {"rel_l2": float(f"{r:.4g}"), "sdr_db": round(-20.0 * float(np.log10(max(r, 1e-30))), 2),
+                    "max_abs": float(f"{float(np.max(np.abs(d))):.4g}")}
+        if accuracy is not None:
+            accuracy[args.dtype] = acc_entry(preds[0].demix(mix[:, :n_acc]).cpu().numpy())
+        del stems, preds, nets
+        torch.cuda.empty_cache()
+        for name in ("f16", "bf16", "f32"):
+            if name == args.dtype:
+                continue
+            dtp = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[name]
+            pb = args.batch if name != "f32" else min(args.batch, 13)          # fp32 activations: twice the workspace per window
+            p_nets = [TDFNet(cfg, sd, ctx=ctx, dtype=dtp, max_batch=pb) for sd in sds]
+            p_preds = [Predictor(pargs, net, ctx=ctx, max_batch=0) for net in p_nets]
+            if accuracy is not None:
+                accuracy[name] = acc_entry(p_preds[0].demix(mix[:, :n_acc]).cpu().numpy())      # also the warm-up of this type's kernels
+            else:
+                p_preds[0].demix(mix[:, :2 * gen - 1])
+            p_steps = 1 if name == "f32" else max(1, min(args.steps, 3))
+            if name != "f32":
+                [p.demix(mix) for p in p_preds]
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(p_steps):
+                out_p = [p.demix(mix) for p in p_preds]
+            fence()
+            dtp_s = time.perf_counter() - t0
+            assert bool(torch.isfinite(out_p[0]).all())
+            precision[name] = {"ms_per_step": round(dtp_s / p_steps * 1e3, 2), "value": round(N_STEMS * (n_samples / SR) * p_steps / dtp_s, 2),
+                               "steps": p_steps, "windows_per_launch": pb}
+            del out_p, p_preds, p_nets
+            torch.cuda.empty_cache()
 
     if rank == 0:
         audio_seconds = n_samples / SR
@@ -480,6 +535,8 @@ def main() -> None:
             "roofline": roofline,
             "kernels": other,
             "stages": stages,
+            "precision": precision,
+            "accuracy": accuracy,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -324,7 +324,7 @@ def test_full_size_mdx_bf16_vs_oracle(ctx):
     # 0.8 x the cost of the storage type, total error at most 1.25 x that cost, and a hard cap.
     assert r_st < 0.8 * r_oo, (r_st, r_oo)
     assert r_32 < 1.25 * r_oo, (r_32, r_oo)
-    assert r_32 < 0.3
+    assert r_32 < HALF_BOUNDS["bf16"][11][1], r_32          # the depth-11 row of the per-depth table below
 
 
 def test_full_size_mdx_f16_vs_oracle(ctx):
@@ -356,7 +356,62 @@ def test_full_size_mdx_f16_vs_oracle(ctx):
     print(f"full-size f16: vs f16-storage oracle rel L2 = {r_st:.3e}; vs fp32 oracle {r_32:.3e} (SDR {-20 * np.log10(r_32):.1f} dB); "
           f"f16-storage oracle vs fp32 oracle {r_oo:.3e}; max|delta| vs fp32 oracle = {np.max(np.abs(got - want)):.3e}")
     assert r_st < 0.8 * r_oo and r_32 < 1.25 * r_oo
-    assert r_32 < 5e-2
+    assert r_32 < HALF_BOUNDS["f16"][11][1], r_32
+
+
+# Per-depth bounds of the half-precision storage types at the bench widths (g = 48, 3072 x 256, n_fft 6144), end to end in PCM over
+# one model window: {storage: {num_blocks: (bound on rel L2 vs the storage oracle, bound on rel L2 vs the fp32 oracle)}}.  The error
+# of a storage type grows with the depth of this random-init network (a flipped rounding is amplified by every later layer), so one
+# cap for all depths says nothing about the shallow ones: each row is ~1.5 x what the kernels measure at that depth
+# (profiles/r03_half_storage_per_depth.txt), i.e. a kernel whose rounding points moved, or whose accumulation lost bits, trips the
+# row of the first depth where it shows.
+HALF_BOUNDS = {
+    "bf16": {1: (6e-3, 1.0e-2), 3: (1.2e-2, 2.0e-2), 5: (3.0e-2, 5.0e-2), 7: (6.0e-2, 1.0e-1), 9: (1.0e-1, 1.7e-1), 11: (1.9e-1, 3.0e-1)},
+    "f16": {1: (8e-4, 1.3e-3), 3: (1.5e-3, 2.5e-3), 5: (4.0e-3, 6.5e-3), 7: (8.0e-3, 1.3e-2), 9: (1.4e-2, 2.2e-2), 11: (3.0e-2, 5.0e-2)},
+}
+
+
+@pytest.mark.parametrize("storage", ["bf16", "f16"])
+def test_half_storage_error_per_depth(ctx, storage):
+    """bf16 / f16 storage at network depths 1 ... 11 (bench widths), one model window each, against the storage oracle and the fp32
+    oracle, with a bound per depth (HALF_BOUNDS) instead of one cap."""
+    from audiolab_amd.mdx import Predictor
+    from audiolab_amd.synth import synth_mix, synthetic_state_dict
+    from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
+    from oracle import mdx_oracle, tdfnet_oracle
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[storage]
+    mix = synth_mix(200000, seed=5)
+
+    def rel(a, b):
+        d = (a - b).astype(np.float64)
+        return float(np.sqrt((d ** 2).sum() / (b.astype(np.float64) ** 2).sum()))
+    rows = []
+    for depth in (1, 3, 5, 7, 9, 11):
+        cfg = TDFNetConfig(num_blocks=depth)
+        sd = synthetic_state_dict(cfg, seed=depth)
+        g = mdx_oracle.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
+
+        def run_with(st):
+            def run(spek):
+                with torch.no_grad():
+                    return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)), cfg.num_blocks,
+                                                 cfg.l, cfg.bn, storage=st).numpy()
+            return run
+        want = mdx_oracle.demix(mix, g, run_with(None), chunks=0, margin=44100, dtype=np.float32)
+        want_st = mdx_oracle.demix(mix, g, run_with(dt), chunks=0, margin=44100, dtype=np.float32)
+        net = TDFNet(cfg, sd, ctx=ctx, dtype=dt, max_batch=2)
+        args = types.SimpleNamespace(margin=44100, chunks=0, denoise=False, dim_f=cfg.dim_f, dim_t=8, n_fft=cfg.n_fft)
+        got = Predictor(args, net, ctx=ctx).demix(torch.from_numpy(mix).cuda()).cpu().numpy()
+        rows.append((depth, rel(got, want_st), rel(got, want), rel(want_st, want), float(np.max(np.abs(got - want))),
+                     float(np.max(np.abs(want)))))
+        del net
+    print(f"{storage} storage per depth: depth | vs storage oracle | vs fp32 oracle | storage oracle vs fp32 | max|delta| vs fp32 | peak")
+    for r in rows:
+        print(f"  {r[0]:2d} | {r[1]:.3e} | {r[2]:.3e} | {r[3]:.3e} | {r[4]:.3e} | {r[5]:.3f}")
+    for depth, r_st, r_32, r_oo, _, _ in rows:
+        b_st, b_32 = HALF_BOUNDS[storage][depth]
+        assert r_st < b_st, (storage, depth, r_st, b_st)
+        assert r_32 < b_32, (storage, depth, r_32, b_32)
 
 
 def test_properties_at_baseline_size(ctx):
