@@ -44,6 +44,7 @@ class TensorEntry(C.Structure):
 
 _SIGNATURES = {
     "alsep_abi_version": (C.c_int, []),
+    "alsep_experiments_enabled": (C.c_int, []),
     "alsep_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "alsep_destroy": (C.c_int, [C.c_void_p]),
     "alsep_last_error": (C.c_char_p, [C.c_void_p]),
@@ -127,6 +128,15 @@ _SIGNATURES = {
     "alsep_vr_split_pred": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "alsep_vr_mirror": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4),
     "alsep_vr_band_spec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8),
+    "alsep_reverb_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
+    "alsep_reverb_xcorr_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_int64,
+                                            C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
+    "alsep_reverb_wiener_ir": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_int64,
+                                         C.c_double, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "alsep_reverb_envelope_db": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    "alsep_rfft_mag_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "alsep_dft_f64_workspace_bytes": (C.c_int64, [C.c_int64]),
+    "alsep_dft_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64]),
 }
 
 EXPORTS: Tuple[str, ...] = tuple(_SIGNATURES)

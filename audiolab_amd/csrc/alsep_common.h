@@ -92,11 +92,28 @@ static inline int alsep_fail(alsep_ctx* ctx, int code, const char* fmt, ...) {
                               hipGetErrorString(e_), __FILE__, __LINE__);                 \
     } while (0)
 
-// every entry point that allocates or launches first makes the ctx's device current (a Context('cuda:1') in a process
-// whose current device is 0 must not put its tables on device 0)
+// every entry point that allocates or launches makes the ctx's device current for its own duration and restores the caller's
+// device on every return path (a Context('cuda:1') used from a thread whose current device is 0 must neither put its tables on
+// device 0 nor leave the thread on device 1: torch's index-less allocations and current_stream() calls follow the current device)
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t enter(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev == device) return hipSuccess;
+        hipError_t e = hipSetDevice(device);
+        switched = (e == hipSuccess) && prev >= 0;
+        return e;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
 #define ALSEP_ENTER(ctx)                                                                  \
+    DeviceGuard alsep_device_guard_;                                                      \
     do {                                                                                  \
-        if ((ctx) && hipSetDevice((ctx)->device) != hipSuccess)                           \
+        if ((ctx) && alsep_device_guard_.enter((ctx)->device) != hipSuccess)              \
             return alsep_fail((ctx), ALSEP_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->device); \
     } while (0)
 

@@ -253,6 +253,14 @@ unsigned grid_for(int64_t n, int per_thread = 1) {
 
 extern "C" int alsep_abi_version(void) { return ALSEP_ABI_VERSION; }
 
+extern "C" int alsep_experiments_enabled(void) {
+#ifdef ALSEP_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int alsep_create(int device_id, void* hip_stream, alsep_ctx** out) {
     if (!out || device_id < 0) return ALSEP_ERR_ARG;
     if (hipSetDevice(device_id) != hipSuccess) return ALSEP_ERR_HIP;

@@ -411,7 +411,11 @@ nn_vec_fma_kernel(float* __restrict__ y, const float* __restrict__ x, const floa
 __global__ void __launch_bounds__(kNnThreads)
 nn_vec_div_kernel(float* __restrict__ y, const float* __restrict__ w, int64_t rows, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < rows * n; i += (int64_t)gridDim.x * kNnThreads)
-        y[i] = y[i] / w[i % n];
+        {   // a sample no window covers with a positive weight (num_overlap 1: both fades are 0 at a chunk boundary) is 0 / 0 upstream,
+            // which the training project's demix_track turns into 0 with nan_to_num
+            const float d = w[i % n];
+            y[i] = d != 0.f ? y[i] / d : 0.f;
+        }
 }
 // torch F.pad(mode="reflect") along the last axis: y[r][i] = x[r][reflect(i - left)], length n -> n + left + right
 __global__ void __launch_bounds__(kNnThreads)

@@ -578,6 +578,7 @@ conv3x3_bf16_regw_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, c
 #undef ALSEP_RW_STAGE
 }
 
+#ifdef ALSEP_EXPERIMENTS   // superseded by the big-tile / mq kernels; kept for A/B runs (-DALSEP_EXPERIMENTS), not in the product build
 // ------------------------------------------------------------------------------------------
 // bf16 3x3 convolution, deeper levels (Cout = 48*NY, NY = 2..6): persistent + software-pipelined.
 // One workgroup per CU walks tiles; for each tile and input chunk q the halo patch is staged ONCE
@@ -766,6 +767,7 @@ conv3x3_bf16_pipe_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, c
 #undef ALSEP_PIPE_WAIT
 }
 
+#endif  // ALSEP_EXPERIMENTS (pipe kernel)
 // ------------------------------------------------------------------------------------------
 // bf16 3x3 convolution, levels >= 1 (Cout = 48*NY, NY = 2..4): big-tile persistent kernel.
 // The ablations (profiles/r01_conv_ablation_*) show the plain kernel bounded by what goes through
@@ -1095,6 +1097,7 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
     }
 }
 
+#ifdef ALSEP_EXPERIMENTS   // superseded by conv3x3_bf16_mq_kernel (c = 96); equal to the big-tile kernel at c = 144
 // ------------------------------------------------------------------------------------------
 // bf16 3x3 convolution, levels 1 and 2, "merged" form of the big-tile kernel (round 2).
 // In-kernel stamps of conv3x3_bf16_big_kernel (profiles/r02_big_conv_stamps.txt) showed (a) its software-pipelined k-loop already
@@ -1427,6 +1430,7 @@ conv3x3_bf16_mny_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
     }
 }
 
+#endif  // ALSEP_EXPERIMENTS (merged kernel)
 // ------------------------------------------------------------------------------------------
 // bf16 3x3 convolution, level 1 (c = 96): everything double-buffered.
 // Stamps of the merged kernel (profiles/r02_big_conv_stamps.txt): with its k-loop at 89 % of the MFMA issue floor, 17 % of the launch is
@@ -2942,6 +2946,7 @@ std::vector<bf16_t> pack_conv3x3_big(const std::vector<float>& w, int cin) {
     return pack_conv3x3_dma(wp, cin, cout);
 }
 
+#ifdef ALSEP_EXPERIMENTS
 // image of conv3x3_bf16_mny_kernel<NY>: [q][kt][48 NY rows][WG groups][8]; row R holds output channel ConvBig::channel_of_row(R);
 // group (k-step stl of part kt, lq) sits at 4 stl + (lq ^ wswz(R)) and holds k-group 4 (kt KS + stl) + lq of the chunk (tap-major,
 // 6 groups of 8 input channels per tap; groups >= 54 are zero)
@@ -2966,6 +2971,8 @@ std::vector<bf16_t> pack_conv3x3_mny(const std::vector<float>& w, int cin) {
                     }
     return out;
 }
+
+#endif  // ALSEP_EXPERIMENTS
 
 // image of conv3x3_bf16_mq_kernel (c_out = 96): [q][part][96 rows][20 groups][8]; k-step stl of part pt is tap 5 pt + stl, its group lq
 // (input channels 32 q + 8 lq ..) sits at 4 stl + (lq ^ wswz(R)); row R holds output channel ConvBig<2>::channel_of_row(R)
@@ -3006,10 +3013,12 @@ int make_conv(alsep_net* net, const TensorMap& tm, const std::string& p, int c, 
         if (!rc && (c == 96 || c == 144)) {                  // a second image for the big-tile kernel (its own output-channel order)
             auto pb = c == 96 ? pack_conv3x3_big<2>(*w, c) : pack_conv3x3_big<3>(*w, c);
             rc = upload(net, pb.data(), pb.size() * sizeof(bf16_t), &L->w_big);
+#ifdef ALSEP_EXPERIMENTS
             if (!rc) {
                 auto pm = c == 96 ? pack_conv3x3_mny<2>(*w, c) : pack_conv3x3_mny<3>(*w, c);
                 rc = upload(net, pm.data(), pm.size() * sizeof(bf16_t), &L->w_mny);
             }
+#endif
             if (!rc && c == 96) {
                 auto pq = pack_conv3x3_mq(*w, c);
                 rc = upload(net, pq.data(), pq.size() * sizeof(bf16_t), &L->w_mq);
@@ -3228,6 +3237,10 @@ int run_conv_tw(alsep_ctx* ctx, const ConvLayer& L, const T* X, T* Y, int64_t B,
 }
 
 // timing-only diagnostic (ALSEP_CONV_ABLATE=1|2|4: skip LDS-DMA / MFMA loop / stores); results are wrong when set
+// The product build has no switch that changes WHAT is computed: the work-skipping (ablation), staggering, stamped and superseded
+// kernel variants below exist only in a library compiled with -DALSEP_EXPERIMENTS (ALSEP_BUILD_EXPERIMENTS=1 python -c
+// 'import __graft_entry__ as g; g.build(force=True)'; alsep_experiments_enabled() tells which one is loaded).
+#ifdef ALSEP_EXPERIMENTS
 int conv_ablate() {
     static const int v = [] { const char* e = getenv("ALSEP_CONV_ABLATE"); return e ? atoi(e) : 0; }();
     return v;
@@ -3237,6 +3250,10 @@ int conv_stagger() {
     static const int v = [] { const char* e = getenv("ALSEP_CONV_STAGGER"); return e ? atoi(e) : 0; }();
     return v;
 }
+#else
+constexpr int conv_ablate() { return 0; }
+constexpr int conv_stagger() { return 0; }
+#endif
 
 int conv_ny_fastest() {
     static const int v = [] { const char* e = getenv("ALSEP_CONV_NYFAST"); return e ? atoi(e) : 1; }();
@@ -3284,6 +3301,7 @@ int launch_conv_regw(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t
     return ALSEP_OK;
 }
 
+#ifdef ALSEP_EXPERIMENTS
 template <int NY>
 int launch_conv_pipe(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zero_page, int64_t B,
                      int Th, int Fw) {
@@ -3301,8 +3319,9 @@ int launch_conv_pipe(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t
     ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_pipe_kernel");
     return ALSEP_OK;
 }
+#endif  // ALSEP_EXPERIMENTS
 
-#ifndef ALSEP_CPU_EMUL
+#if defined(ALSEP_EXPERIMENTS) && !defined(ALSEP_CPU_EMUL)
 // timing experiments: print the per-phase cycle sums a stamped conv kernel left in dbuf [workgroup][wave][8]
 int report_stamps(alsep_ctx* ctx, unsigned long long* dbuf, int gx, int stages, long long ntiles, const char* label) {
     const size_t n = (size_t)256 * 8 * 8;
@@ -3345,9 +3364,13 @@ int launch_conv_big(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     // SLOWER (233.5 -> 238.4 ms): every other kernel -- the untouched NY = 3 conv, the plain conv, even the stand-alone STFT loop that
     // runs after the steps -- loses 5-9 % in the same process.  The chip gives the saved stall cycles back as a lower clock
     // (MI355X_MICROARCH.md, DVFS give-back), and keeps it lower for the kernels that follow.
+#ifdef ALSEP_EXPERIMENTS
     static const int swp = [] { const char* e = getenv("ALSEP_CONV_BIG_SWP"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int swp = 0;
+#endif
     ProfScope prof(ctx, NY == 3 ? ALSEP_PROF_CONV3X3_BIG3 : ALSEP_PROF_CONV3X3_BIG);
-#ifndef ALSEP_CPU_EMUL
+#if defined(ALSEP_EXPERIMENTS) && !defined(ALSEP_CPU_EMUL)
     // ALSEP_CONV_BIG_STAMP=n (timing experiments): the first n launches run the stamped variant, synchronise and print the per-phase
     // cycle sums (mean over waves, and waves 0 / 7 of workgroup 0) to stderr
     static int stamp_left = [] { const char* e = getenv("ALSEP_CONV_BIG_STAMP"); return e ? atoi(e) : 0; }();
@@ -3389,13 +3412,16 @@ int launch_conv_big(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
         return ALSEP_OK;
     }
 #endif
+#ifdef ALSEP_EXPERIMENTS
     if (swp >= (NY == 2 ? 1 : 2)) {                          // NY = 3: the second fragment set does not fit 256 registers (76 spilled): opt-in only
         ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_big_kernel<NY, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)Cf::lds_bytes));
         hipLaunchKernelGGL((conv3x3_bf16_big_kernel<NY, true>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
                            (const bf16_t*)L.w_big.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
                            L.cout, tiles_t, tiles_f, (int)ntiles);
-    } else {
+    } else
+#endif
+    {
         hipLaunchKernelGGL((conv3x3_bf16_big_kernel<NY, false>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
                            (const bf16_t*)L.w_big.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
                            L.cout, tiles_t, tiles_f, (int)ntiles);
@@ -3405,6 +3431,7 @@ int launch_conv_big(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     return ALSEP_OK;
 }
 
+#ifdef ALSEP_EXPERIMENTS
 template <int NY>
 int launch_conv_mny(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zero_page, int64_t B, int Th, int Fw) {
     typedef ConvMny<NY> Cf;
@@ -3415,7 +3442,7 @@ int launch_conv_mny(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_mny_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
     const int gx = ntiles < 256 ? (int)ntiles : 256;
     ProfScope prof(ctx, NY == 3 ? ALSEP_PROF_CONV3X3_BIG3 : ALSEP_PROF_CONV3X3_BIG);
-#ifndef ALSEP_CPU_EMUL
+#if defined(ALSEP_EXPERIMENTS) && !defined(ALSEP_CPU_EMUL)
     static int stamp_left = [] { const char* e = getenv("ALSEP_CONV_BIG_STAMP"); return e ? atoi(e) : 0; }();
     if (stamp_left > 0) {
         --stamp_left;
@@ -3451,6 +3478,7 @@ int launch_conv_mny(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     ALSEP_LAUNCH_CHECK(ctx, NY == 3 ? "conv3x3_bf16_mny_kernel<3>" : "conv3x3_bf16_mny_kernel<2>");
     return ALSEP_OK;
 }
+#endif  // ALSEP_EXPERIMENTS
 
 int launch_conv_mq(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y, const bf16_t* zero_page, int64_t B, int Th, int Fw) {
     typedef ConvMq Cf;
@@ -3460,7 +3488,7 @@ int launch_conv_mq(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* 
     if (!L.w_mq.p || L.cout != Cf::ROWS || L.cin % Cf::KC) return alsep_fail(ctx, ALSEP_ERR_STATE, "conv3x3: no mq weight image for this layer");
     const int gx = ntiles < 256 ? (int)ntiles : 256;
     ProfScope prof(ctx, ALSEP_PROF_CONV3X3_BIG);
-#ifndef ALSEP_CPU_EMUL
+#if defined(ALSEP_EXPERIMENTS) && !defined(ALSEP_CPU_EMUL)
     static int stamp_left = [] { const char* e = getenv("ALSEP_CONV_BIG_STAMP"); return e ? atoi(e) : 0; }();
     if (stamp_left > 0) {
         --stamp_left;
@@ -3482,18 +3510,21 @@ int launch_conv_mq(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* 
         return report_stamps(ctx, dbuf, gx, (int)((ntiles + gx - 1) / gx) * Cf::PARTS * (L.cin / Cf::KC), (long long)ntiles, sprio ? "mq prio" : "mq");
     }
 #endif
+#ifdef ALSEP_EXPERIMENTS
     static const int prio = [] { const char* e = getenv("ALSEP_CONV_MQ_PRIO"); return e ? atoi(e) : 0; }();
     if (prio) {
         ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_mq_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
         hipLaunchKernelGGL((conv3x3_bf16_mq_kernel<false, 1>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
                            (const bf16_t*)L.w_mq.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin, L.cout, tiles_t,
                            tiles_f, (int)ntiles, nullptr);
-    } else {
-        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_mq_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
-        hipLaunchKernelGGL((conv3x3_bf16_mq_kernel<false, 0>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
-                           (const bf16_t*)L.w_mq.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin, L.cout, tiles_t,
-                           tiles_f, (int)ntiles, nullptr);
+        ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_mq_kernel");
+        return ALSEP_OK;
     }
+#endif
+    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_mq_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
+    hipLaunchKernelGGL((conv3x3_bf16_mq_kernel<false, 0>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                       (const bf16_t*)L.w_mq.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin, L.cout, tiles_t,
+                       tiles_f, (int)ntiles, nullptr);
     ALSEP_LAUNCH_CHECK(ctx, "conv3x3_bf16_mq_kernel");
     return ALSEP_OK;
 }
@@ -3507,9 +3538,13 @@ int launch_conv_m0(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* 
     if (ntiles > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "conv3x3: too many tiles");
     if (!L.w_big.p || L.cout != Cf::ROWS || L.cin != Cf::KC) return alsep_fail(ctx, ALSEP_ERR_STATE, "conv3x3: no m0 weight image for this layer");
     const int gx = ntiles < 256 ? (int)ntiles : 256;
+#ifdef ALSEP_EXPERIMENTS
     static const int defer = [] { const char* e = getenv("ALSEP_CONV_M0_DEFER"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int defer = 0;
+#endif
     ProfScope prof(ctx, ALSEP_PROF_CONV3X3_REGW);
-#ifndef ALSEP_CPU_EMUL
+#if defined(ALSEP_EXPERIMENTS) && !defined(ALSEP_CPU_EMUL)
     static int stamp_left = [] { const char* e = getenv("ALSEP_CONV_M0_STAMP"); return e ? atoi(e) : 0; }();
     if (stamp_left > 0) {
         --stamp_left;
@@ -3530,12 +3565,16 @@ int launch_conv_m0(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* 
         return report_stamps(ctx, dbuf, gx, (int)((ntiles + gx - 1) / gx), (long long)ntiles, defer ? "m0 defer" : "m0");
     }
 #endif
+#ifdef ALSEP_EXPERIMENTS
     if (defer) {
         ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_m0_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
         hipLaunchKernelGGL((conv3x3_bf16_m0_kernel<false, true>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
                            (const bf16_t*)L.w_big.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin, L.cout, tiles_t,
                            tiles_f, (int)ntiles, nullptr);
-    } else {
+    } else
+#endif
+    {
+        (void)defer;
         ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_m0_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
         hipLaunchKernelGGL((conv3x3_bf16_m0_kernel<false, false>), dim3((unsigned)gx), dim3(kBigThreads), Cf::lds_bytes, ctx->stream, X, Y,
                            (const bf16_t*)L.w_big.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin, L.cout, tiles_t,
@@ -3559,10 +3598,12 @@ int conv_mq_enabled() {
 }
 
 // ALSEP_CONV_MNY: bit 0 the merged kernel at c = 96, bit 1 at c = 144 (default: see run_conv_dma)
+#ifdef ALSEP_EXPERIMENTS
 int conv_mny_enabled() {
     static const int v = [] { const char* e = getenv("ALSEP_CONV_MNY"); return e ? atoi(e) : 0; }();
     return v;
 }
+#endif
 
 int conv_big_enabled() {
     static const int v = [] { const char* e = getenv("ALSEP_CONV_BIG"); return e ? atoi(e) : 1; }();
@@ -3574,12 +3615,14 @@ int conv_big3_enabled() {
     return v;
 }
 
+#ifdef ALSEP_EXPERIMENTS
 int conv_pipe_enabled() {
     // opt-in: bit-identical to the plain kernel but not faster on MI355X (profiles/r01_conv_variants.txt):
     // the per-CU LDS-DMA intake, not the missing overlap, bounds these levels
     static const int v = [] { const char* e = getenv("ALSEP_CONV_PIPE"); return e ? atoi(e) : 0; }();
     return v;
 }
+#endif
 
 int conv_regw_enabled() {
     static const int v = [] { const char* e = getenv("ALSEP_CONV_REGW"); return e ? atoi(e) : 1; }();
@@ -3598,17 +3641,24 @@ int run_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y,
     if (conv_big_enabled() && Th % 8 == 0 && Fw % 64 == 0 && L.cin == L.cout &&
         (conv_big_enabled() >= 2 || B * (Th / 8) * (Fw / 64) >= 96)) {       // =2: no minimum tile count (tests)
         switch (L.cout / 48) {
-            case 2:
+            case 2:                                          // ALSEP_CONV_MQ=0: the plain kernel (experiments builds: merged / big-tile NY = 2)
                 if (conv_mq_enabled()) return launch_conv_mq(ctx, L, X, Y, zp, B, Th, Fw);
+#ifdef ALSEP_EXPERIMENTS
                 if (conv_mny_enabled() & 1) return launch_conv_mny<2>(ctx, L, X, Y, zp, B, Th, Fw);
                 return launch_conv_big<2>(ctx, L, X, Y, zp, B, Th, Fw);
+#else
+                break;
+#endif
             case 3:                                          // 8 VGPRs spill, outside the MFMA loops (ALSEP_CONV_BIG3=0: plain kernel)
+#ifdef ALSEP_EXPERIMENTS
                 if (conv_mny_enabled() & 2) return launch_conv_mny<3>(ctx, L, X, Y, zp, B, Th, Fw);
+#endif
                 if (conv_big3_enabled()) return launch_conv_big<3>(ctx, L, X, Y, zp, B, Th, Fw);
                 break;
             default: break;                                  // NY = 4 spills heavily at 2 waves/SIMD with ROCm 7.2
         }
     }
+#ifdef ALSEP_EXPERIMENTS
     if (conv_pipe_enabled() && Th % 4 == 0 && Fw % 64 == 0 && L.cin == L.cout &&
         (conv_pipe_enabled() >= 2 || B * (Th / 4) * (Fw / 64) >= 128)) {   // =2: no minimum tile count (tests)
         switch (L.cout / 48) {
@@ -3617,6 +3667,7 @@ int run_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* Y,
             default: break;                                  // NY = 4 spills registers with ROCm 7.2: stays on the plain kernel
         }
     }
+#endif
     if (Fw >= 64 && Fw % 64 == 0) return launch_conv_dma<64>(ctx, L, X, Y, zp, B, Th, Fw);
     if (Fw >= 32) return launch_conv_dma<32>(ctx, L, X, Y, zp, B, Th, Fw);
     return launch_conv_dma<16>(ctx, L, X, Y, zp, B, Th, Fw);

@@ -4,18 +4,18 @@ reference touches on ``audio_separator.separator.Separator`` (modules/separator/
 model_instance.output_dir, :281 separate(path) -> [basenames]) plus an in-memory
 ``separate_array`` used by the fast path (no temp WAV, no PCM16 round trip: SURVEY 8(b) b2).
 
-Model roster.  The reference downloads its models at run time (stem_separator.py:109-124); none
-is reachable offline, so every roster entry below is a TFC-TDF U-Net with random-init weights
-(audiolab_amd.synth) unless the model file itself is present: ``<model_file_dir>/<name>`` (an MDX-Net ``.onnx``, read by
-audiolab_amd.onnx_reader -- network hyper-parameters come from the graph, n_fft and the stem labels from the roster) or
-``<model_file_dir>/<name>.pt`` (a torch state_dict).  Geometry per file name follows the public UVR/KUIELab model tables
-(PARITY UNPINNED).
+Model roster.  The reference downloads its models at run time (stem_separator.py:109-124); none is reachable offline.  ``MODEL_ROSTER``
+maps every file name the reference loads to its architecture and hyper-parameters: MDX-Net ``.onnx`` (TFC-TDF U-Net, csrc/tdfnet.hip),
+Mel-Band / BS Roformer and MDX23C ``.ckpt`` (roformer.py / mdx23c.py over csrc/nn.hip), htdemucs ``.yaml`` (htdemucs.py), VR ``.pth``
+(vrnet.py + vr_frontend.py).  Weights come from ``<model_file_dir>/<name>`` -- an ``.onnx`` graph (audiolab_amd.onnx_reader: network
+hyper-parameters from the graph, n_fft and labels from the roster), a ``.ckpt`` / ``.pth`` / ``.pt`` state_dict, a demucs ``.th`` package
+(restricted unpickler, audiolab_amd/th_reader.py), with a training-project ``.yaml`` beside a ``.ckpt`` overriding the roster's
+hyper-parameters -- or, only with ``allow_synthetic=True`` (bench / tests), from a seeded random init.  Every loader checks the tensors'
+shapes against the configuration and names the mismatching hyper-parameter.  Geometry per file name follows the public UVR / KUIELab /
+training-project tables (PARITY UNPINNED: upstream, uncited).
 
-Multi-stem entries.  A roster value ``("multi", [(label, cfg), ...])`` describes a model file that yields several stems
-(the reference's drum-kit splitter ``MDX23C-DrumSep-aufr33-jarredou.ckpt`` returns six, stem_separator.py:563-574): one
-network per label.  The default roster holds MDX-Net models only; the other architectures the orchestrator names (MDX23C,
-VR, Roformer: SURVEY 8(f)) have no kernels yet, so those stages run only when the caller's roster supplies the file name --
-with whatever network it maps it to.
+Multi-stem entries.  A roster value ``("multi", [(label, cfg), ...])`` describes an MDX-Net style file set that yields several stems: one
+network per label.
 
 MDX runner.  ``chunker="margin"`` (default): margin chunker + trim stitching exactly as the in-tree
 runner (mdxnet.py:109-197, pinned).  ``chunker="ola"``: Hann-window overlap-add with ``overlap`` and
@@ -107,6 +107,45 @@ MODEL_ROSTER: Dict[str, tuple] = {
 _BENCH = _cfg(6144, 3072, 256)
 BENCH_ROSTER: Dict[str, tuple] = {f"bench_4stem_{t.lower()}.onnx": (t, f"No {t}", _BENCH) for t in ("Vocals", "Drums", "Bass", "Other")}
 FOUR_STEM_SET = ("kuielab_a_vocals.onnx", "kuielab_a_drums.onnx", "kuielab_a_bass.onnx", "kuielab_a_other.onnx")
+
+
+# The .yaml that audio-separator downloads beside a .ckpt does not always carry the checkpoint's name.  Names as published in that
+# package's model list, as recalled by the builder (upstream, uncited -- the package is not in /root/reference): tried after
+# ``<checkpoint stem>.yaml``; a miss falls back to the roster's hyper-parameters with a WARNING.
+YAML_NAMES: Dict[str, tuple] = {
+    "MDX23C-8KFFT-InstVoc_HQ.ckpt": ("model_2_stem_full_band_8k.yaml",),
+    "MDX23C-DrumSep-aufr33-jarredou.ckpt": ("aufr33-jarredou_DrumSep_model_mdx23c_ep_141_sdr_10.8059.yaml",),
+    "melband_roformer_big_beta4.ckpt": ("config_melbandroformer_big_beta4.yaml",),
+    "dereverb_mel_band_roformer_anvuew_sdr_19.1729.ckpt": ("dereverb_mel_band_roformer_anvuew.yaml",),
+    "dereverb-echo_mel_band_roformer_sdr_13.4843_v2.ckpt": ("config_dereverb-echo_mel_band_roformer.yaml",),
+    "dereverb-echo_mel_band_roformer_sdr_10.0169.ckpt": ("config_dereverb-echo_mel_band_roformer.yaml",),
+    "mel_band_roformer_crowd_aufr33_viperx_sdr_8.7144.ckpt": ("model_mel_band_roformer_crowd.yaml",),
+}
+
+
+def _yaml_loader():
+    """yaml.SafeLoader that also reads ``!!python/tuple`` (the training project's BS-RoFormer configs write ``freqs_per_bands`` with
+    that tag; plain safe_load raises ConstructorError on it).  Nothing else beyond the safe schema is constructed."""
+    import yaml
+
+    class Loader(yaml.SafeLoader):
+        pass
+    Loader.add_constructor("tag:yaml.org,2002:python/tuple", lambda ld, node: tuple(ld.construct_sequence(node, deep=True)))
+    return Loader
+
+
+def load_model_yaml(model_file_dir: str, model_filename: str) -> Optional[dict]:
+    """The hyper-parameter file of a .ckpt model: ``<stem>.yaml``, then the names of ``YAML_NAMES``; None (and a WARNING) if absent."""
+    import yaml
+    cands = (os.path.splitext(model_filename)[0] + ".yaml",) + tuple(YAML_NAMES.get(model_filename, ()))
+    for name in cands:
+        path = os.path.join(model_file_dir, name)
+        if os.path.isfile(path):
+            with open(path) as f:
+                return yaml.load(f, Loader=_yaml_loader()) or {}
+    logger.warning("%s: no hyper-parameter file (%s) under %s -- using the roster's values; a checkpoint trained with other values is "
+                   "rejected by the shape check", model_filename, " / ".join(cands), model_file_dir)
+    return None
 
 
 class _ModelInstance:
@@ -297,10 +336,8 @@ class Separator:
         mask_estimator_depth / mlp_expansion_factor; audio: chunk_size; inference: num_overlap) overrides the roster's hyper-parameters."""
         import dataclasses
         cfg, opts = entry[1], (entry[2] if len(entry) > 2 else {})
-        ypath = os.path.join(self.model_file_dir, os.path.splitext(model_filename)[0] + ".yaml")
-        if os.path.isfile(ypath):
-            import yaml
-            y = yaml.safe_load(open(ypath)) or {}
+        y = load_model_yaml(self.model_file_dir, model_filename)
+        if y is not None:
             m, over = y.get("model", {}) or {}, {}
             for src, dst in (("dim", "dim"), ("depth", "depth"), ("heads", "heads"), ("dim_head", "dim_head"), ("num_bands", "num_bands"),
                              ("num_stems", "num_stems"), ("stft_n_fft", "n_fft"), ("stft_hop_length", "hop"),
@@ -342,10 +379,8 @@ class Separator:
         import dataclasses
         cfg, opts = entry[1], (entry[2] if len(entry) > 2 else {})
         labels = tuple(opts.get("labels", tuple(n.capitalize() for n in cfg.instruments)))
-        ypath = os.path.join(self.model_file_dir, os.path.splitext(model_filename)[0] + ".yaml")
-        if os.path.isfile(ypath):
-            import yaml
-            y = yaml.safe_load(open(ypath)) or {}
+        y = load_model_yaml(self.model_file_dir, model_filename)
+        if y is not None:
             a, m, over = y.get("audio", {}) or {}, y.get("model", {}) or {}, {}
             for src, dst in (("n_fft", "n_fft"), ("hop_length", "hop"), ("dim_f", "dim_f"), ("chunk_size", "chunk_size")):
                 if src in a:

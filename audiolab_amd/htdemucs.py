@@ -74,6 +74,78 @@ class HTDemucsConfig:
         return [self.channels * self.growth ** i for i in range(self.depth)]
 
 
+def expected_shapes(cfg: HTDemucsConfig) -> Dict[str, Tuple[Tuple[int, ...], str]]:
+    """name -> (shape, hyper-parameter that fixes it) of every tensor an HTDemucs with this configuration reads (demucs' names)"""
+    exp: Dict[str, Tuple[Tuple[int, ...], str]] = {}
+    wch = f"channels={cfg.channels} / growth={cfg.growth} / depth={cfg.depth}"
+
+    def conv(p, cout, cin, *k, transposed=False, hyper=wch):
+        exp[p + ".weight"] = (((cin, cout) if transposed else (cout, cin)) + tuple(k), hyper)
+        exp[p + ".bias"] = ((cout,), hyper)
+
+    def norm(p, c, hyper=wch):
+        exp[p + ".weight"] = ((c,), hyper)
+        exp[p + ".bias"] = ((c,), hyper)
+
+    def dconv(p, c):
+        hidden = c // cfg.dconv_comp
+        hy = f"dconv_comp={cfg.dconv_comp} / dconv_depth={cfg.dconv_depth} / {wch}"
+        for d in range(cfg.dconv_depth):
+            q = f"{p}.layers.{d}"
+            conv(q + ".0", hidden, c, 3, hyper=hy)
+            norm(q + ".1", hidden, hy)
+            conv(q + ".3", 2 * c, hidden, 1, hyper=hy)
+            norm(q + ".4", 2 * c, hy)
+            exp[q + ".6.scale"] = ((c,), hy)
+
+    K, S = cfg.kernel_size, cfg.S
+    chin, chin_z = cfg.audio_channels, cfg.audio_channels * 2
+    src = f"sources ({S}) / audio_channels={cfg.audio_channels}"
+    for idx, chout in enumerate(cfg.widths()):
+        ke = 1 + 2 * cfg.context_enc
+        conv(f"encoder.{idx}.conv", chout, chin_z, K, 1, hyper=f"kernel_size={K} / {wch}")
+        conv(f"encoder.{idx}.rewrite", 2 * chout, chout, ke, ke, hyper=f"context_enc={cfg.context_enc} / {wch}")
+        dconv(f"encoder.{idx}.dconv", chout)
+        conv(f"tencoder.{idx}.conv", chout, chin, K, hyper=f"kernel_size={K} / {wch}")
+        conv(f"tencoder.{idx}.rewrite", 2 * chout, chout, ke, hyper=f"context_enc={cfg.context_enc} / {wch}")
+        dconv(f"tencoder.{idx}.dconv", chout)
+        if idx == 0:
+            chin, chin_z = cfg.audio_channels * S, cfg.audio_channels * S * 2
+        di = cfg.depth - 1 - idx
+        kd = 1 + 2 * cfg.context
+        hy = src if idx == 0 else wch
+        conv(f"decoder.{di}.conv_tr", chin_z, chout, K, 1, transposed=True, hyper=f"kernel_size={K} / {hy}")
+        conv(f"decoder.{di}.rewrite", 2 * chout, chout, kd, kd, hyper=f"context={cfg.context} / {wch}")
+        conv(f"tdecoder.{di}.conv_tr", chin, chout, K, transposed=True, hyper=f"kernel_size={K} / {hy}")
+        conv(f"tdecoder.{di}.rewrite", 2 * chout, chout, kd, hyper=f"context={cfg.context} / {wch}")
+        chin = chin_z = chout
+    exp["freq_emb.embedding.weight"] = ((cfg.nfft // 2 // cfg.stride, cfg.channels), f"nfft={cfg.nfft} / stride={cfg.stride} / channels={cfg.channels}")
+    cb, cd = cfg.widths()[-1], cfg.bottom_channels
+    bc = f"bottom_channels={cd}"
+    for name, (co, ci) in {"channel_upsampler": (cd, cb), "channel_upsampler_t": (cd, cb), "channel_downsampler": (cb, cd),
+                           "channel_downsampler_t": (cb, cd)}.items():
+        conv(name, co, ci, 1, hyper=f"{bc} / {wch}")
+    p = "crosstransformer"
+    norm(p + ".norm_in", cd, bc)
+    norm(p + ".norm_in_t", cd, bc)
+    hidden = int(cd * cfg.t_hidden_scale)
+    th = f"{bc} / t_hidden_scale={cfg.t_hidden_scale} / t_layers={cfg.t_layers}"
+    for branch in ("layers", "layers_t"):
+        for idx in range(cfg.t_layers):
+            q = f"{p}.{branch}.{idx}"
+            att = "self_attn" if idx % 2 == 0 else "cross_attn"
+            exp[f"{q}.{att}.in_proj_weight"] = ((3 * cd, cd), th)
+            exp[f"{q}.{att}.in_proj_bias"] = ((3 * cd,), th)
+            conv(f"{q}.{att}.out_proj", cd, cd, hyper=th)
+            conv(f"{q}.linear1", hidden, cd, hyper=th)
+            conv(f"{q}.linear2", cd, hidden, hyper=th)
+            for n in ("norm1", "norm2") + (("norm3",) if idx % 2 else ()) + ("norm_out",):
+                norm(f"{q}.{n}", cd, th)
+            for gname in ("gamma_1", "gamma_2"):
+                exp[f"{q}.{gname}.scale"] = ((cd,), th)
+    return exp
+
+
 class _Conv:
     """weights of one convolution / linear in the layout alsep_nn_conv2d reads: [KH][KW][Cin][Cout], scale 1, shift = bias"""
 
@@ -94,6 +166,10 @@ class HTDemucs:
             raise AlsepError("HTDemucs: bottom_channels must be divisible by the head count")
         sd = state_dict
         dev = self.ctx.device
+        from .roformer import check_shapes
+        check_shapes(sd, expected_shapes(cfg), "HTDemucs",
+                     ((f"encoder.{cfg.depth}.", f"depth={cfg.depth}"), (f"crosstransformer.layers.{cfg.t_layers}.", f"t_layers={cfg.t_layers}"),
+                      ("encoder.0.dconv.layers.%d." % cfg.dconv_depth, f"dconv_depth={cfg.dconv_depth}")))
         try:
             self._build(sd)
         except KeyError as e:

@@ -49,6 +49,51 @@ class MDX23CConfig:
         return self.num_subbands * 2 * 2
 
 
+def expected_shapes(cfg: MDX23CConfig) -> Dict[str, Tuple[Tuple[int, ...], str]]:
+    """name -> (shape, hyper-parameter that fixes it) of every tensor an MDX23C with this configuration reads (tfc_tdf_v3 names)"""
+    exp: Dict[str, Tuple[Tuple[int, ...], str]] = {}
+    ch = f"num_channels={cfg.num_channels} / growth={cfg.growth}"
+
+    def norm(p, c, hyper=ch):
+        exp[p + ".weight"] = ((c,), hyper)
+        exp[p + ".bias"] = ((c,), hyper)
+
+    def tfc_tdf(p, in_c, c, f):
+        fh = f"audio.dim_f={cfg.dim_f} / num_subbands={cfg.num_subbands} / bottleneck_factor={cfg.bottleneck_factor} (TDF width {f})"
+        for i in range(cfg.num_blocks_per_scale):
+            q = f"{p}.blocks.{i}"
+            norm(q + ".tfc1.0", in_c)
+            exp[q + ".tfc1.2.weight"] = ((c, in_c, 3, 3), ch)
+            norm(q + ".tdf.0", c)
+            exp[q + ".tdf.2.weight"] = ((f // cfg.bottleneck_factor, f), fh)
+            norm(q + ".tdf.3", c)
+            exp[q + ".tdf.5.weight"] = ((f, f // cfg.bottleneck_factor), fh)
+            norm(q + ".tfc2.0", c)
+            exp[q + ".tfc2.2.weight"] = ((c, c, 3, 3), ch)
+            exp[q + ".shortcut.weight"] = ((c, in_c, 1, 1), ch)
+            in_c = c
+
+    c, gr, f = cfg.num_channels, cfg.growth, cfg.dim_f // cfg.num_subbands
+    exp["first_conv.weight"] = ((c, cfg.dim_c, 1, 1), f"num_channels={cfg.num_channels} / num_subbands={cfg.num_subbands}")
+    for i in range(cfg.num_scales):
+        tfc_tdf(f"encoder_blocks.{i}.tfc_tdf", c, c, f)
+        norm(f"encoder_blocks.{i}.downscale.conv.0", c)
+        exp[f"encoder_blocks.{i}.downscale.conv.2.weight"] = ((c + gr, c, 2, 2), ch)
+        f //= 2
+        c += gr
+    tfc_tdf("bottleneck_block", c, c, f)
+    for i in range(cfg.num_scales):
+        norm(f"decoder_blocks.{i}.upscale.conv.0", c)
+        exp[f"decoder_blocks.{i}.upscale.conv.2.weight"] = ((c, c - gr, 2, 2), ch)
+        f *= 2
+        c -= gr
+        tfc_tdf(f"decoder_blocks.{i}.tfc_tdf", 2 * c, c, f)
+    exp["final_conv.0.weight"] = ((c, c + cfg.dim_c, 1, 1), ch)
+    exp["final_conv.2.weight"] = ((cfg.num_stems * cfg.dim_c, c, 1, 1),
+                                  f"training.instruments ({cfg.num_stems} stems) / num_subbands={cfg.num_subbands}")
+    return exp
+
+
 class _W:
     """[KH][KW][Cin][Cout] convolution weights (no bias anywhere in this network)"""
 
@@ -69,6 +114,11 @@ class MDX23C:
         self.ctx = ctx if ctx is not None else _lib.default_context(None)
         self.dtype = torch.float32
         sd, dev = state_dict, self.ctx.device
+        from .roformer import check_shapes
+        check_shapes(sd, expected_shapes(cfg), "MDX23C",
+                     ((f"encoder_blocks.{cfg.num_scales}.", f"num_scales={cfg.num_scales}"),
+                      (f"decoder_blocks.{cfg.num_scales}.", f"num_scales={cfg.num_scales}"),
+                      ("encoder_blocks.0.tfc_tdf.blocks.%d." % cfg.num_blocks_per_scale, f"num_blocks_per_scale={cfg.num_blocks_per_scale}")))
         v = lambda k: sd[k].detach().float().contiguous().to(dev)
 
         def conv(k):                      # Conv2d [Cout, Cin, KH, KW] over (T, F) -> H = T, W = F

@@ -94,6 +94,62 @@ def band_indices(cfg: RoformerConfig) -> List[np.ndarray]:
     return [(f[:, None] * 2 + np.arange(2)[None]).reshape(-1) for f in per_f]
 
 
+def check_shapes(sd: Dict[str, torch.Tensor], expected: Dict[str, Tuple[Tuple[int, ...], str]], family: str,
+                 forbidden_prefixes: Tuple[Tuple[str, str], ...] = ()) -> None:
+    """Every tensor of ``expected`` {name: (shape, hyper-parameter that fixes it)} must be in ``sd`` with exactly that shape, and no key
+    may start with one of ``forbidden_prefixes`` [(prefix, hyper-parameter)] -- e.g. ``layers.{depth}.`` for a checkpoint deeper than
+    the configuration.  The kernels take strides and buffer sizes from the configuration, never from the tensors: a checkpoint whose
+    hyper-parameters differ from it would read out of bounds or run a truncated network.  Raises AlsepError naming the hyper-parameter
+    (the key of the model's ``.yaml`` that overrides the roster value)."""
+    for prefix, hyper in forbidden_prefixes:
+        extra = next((k for k in sd if k.startswith(prefix)), None)
+        if extra is not None:
+            raise AlsepError(f"{family}: the checkpoint holds '{extra}', beyond the configured {hyper} -- the configuration would silently "
+                             f"drop it (set {hyper.split('=')[0].strip()} in the model's .yaml beside the weights)")
+    for name, (shape, hyper) in expected.items():
+        t = sd.get(name)
+        if t is None:
+            raise AlsepError(f"{family}: state_dict is missing '{name}' (configuration value: {hyper})")
+        if tuple(t.shape) != tuple(shape):
+            raise AlsepError(f"{family}: '{name}' has shape {tuple(t.shape)}, the configuration expects {tuple(shape)} -- "
+                             f"hyper-parameter mismatch: {hyper} (set it in the model's .yaml beside the weights)")
+
+
+def expected_shapes(cfg: "RoformerConfig") -> Dict[str, Tuple[Tuple[int, ...], str]]:
+    """name -> (shape, hyper-parameter) of every tensor a Roformer with this configuration reads"""
+    exp: Dict[str, Tuple[Tuple[int, ...], str]] = {}
+    bands = band_indices(cfg)
+    inner, hidden = cfg.heads * cfg.dim_head, cfg.dim * cfg.mlp_expansion_factor
+    layout = f"band layout ({'freqs_per_bands' if cfg.kind == 'bs' else 'num_bands / sample_rate / stft_n_fft'})"
+    for i, idx in enumerate(bands):
+        w = 2 * len(idx)
+        exp[f"band_split.to_features.{i}.0.gamma"] = ((w,), layout)
+        exp[f"band_split.to_features.{i}.1.weight"] = ((cfg.dim, w), f"dim={cfg.dim} / {layout}")
+        exp[f"band_split.to_features.{i}.1.bias"] = ((cfg.dim,), f"dim={cfg.dim}")
+    for li in range(cfg.depth):
+        for tr in (0, 1):
+            p = f"layers.{li}.{tr}.layers.0"
+            exp[p + ".0.norm.gamma"] = ((cfg.dim,), f"dim={cfg.dim} (depth={cfg.depth})")
+            exp[p + ".0.to_qkv.weight"] = ((3 * inner, cfg.dim), f"heads={cfg.heads} x dim_head={cfg.dim_head}, dim={cfg.dim}")
+            exp[p + ".0.to_gates.weight"] = ((cfg.heads, cfg.dim), f"heads={cfg.heads}")
+            exp[p + ".0.to_gates.bias"] = ((cfg.heads,), f"heads={cfg.heads}")
+            exp[p + ".0.to_out.0.weight"] = ((cfg.dim, inner), f"heads={cfg.heads} x dim_head={cfg.dim_head}")
+            exp[p + ".1.net.0.gamma"] = ((cfg.dim,), f"dim={cfg.dim}")
+            exp[p + ".1.net.1.weight"] = ((4 * cfg.dim, cfg.dim), f"dim={cfg.dim} (feed-forward factor 4)")
+            exp[p + ".1.net.1.bias"] = ((4 * cfg.dim,), f"dim={cfg.dim}")
+            exp[p + ".1.net.4.weight"] = ((cfg.dim, 4 * cfg.dim), f"dim={cfg.dim}")
+            exp[p + ".1.net.4.bias"] = ((cfg.dim,), f"dim={cfg.dim}")
+    exp["final_norm.gamma"] = ((cfg.dim,), f"dim={cfg.dim}")
+    for s_ in range(cfg.num_stems):
+        for i, idx in enumerate(bands):
+            dims = (cfg.dim,) + (hidden,) * (cfg.mask_estimator_depth - 1) + (4 * len(idx),)
+            for j in range(cfg.mask_estimator_depth):
+                hyper = f"mask_estimator_depth={cfg.mask_estimator_depth}, mlp_expansion_factor={cfg.mlp_expansion_factor}, {layout}"
+                exp[f"mask_estimators.{s_}.to_freqs.{i}.0.net.{2 * j}.weight"] = ((dims[j + 1], dims[j]), hyper)
+                exp[f"mask_estimators.{s_}.to_freqs.{i}.0.net.{2 * j}.bias"] = ((dims[j + 1],), hyper)
+    return exp
+
+
 class _Lin:
     def __init__(self, ctx: Context, w: torch.Tensor, b: Optional[torch.Tensor]):
         self.out, self.inp = (int(v) for v in w.shape)
@@ -109,6 +165,11 @@ class Roformer:
         sd = state_dict
         dev = self.ctx.device
         bands = band_indices(cfg)
+        check_shapes(sd, expected_shapes(cfg), f"Roformer ({cfg.kind})",
+                     ((f"layers.{cfg.depth}.", f"depth={cfg.depth}"), (f"mask_estimators.{cfg.num_stems}.", f"num_stems={cfg.num_stems}"),
+                      (f"band_split.to_features.{len(bands)}.", f"number of bands={len(bands)}"),
+                      *((f"mask_estimators.{s_}.to_freqs.0.0.net.{2 * cfg.mask_estimator_depth}.", f"mask_estimator_depth={cfg.mask_estimator_depth}")
+                        for s_ in range(cfg.num_stems))))
         self.nb = len(bands)
         self.band_len = [len(b) for b in bands]
         self.band_off = np.concatenate([[0], np.cumsum(self.band_len)]).astype(np.int64)      # offsets in merged-index entries

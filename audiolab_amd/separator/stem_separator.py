@@ -4,14 +4,11 @@ stem labels and progress protocol as the reference's ``modules/separator/stem_se
 ``EnsembleDemucsMDXMusicSeparationModel`` :82-840), with the arithmetic on the GPU and tensors
 resident in HBM between stages (no temp PCM16 WAV per model, :57-75 / :278).
 
-Roster differences (the build owns its roster; all weights are synthetic offline): the vocal
-ensemble is the reference's MDX-Net members (:384-386); the multistem stage uses the 4-stem MDX-Net set instead of
-htdemucs_6s (:466) and therefore yields drums/bass/other (no guitar/piano).  Every other stage of the reference --
-reverb / echo / crowd / noise transform chain (:777-840), BG-vocal split (:737-775), drum-kit split (:534-587), woodwinds
-(:589-623) -- is built with the reference's stage order, label matching, residual-subtract bookkeeping and progress
-accounting; it RUNS when the engine's roster knows the model file the reference names for it (the default roster knows the
-MDX-Net ones, e.g. ``UVR-MDX-NET_Crowd_HQ_1.onnx``; Roformer / MDX23C / VR architectures have no kernels yet -- SURVEY 8(f)
--- so those files are absent from it and their stages are skipped with a log line instead of failing the whole job).
+Roster (the build owns its roster; weights are synthetic offline unless the files are present): every stage of the
+reference has kernels behind it -- the vocal ensemble in the reference's member order (Mel-Band / BS Roformer, MDX23C, MDX-Net; :379-387),
+htdemucs_6s for the multistem stage (:466), the reverb / echo / crowd / noise transform chain (:777-840), the drum-kit split (:534-587), the
+woodwinds split (:589-623) and the reverb impulse-response extraction (:822-829, audiolab_amd/reverb.py).  A stage whose model file is not in
+the engine's roster (a caller-supplied roster may be narrower) is skipped with a log line instead of failing the whole job.
 """
 from __future__ import annotations
 
@@ -32,19 +29,22 @@ logger = logging.getLogger(__name__)
 
 
 def ensure_wav(input_path: str, sr: int = 44100) -> str:
-    """:31-54 -- non-WAV inputs are transcoded by ffmpeg to pcm_s16le stereo (if ffmpeg exists)."""
+    """Path of a WAV rendition of ``input_path`` (:31-54): a ``.wav`` is returned as it is; anything else is transcoded ONCE to
+    ``<name>_converted.wav`` (16-bit stereo at ``sr``) by ffmpeg, and that file is reused on later calls."""
     if not os.path.exists(input_path):
         raise FileNotFoundError(f"Missing file: {input_path}")
-    base, ext = os.path.splitext(input_path)
-    if ext.lower() == ".wav":
+    stem, suffix = os.path.splitext(input_path)
+    if suffix.lower() == ".wav":
         return input_path
-    out_wav = base + "_converted.wav"
-    if not os.path.isfile(out_wav):
-        if shutil.which("ffmpeg") is None:
-            raise RuntimeError(f"{input_path}: only WAV input is supported without ffmpeg")
-        cmd = ["ffmpeg", "-y", "-i", input_path, "-acodec", "pcm_s16le", "-ac", "2", "-ar", str(sr), out_wav]
-        subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    return out_wav
+    target = f"{stem}_converted.wav"
+    if os.path.isfile(target):
+        return target
+    ffmpeg = shutil.which("ffmpeg")
+    if ffmpeg is None:
+        raise RuntimeError(f"{input_path}: only WAV input is supported without ffmpeg")
+    subprocess.run([ffmpeg, "-y", "-i", input_path, "-acodec", "pcm_s16le", "-ac", "2", "-ar", str(sr), target],
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return target
 
 
 def _call_progress(callback, frac: float, desc: str, total: int) -> None:
@@ -149,36 +149,36 @@ class EnsembleDemucsMDXMusicSeparationModel:
     DRUM_MODEL = "MDX23C-DrumSep-aufr33-jarredou.ckpt"                      # :541
     WOODWIND_MODEL = "17_HP-Wind_Inst-UVR.pth"                              # :596
 
-    @staticmethod
-    def _should_apply_transform(stem_name: str, setting: str) -> bool:
-        """:680-699."""
-        if setting == "Nothing":
-            return False
-        if setting == "All":
-            return True
-        if setting == "All Vocals":
-            return "vocals)" in stem_name.lower()
-        if setting == "Main Vocals":
-            return "vocals)" in stem_name and "(bg_vocals" not in stem_name.lower()
-        return False
+    # which stems a transform setting covers (:680-699): "All Vocals" matches any "...vocals)" tag case-insensitively, "Main Vocals" the
+    # lead only -- case-SENSITIVELY on "vocals)" as the reference tests it, so the "(Vocals)" file tag does not match but the lower-case
+    # stem labels this engine passes do
+    _SCOPE_TESTS = {
+        "All": lambda tag: True,
+        "All Vocals": lambda tag: "vocals)" in tag.lower(),
+        "Main Vocals": lambda tag: "vocals)" in tag and "(bg_vocals" not in tag.lower(),
+    }
 
-    @staticmethod
-    def _rename_file(base_in: str, filepath: str) -> str:
-        """:702-735 -- the name a transformed stem file gets (model references stripped from the parenthesised tags).
-        The in-memory path writes no intermediate files, so nothing is renamed on disk; the function is kept for the
-        callers that build names."""
+    @classmethod
+    def _should_apply_transform(cls, stem_name: str, setting: str) -> bool:
+        test = cls._SCOPE_TESTS.get(setting)                 # "Nothing" and unknown settings apply to no stem
+        return bool(test and test(stem_name))
+
+    # model references that the reference strips from the parenthesised tags of a transformed stem's file name (:713-727)
+    _MODEL_TAGS = tuple(t.lower() for t in (
+        "deverb_bs_roformer", "UVR-DeEcho-DeReverb", "UVR-De-Echo-Normal", "UVR-DeNoise", "UVR-DeNoise-Lite", "mel_band_roformer", "MDX23C",
+        "UVR-MDX-NET", "drumsep", "roformer", "viperx", "crowd", "karaoke", "instrumental", "_InstVoc", "_VOCFT", "NoReverb", "NoEcho",
+        "NoDelay", "NoCrowd", "NoNoise", "_mel_band_roformer_karaoke_aufr33_viperx_sdr_10"))
+
+    @classmethod
+    def _rename_file(cls, base_in: str, filepath: str) -> str:
+        """:702-735 -- the name a transformed stem gets: ``<input base>_`` + the parenthesised tags of ``filepath`` that name no model.
+        The in-memory path writes no intermediate files, so nothing is renamed on disk; kept for callers that build names."""
         import re
-        dirname = os.path.dirname(filepath)
-        ext = os.path.splitext(filepath)[1]
-        base_only = os.path.splitext(os.path.basename(base_in))[0]
-        all_parens = re.findall(r"\([^)]*\)", os.path.basename(filepath))
-        to_strip = ["deverb_bs_roformer", "UVR-DeEcho-DeReverb", "UVR-De-Echo-Normal", "UVR-DeNoise", "UVR-DeNoise-Lite",
-                    "mel_band_roformer", "MDX23C", "UVR-MDX-NET", "drumsep", "roformer", "viperx", "crowd", "karaoke",
-                    "instrumental", "_InstVoc", "_VOCFT", "NoReverb", "NoEcho", "NoDelay", "NoCrowd", "NoNoise",
-                    "_mel_band_roformer_karaoke_aufr33_viperx_sdr_10"]
-        filtered = [g for g in all_parens if not any(p.lower() in g.lower() for p in to_strip)]
-        final_name = (base_only + "_" + "".join(filtered) + ext).replace(") (", ")(").replace("__", "_")
-        return os.path.join(dirname, final_name)
+        folder, name = os.path.split(filepath)
+        tags = [t for t in re.findall(r"\([^)]*\)", name) if not any(m in t.lower() for m in cls._MODEL_TAGS)]
+        stem = os.path.splitext(os.path.basename(base_in))[0]
+        new_name = f"{stem}_{''.join(tags)}{os.path.splitext(name)[1]}".replace(") (", ")(").replace("__", "_")
+        return os.path.join(folder, new_name)
 
     def _have(self, model_file: str, what: str) -> bool:
         if model_file in self.separator.roster:
@@ -195,9 +195,12 @@ class EnsembleDemucsMDXMusicSeparationModel:
         tag = os.path.splitext(model_file)[0]
         return [(f"tmp_(%s)_%s.wav" % (label, tag), t) for label, t in outs.items()]
 
-    def _apply_transform_chain(self, stem: torch.Tensor, base_name: str, stem_label: str, skip_transforms=None) -> torch.Tensor:
+    def _apply_transform_chain(self, stem: torch.Tensor, base_name: str, stem_label: str, skip_transforms=None,
+                               output_folder: Optional[str] = None, sr: int = 44100) -> torch.Tensor:
         """:777-840.  Output selection as the reference: with two outputs the one whose name contains the wanted label
-        (spaces removed, lower case) -- else the SECOND one; otherwise the first match, or the input unchanged."""
+        (spaces removed, lower case) -- else the SECOND one; otherwise the first match, or the input unchanged.  After a de-reverb /
+        de-echo transform on the vocals with ``store_reverb_ir``, the impulse response between the chosen (dry) and the other (wet)
+        output is extracted into ``<output_folder>/impulse_response.ir`` (:822-829); a failure there is logged, not raised, as :828-829."""
         skip_transforms = skip_transforms or []
         chain = [(self.REVERB_MODEL, "No Reverb", self.reverb_removal), (self.delay_removal_model, "dry", self.echo_removal),
                  (self.crowd_removal_model, "No Crowd", self.crowd_removal), (self.noise_removal_model, "No Noise", self.noise_removal)]
@@ -210,9 +213,16 @@ class EnsembleDemucsMDXMusicSeparationModel:
                 want = out_label.replace(" ", "").lower()
                 chosen = None
                 if len(outs) == 2:
-                    chosen = outs[0][1] if want in outs[0][0].replace(" ", "").lower() else outs[1][1]
-                    if out_label in ("No Echo", "No Reverb") and stem_label.lower() == "vocals" and self.store_reverb_ir:
-                        logger.info("reverb impulse-response extraction (handlers/reverb.py:112-172) is not part of this build")
+                    first = want in outs[0][0].replace(" ", "").lower()
+                    chosen, alt = (outs[0][1], outs[1][1]) if first else (outs[1][1], outs[0][1])
+                    if out_label in ("No Echo", "No Reverb") and stem_label.lower() == "vocals" and self.store_reverb_ir and output_folder:
+                        try:
+                            from audiolab_amd.reverb import extract_reverb
+                            out_ir = os.path.join(output_folder, "impulse_response.ir")
+                            logger.info(f"Extracting reverb IR for {base_name}")
+                            extract_reverb(chosen, alt, out_ir, sr=sr, ctx=self.ctx)
+                        except Exception as e:                       # the reference logs and carries on (:828-829)
+                            logger.error(f"Error extracting IR: {e}")
                 else:
                     for name, t in outs:
                         if want in name.replace(" ", "").lower():
@@ -403,7 +413,7 @@ def predict_with_model(options: Dict, callback: Callable = None, separator: Opti
     if model.reverb_removal != "Nothing":
         for base_name, res in results.items():
             if res.get("vocals") is not None:
-                res["vocals"] = model._apply_transform_chain(res["vocals"], base_name, "vocals")
+                res["vocals"] = model._apply_transform_chain(res["vocals"], base_name, "vocals", output_folder=res["output_folder"], sr=res["sr"])
     if model.separate_bg_vocals:
         for base_name, res in results.items():
             if res.get("vocals") is not None:
@@ -414,9 +424,11 @@ def predict_with_model(options: Dict, callback: Callable = None, separator: Opti
     if any(o != "Nothing" for o in (model.crowd_removal, model.noise_removal)):
         for base_name, res in results.items():
             if res.get("vocals") is not None:
-                res["vocals"] = model._apply_transform_chain(res["vocals"], base_name, "vocals", skip_transforms=["No Reverb"])
+                res["vocals"] = model._apply_transform_chain(res["vocals"], base_name, "vocals", skip_transforms=["No Reverb"],
+                                                             output_folder=res["output_folder"], sr=res["sr"])
             if res.get("instrumental") is not None:
-                res["instrumental"] = model._apply_transform_chain(res["instrumental"], base_name, "instrumental")
+                res["instrumental"] = model._apply_transform_chain(res["instrumental"], base_name, "instrumental",
+                                                                   output_folder=res["output_folder"], sr=res["sr"])
     if not model.vocals_only:
         model._multistem_separation_all(results)
         if model.alt_bass_model:

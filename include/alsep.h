@@ -48,6 +48,9 @@ typedef struct alsep_plan alsep_plan;     /* STFT geometry + twiddle/envelope ta
 typedef struct alsep_net alsep_net;       /* packed TFC-TDF U-Net weights */
 
 int alsep_abi_version(void);
+/* 1 when the library was compiled with -DALSEP_EXPERIMENTS (timing-experiment switches and superseded kernel variants present);
+ * the product build returns 0: no environment variable can then change what is computed. */
+int alsep_experiments_enabled(void);
 
 /* ctx: replaces device selection at modules/separator/stem_separator.py:99-100. */
 int alsep_create(int device_id, void* hip_stream, alsep_ctx** out);
@@ -324,6 +327,32 @@ int alsep_vr_mirror(alsep_ctx* ctx, const float* spec_m, const float* he, float*
  * at [e0, e0+eh) (NULL: none), all times gain[f] (the low-pass / high-pass ramps and zeroed ranges), zero elsewhere; band [4, Fb, l] */
 int alsep_vr_band_spec(alsep_ctx* ctx, const float* spec_m, const float* extra, const float* gain, float* band, int bins, int l, int Fb, int f0,
                        int h, int o0, int e0, int eh);
+
+/* ---- reverb impulse-response extraction: replaces handlers/reverb.py:112-172 (extract_reverb), called from
+ * modules/separator/stem_separator.py:822-829 when a de-reverb transform ran on the vocals with store_reverb_ir.  Whole-track FFT work in
+ * double precision (csrc/reverb.hip).  Audio arguments: float32 device tensors [channels][n] with row stride ld; the mono signals are
+ * np.mean over the channels as reverb.py:52-53.  All functions need a workspace of alsep_reverb_workspace_bytes(n_wet, n_dry) bytes
+ * (-1: a signal is too long, > 2^27 transform points). */
+int64_t alsep_reverb_workspace_bytes(int64_t n_wet, int64_t n_dry);
+/* fft_xcorr (reverb.py:55-66) + np.argmax over its n_wet + n_dry - 1 entries (:130-131) -> *argmax_out (host).  Optionally the
+ * correlation values at probe_idx[0 .. n_probe) (host indices) -> probe_out (host), for tests.  Synchronises the stream. */
+int alsep_reverb_xcorr_argmax(alsep_ctx* ctx, const float* wet, int c_wet, int64_t n_wet, int64_t ld_wet, const float* dry, int c_dry,
+                              int64_t n_dry, int64_t ld_dry, void* ws, int64_t ws_bytes, int64_t* argmax_out, double* probe_out,
+                              const int64_t* probe_idx, int n_probe);
+/* wiener_deconvolution(wet_mono, dry_mono, eps)[:n_out] (reverb.py:94-106, :142-143) -> ir_out (device, float64); the deconvolution has
+ * 2 * (n_wet / 2) samples (np.fft.irfft's default length), *n_written (host) = min(n_out, that). */
+int alsep_reverb_wiener_ir(alsep_ctx* ctx, const float* wet, int c_wet, int64_t n_wet, int64_t ld_wet, const float* dry, int c_dry,
+                           int64_t n_dry, int64_t ld_dry, double eps, void* ws, int64_t ws_bytes, double* ir_out, int64_t n_out,
+                           int64_t* n_written);
+/* the curve estimate_rt60 fits (reverb.py:74-81), in its float32 arithmetic: 20 log10(sqrt(sum_c x^2) + 1e-10) -> out [n] (device) */
+int alsep_reverb_envelope_db(alsep_ctx* ctx, const float* x, int c, int64_t n, int64_t ld, float* out);
+/* |np.fft.rfft(x)| of a real float64 device signal of any length n (spectral centroid, reverb.py:155-157) -> mag_out [n / 2 + 1];
+ * workspace: (2 n) * 16 + alsep_dft_f64_workspace_bytes(n) bytes */
+int alsep_rfft_mag_f64(alsep_ctx* ctx, const double* x, int64_t n, void* ws, int64_t ws_bytes, double* mag_out);
+/* complex DFT of any length n <= 2^27 on interleaved float64 (re, im) device data, unnormalised (inverse != 0: the conjugate kernel);
+ * in != out; workspace alsep_dft_f64_workspace_bytes(n) */
+int64_t alsep_dft_f64_workspace_bytes(int64_t n);
+int alsep_dft_f64(alsep_ctx* ctx, const double* in, double* out, int64_t n, int inverse, void* ws, int64_t ws_bytes);
 
 #ifdef __cplusplus
 }

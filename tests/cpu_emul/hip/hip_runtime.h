@@ -89,6 +89,8 @@ void wave_sync();
 }  // namespace emul
 
 static inline void __syncthreads() { emul::sync_block(); }
+// device math the host libm lacks
+static inline void sincospi(double x, double* s, double* c) { *s = std::sin(M_PI * x); *c = std::cos(M_PI * x); }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                       \
     do {                                                                                   \
