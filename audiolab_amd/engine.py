@@ -18,9 +18,10 @@ Multi-stem entries.  A roster value ``("multi", [(label, cfg), ...])`` describes
 network per label.
 
 MDX runner.  ``chunker="margin"`` (default): margin chunker + trim stitching exactly as the in-tree
-runner (mdxnet.py:109-197, pinned).  ``chunker="ola"``: Hann-window overlap-add with ``overlap`` and
-``compensate`` as the third-party MDXSeparator does (unpinned).  The secondary stem is
-``mix - primary`` in the time domain (mdxnet.py:211).
+runner (mdxnet.py:109-197, pinned); the secondary stem is ``mix - primary`` in the time domain (mdxnet.py:211).
+``chunker="ola"``: the third-party MDXSeparator's sequence (unpinned): normalisation to 0.9, Hann-window overlap-add with
+``overlap`` and ``compensate``, and -- with ``invert_using_spec`` -- the secondary stem by spectral inversion against the
+``is_match_mix`` rendition of the mix.
 """
 from __future__ import annotations
 
@@ -171,13 +172,16 @@ class Separator:
                  dtype: Optional[torch.dtype] = None, sample_rate: int = 44100, chunks: int = 0, margin: int = 44100,
                  denoise: bool = False, max_batch: int = 32, sharded: bool = False, roster: Optional[Dict[str, tuple]] = None,
                  chunker: str = "margin", overlap: float = 0.25, compensate: Optional[float] = None,
-                 allow_synthetic: bool = False, **_ignored):
+                 allow_synthetic: bool = False, normalization_threshold: float = 0.9, **_ignored):
         """``allow_synthetic=True`` (bench, tests): a roster name without a weight file gets seeded random-init weights.
         The default refuses to: a missing model file is an error, never plausible-looking noise."""
         self.log_level = log_level
         self.model_file_dir = model_file_dir
         self.output_dir = output_dir
-        self.invert_using_spec = invert_using_spec
+        # honoured by the audio-separator style runner (chunker="ola"): the secondary stem by spectral inversion; the in-tree runner
+        # (chunker="margin", mdxnet.py:211) has no such option and yields mix - primary
+        self.invert_using_spec = bool(invert_using_spec)
+        self.normalization = float(normalization_threshold or 0.0)
         self.use_autocast = use_autocast
         self.ctx = ctx if ctx is not None else _lib.default_context(None)
         # use_autocast=True is the reference's GPU setting (stem_separator.py:106): torch autocast on CUDA = IEEE half.  Measured at
@@ -293,12 +297,29 @@ class Separator:
         self.model_instance = inst
 
     def _load_demucs(self, model_filename: str, entry: tuple) -> None:
-        """("demucs", HTDemucsConfig, {shifts, overlap}): weights from ``<model_file_dir>/<name>.pt`` (a state_dict with demucs'
-        parameter names) or, with allow_synthetic, seeded random-init ones.  float32 (the kernels of this family are fp32)."""
+        """("demucs", HTDemucsConfig, {shifts, overlap}).  Weights, in this order: the files the reference has -- ``<dir>/<name>.yaml``
+        (demucs' bag-of-models list) pointing at ``<signature>-<checksum>.th`` (a pickled package: read by audiolab_amd.th_reader's
+        allow-list unpickler, hyper-parameters from its ``kwargs``, ``state`` as the weights); ``<dir>/<name>.pt`` (a plain state_dict with
+        demucs' parameter names); with allow_synthetic, seeded random-init ones.  float32 (the kernels of this family are fp32)."""
+        from . import th_reader
         cfg = entry[1]
         opts = entry[2] if len(entry) > 2 else {}
         pt = os.path.join(self.model_file_dir, model_filename + ".pt")
-        sd = self._weights_file(model_filename)
+        th_path = th_reader.resolve_demucs_yaml(self.model_file_dir, model_filename) if model_filename.endswith(".yaml") else None
+        if th_path is None and model_filename.endswith(".th") and os.path.isfile(os.path.join(self.model_file_dir, model_filename)):
+            th_path = os.path.join(self.model_file_dir, model_filename)
+        sd = None
+        if th_path is not None:
+            pkg = th_reader.read_th(th_path)
+            if pkg["klass"] != "HTDemucs":
+                raise AlsepError(f"{th_path}: a {pkg['klass']} package -- only HTDemucs is implemented")
+            cfg = th_reader.htdemucs_config_from_kwargs(pkg["kwargs"])
+            sd, weights = pkg["state"], "real"
+        else:
+            sd = self._weights_file(model_filename) if not model_filename.endswith(".yaml") else None
+            if sd is None and os.path.isfile(pt):
+                sd = torch.load(pt, map_location="cpu", weights_only=True)
+                sd = sd.get("state", sd) if isinstance(sd, dict) and isinstance(sd.get("state"), dict) else sd
         if sd is not None:
             weights = "real"
         elif self.allow_synthetic:
@@ -308,8 +329,8 @@ class Separator:
             logger.warning("%s: no weight file under %s -- SYNTHETIC random-init weights (allow_synthetic=True)", model_filename,
                            self.model_file_dir)
         else:
-            raise AlsepError(f"model '{model_filename}': no weight file ({pt}); random-init weights are only used with "
-                             f"Separator(allow_synthetic=True)")
+            raise AlsepError(f"model '{model_filename}': no weight file ({os.path.join(self.model_file_dir, model_filename)} naming a .th "
+                             f"package, or {pt}); random-init weights are only used with Separator(allow_synthetic=True)")
         net = HTDemucs(cfg, sd, ctx=self.ctx)
         inst = _ModelInstance(model_filename, net, None, cfg.sources[0].capitalize(), None)
         inst.demucs = DemucsRunner(net, shifts=int(opts.get("shifts", 2)), overlap=float(opts.get("overlap", 0.25)), sharded=self.sharded)
@@ -489,6 +510,8 @@ class Separator:
                 self.ctx.check(self.ctx.lib.alsep_axpby(self.ctx.handle, -1.0, _lib.ptr(first), 1.0, _lib.ptr(sec), sec.numel()), "alsep_axpby")
                 out[inst.secondary_stem_name] = sec
             return out
+        if self.chunker == "ola" and not inst.extra:
+            return self._separate_pair_ola(m, inst)
         primary = inst.predictor.demix(m)
         if primary.dim() == 3:                                  # Predictor returns [1,2,N] like the reference
             primary = primary[0]
@@ -501,6 +524,29 @@ class Separator:
         for label, _, pred in inst.extra:                       # multi-stem model: every further stem from the same input
             t = pred.demix(m)
             out[label] = t[0] if t.dim() == 3 else t
+        return out
+
+    def _separate_pair_ola(self, m: torch.Tensor, inst: "_ModelInstance") -> Dict[str, torch.Tensor]:
+        """``chunker="ola"``: the sequence of the third-party ``MDXSeparator.separate`` that AudioLab reaches at stem_separator.py:281
+        (upstream, uncited -- UNPINNED; restated in oracle/mdx_oracle.py ``separate_ola``): the mix is normalised to ``normalization``
+        (0.9: scaled down only if its peak is higher), the primary stem is the overlap-add of the model outputs, normalised the same
+        way; the secondary stem is, with ``invert_using_spec`` (AudioLab's setting, stem_separator.py:104), the spectral inversion of
+        the primary against the model-path rendition of the mix (the ``is_match_mix`` pass), else ``mix - primary``."""
+        from . import ensemble
+        mixn = ensemble.normalize(self.ctx, m.clone(), self.normalization) if self.normalization else m
+        primary = inst.predictor.demix(mixn)
+        if self.normalization:
+            primary = ensemble.normalize(self.ctx, primary, self.normalization)
+        out = {inst.primary_stem_name: primary}
+        if inst.secondary_stem_name:
+            if self.invert_using_spec:
+                raw_mix = inst.predictor.demix(mixn, match_mix=True)
+                out[inst.secondary_stem_name] = ensemble.invert_stem(self.ctx, raw_mix, primary)
+            else:
+                sec = mixn.clone()
+                self.ctx.check(self.ctx.lib.alsep_axpby(self.ctx.handle, -1.0, _lib.ptr(primary.contiguous()), 1.0, _lib.ptr(sec), sec.numel()),
+                               "alsep_axpby")
+                out[inst.secondary_stem_name] = sec
         return out
 
     def separate(self, audio_file_path: str) -> List[str]:

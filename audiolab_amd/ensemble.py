@@ -161,3 +161,46 @@ def resample(ctx: Context, x: torch.Tensor, sr_in: int, sr_out: int, zeros: int 
     ctx.check(ctx.lib.alsep_resample(ctx.handle, _lib.ptr(x), _lib.ptr(y), rows, n_in, n_out, sr_in, sr_out, zeros, rolloff, beta),
               "alsep_resample")
     return y
+
+
+def normalize(ctx: Context, x: torch.Tensor, max_peak: float = 0.9) -> torch.Tensor:
+    """audio-separator's ``spec_utils.normalize`` (upstream, uncited -- UNPINNED): a signal whose peak exceeds ``max_peak`` is scaled
+    down to it, a quieter one is left alone.  In place on the device (x *= max_peak / max(peak, max_peak)); returns x."""
+    x = _flat(x)
+    pk = peak_abs(ctx, x)
+    ctx.check(ctx.lib.alsep_scale_by_device(ctx.handle, _lib.ptr(x), x.numel(), float(max_peak), _lib.ptr(pk), float(max_peak)),
+              "alsep_scale_by_device")
+    return x
+
+
+_INVERT_PLANS: dict = {}
+
+
+def invert_stem(ctx: Context, mixture: torch.Tensor, stem: torch.Tensor, n_fft: int = 2048, hop: int = 1024) -> torch.Tensor:
+    """audio-separator's ``spec_utils.invert_stem`` (upstream, uncited -- UNPINNED), the secondary stem of an MDX model when the engine is
+    built with ``invert_using_spec=True`` as AudioLab builds it (stem_separator.py:104): both signals go through an n_fft 2048 / hop 1024
+    STFT, the spectrograms are subtracted, and the difference is transformed back.  [2, N] float32 device tensors -> [2, N].
+    One whole-track frame set per signal (centre-padded by reflection, as librosa): the track is zero-padded to a multiple of the hop for
+    the transform and cut back (upstream's inverse transform stops at the last full hop and pads the remainder with zeros)."""
+    from .mdx import StftPlan
+    a, b = _flat(mixture), _flat(stem)
+    if a.shape != b.shape or a.dim() != 2 or a.shape[0] != 2:
+        raise AlsepError("invert_stem expects two [2, N] tensors of the same length")
+    n = a.shape[1]
+    frames = -(-n // hop) + 1
+    key = (id(ctx), n_fft, hop, frames)
+    if key not in _INVERT_PLANS:
+        _INVERT_PLANS.clear()                                # one track length at a time: the tables of a 13 000-frame plan are not small
+        _INVERT_PLANS[key] = StftPlan(ctx, n_fft, hop, n_fft // 2 + 1, frames)
+    plan = _INVERT_PLANS[key]
+    length = plan.chunk_size                                 # hop * (frames - 1) >= n
+
+    def spec_of(x):
+        buf = ctx.zeros((2, length))
+        buf[:, :n] = x
+        return plan.stft_strided(buf, length, 2 * length, 1, torch.float32, _lib.LAYOUT_REF)
+    sa, sb = spec_of(a), spec_of(b)
+    ctx.check(ctx.lib.alsep_axpby(ctx.handle, -1.0, _lib.ptr(sb), 1.0, _lib.ptr(sa), sa.numel()), "alsep_axpby")      # sa -= sb
+    out = ctx.empty((2, length))
+    plan.istft_strided(sa, _lib.LAYOUT_REF, out, length, 2 * length, 0, length, length)
+    return out[:, :n].contiguous()

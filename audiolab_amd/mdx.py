@@ -290,15 +290,18 @@ class OlaRunner:
         self.overlap, self.zero_low_bins, self.compensate, self.denoise = overlap, zero_low_bins, compensate, denoise
         self.max_batch = max_batch
 
-    def demix(self, mix: torch.Tensor) -> torch.Tensor:
-        """mix [2,N] float32 on the device -> [2,N]."""
+    def demix(self, mix: torch.Tensor, match_mix: bool = False) -> torch.Tensor:
+        """mix [2,N] float32 on the device -> [2,N].  ``match_mix=True`` is the package's ``is_match_mix`` pass: the same framing
+        without the network at overlap 0.02 -- the mixture as the model path sees it (bins < 3 and >= dim_f removed), which
+        ``invert_using_spec`` subtracts the primary stem from."""
         plan, ctx = self.plan, self.ctx
         mix = mix.contiguous().float()
         n = mix.shape[-1]
         chunk, trim, gen = plan.chunk_size, plan.trim, plan.gen_size
         pad = gen + trim - (n % gen)
         total = trim + n + pad
-        step = int((1 - self.overlap) * chunk)
+        overlap = 0.02 if match_mix else self.overlap
+        step = int((1 - overlap) * chunk)
         n_chunks = (total + step - 1) // step
         buf_len = (n_chunks - 1) * step + chunk              # chunks cut by the end see zeros
         mixture = ctx.zeros((2, buf_len), torch.float32)
@@ -317,18 +320,19 @@ class OlaRunner:
             if self.zero_low_bins:
                 ctx.check(ctx.lib.alsep_zero_low_bins(ctx.handle, _lib.ptr(spek), _lib.dtype_code(spek.dtype), _lib.LAYOUT_NHWC,
                                                       nb, plan.dim_f, plan.dim_t, self.zero_low_bins), "alsep_zero_low_bins")
-            pred = self.net.forward_nhwc(spek, denoise=self.denoise)
+            pred = spek if match_mix else self.net.forward_nhwc(spek, denoise=self.denoise)
             plan.istft_strided(pred, _lib.LAYOUT_NHWC, waves, chunk, 2 * chunk, 0, chunk, (nb - 1) * 2 * chunk + chunk,
                                out_offset=(b0 - c_lo) * 2 * chunk)
         out = ctx.empty((2, n), torch.float32)
-        use_window = 1 if self.overlap != 0 else 0
+        use_window = 1 if overlap != 0 else 0
+        compensate = 1.0 if match_mix else float(self.compensate)
         if not self.sharded:
             ctx.check(ctx.lib.alsep_ola_combine(ctx.handle, _lib.ptr(waves), n_chunks, chunk, step, total, use_window,
-                                                float(self.compensate), _lib.ptr(out), n, trim, n), "alsep_ola_combine")
+                                                compensate, _lib.ptr(out), n, trim, n), "alsep_ola_combine")
             return out
         part = ctx.empty((3, n), torch.float32)
         ctx.check(ctx.lib.alsep_ola_partial(ctx.handle, _lib.ptr(waves), c_lo, c_hi, chunk, step, total, use_window, _lib.ptr(part),
                                             trim, n), "alsep_ola_partial")
         part = adist.all_reduce_partial(part, self.group)
-        ctx.check(ctx.lib.alsep_ola_finish(ctx.handle, _lib.ptr(part), float(self.compensate), _lib.ptr(out), n, n), "alsep_ola_finish")
+        ctx.check(ctx.lib.alsep_ola_finish(ctx.handle, _lib.ptr(part), compensate, _lib.ptr(out), n, n), "alsep_ola_finish")
         return out

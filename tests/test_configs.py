@@ -146,8 +146,9 @@ def test_config4_f16_ola075_48k_8ch_vs_storage_oracle(gpu_ctx, tmp_path):
     # oracle on the first and the last stereo pair (storage mode and fp32); the middle pairs are checked against the 2-channel path below
     for c0 in (0, 6):
         pair = mix8[c0:c0 + 2]
-        want_st = mo.demix_ola(pair, g, run_with(torch.float16), overlap=0.75, zero_low_bins=3, compensate=1.0, dtype=np.float32)
-        want_32 = mo.demix_ola(pair, g, run_with(None), overlap=0.75, zero_low_bins=3, compensate=1.0, dtype=np.float32)
+        # the engine's sequence in this mode (normalise to 0.9, overlap-add, spectral inversion for the secondary stem): oracle/mdx_oracle.separate_ola
+        want_st, _ = mo.separate_ola(pair, g, run_with(torch.float16), overlap=0.75, compensate=1.0)
+        want_32, sec_32 = mo.separate_ola(pair, g, run_with(None), overlap=0.75, compensate=1.0)
         r_st, r_32, r_oo = _rel(got["Vocals"][c0:c0 + 2], want_st), _rel(got["Vocals"][c0:c0 + 2], want_32), _rel(want_st, want_32)
         print(f"configs[4] channels {c0}-{c0 + 1}: vs f16-storage oracle rel L2 = {r_st:.3e}, vs fp32 oracle {r_32:.3e} "
               f"(SDR {-20 * np.log10(r_32):.1f} dB), storage oracle vs fp32 oracle {r_oo:.3e}, max|delta| vs fp32 oracle = "
@@ -155,7 +156,10 @@ def test_config4_f16_ola075_48k_8ch_vs_storage_oracle(gpu_ctx, tmp_path):
         # the yardstick of tests/test_gpu_parity.py::test_full_size_mdx_f16_vs_oracle: distance to the storage oracle below the cost of
         # the storage type itself, total error within 1.25 x of it, and an absolute bound on the f16 error against fp32
         assert r_st < 0.8 * r_oo and r_32 < 1.25 * r_oo and r_32 < 5e-2
-        assert np.max(np.abs(got["Instrumental"][c0:c0 + 2] - (pair - got["Vocals"][c0:c0 + 2]))) < 1e-6       # mdxnet.py:211
+        # secondary stem: the inversion is linear, so against the oracle's it carries the primary's error plus the f16 spectrogram of the
+        # match-mix pass; and it must be the inversion of the GPU's own primary to fp32 accuracy apart from that pass
+        r_sec = _rel(got["Instrumental"][c0:c0 + 2], sec_32)
+        assert r_sec < 1.25 * r_oo * np.linalg.norm(want_32) / np.linalg.norm(sec_32) + 2e-3, r_sec
     # every pair of the 8-channel run equals the same pair run alone through the 2-channel path (bit for bit: same kernels, same order)
     for c0 in (2, 4):
         alone = eng.separate_array(mix8[c0:c0 + 2])["Vocals"].cpu().numpy()
@@ -166,7 +170,7 @@ def test_config4_full_length_shift_property(gpu_ctx):
     """configs[4] at its stated length -- 60 min at 48 kHz, the bench-geometry network in f16, overlap 0.75 -- on one stereo pair:
     delaying the input by one chunk step (65 280 samples) moves every interior chunk one slot down the batch, so the interior of the
     output is the same signal delayed by the step.  (Needs ~12 GB of HBM; runs in ~10 s.)"""
-    eng = _longform_engine(gpu_ctx)
+    eng = _longform_engine(gpu_ctx, normalization_threshold=0.0)       # a peak-dependent gain would differ between the two runs' edge regions
     eng.max_batch = 32
     eng.load_model("longform_vocals.onnx")
     n = 3600 * 48000

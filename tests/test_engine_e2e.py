@@ -109,7 +109,19 @@ def test_multichannel_ola_075_vs_oracle(dev):
         assert set(out) == {"Drums", "No Drums"} and out["Drums"].shape == (channels, n)
         for c0 in range(0, channels, 2):
             pair = mix[c0:c0 + 2] if c0 + 2 <= channels else np.concatenate([mix[c0:c0 + 1]] * 2)
-            want = mo.demix_ola(pair, g, run, overlap=0.75, denoise=False, zero_low_bins=3, compensate=1.02)
+            want, want_sec = mo.separate_ola(pair, g, run, overlap=0.75, compensate=1.02)      # normalise 0.9, spectral inversion (engine defaults)
             k = min(2, channels - c0)
             assert np.max(np.abs(host(out["Drums"][c0:c0 + k]) - want[:k])) < 1e-4
-            assert np.max(np.abs(host(out["No Drums"][c0:c0 + k]) - (pair - want)[:k])) < 1e-4
+            assert np.max(np.abs(host(out["No Drums"][c0:c0 + k]) - want_sec[:k])) < 1e-4
+    # the two switches of that sequence: a loud mix is scaled down to 0.9 before the model sees it, and without invert_using_spec the
+    # secondary stem is the plain difference
+    loud = (mix[:2] * (1.5 / np.max(np.abs(mix[:2])))).astype(np.float32)
+    got = eng.separate_array(loud)
+    want, want_sec = mo.separate_ola(loud, g, run, overlap=0.75, compensate=1.02)
+    assert np.max(np.abs(host(got["Drums"]) - want)) < 1e-4 and np.max(np.abs(host(got["No Drums"]) - want_sec)) < 1e-4
+    plain = Separator(ctx=dev, use_autocast=False, allow_synthetic=True, roster=roster, max_batch=3, chunker="ola", overlap=0.75, compensate=1.02,
+                      invert_using_spec=False, normalization_threshold=0.0)
+    plain.load_model(name)
+    got = plain.separate_array(loud)
+    want = mo.demix_ola(loud, g, run, overlap=0.75, denoise=False, zero_low_bins=3, compensate=1.02)
+    assert np.max(np.abs(host(got["Drums"]) - want)) < 1e-4 and np.max(np.abs(host(got["No Drums"]) - (loud - want))) < 1e-4

@@ -75,3 +75,94 @@ def test_expected_shapes_cover_the_synthetic_state_dicts():
         sd = mod.synthetic_state_dict(cfg, 0)
         assert set(exp) == set(sd)
         assert all(tuple(sd[k].shape) == tuple(v[0]) for k, v in exp.items())
+
+
+def _write_th(path, cfg, sd, evil=False):
+    """a file as demucs.states.save_with_checksum writes it: a pickled package referring to demucs / omegaconf CLASSES -- made here with
+    stand-in modules of those names that exist only while the file is written"""
+    import fractions
+    import sys
+    import types
+    mods = {}
+    for name in ("demucs", "demucs.htdemucs", "omegaconf", "omegaconf.dictconfig"):
+        mods[name] = types.ModuleType(name)
+    HT = type("HTDemucs", (), {"__module__": "demucs.htdemucs"})
+    DC = type("DictConfig", (), {"__module__": "omegaconf.dictconfig", "__init__": lambda self, d=None: setattr(self, "content", d)})
+    mods["demucs.htdemucs"].HTDemucs = HT
+    mods["omegaconf.dictconfig"].DictConfig = DC
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    try:
+        kwargs = dict(sources=list(cfg.sources), channels=cfg.channels, growth=cfg.growth, nfft=cfg.nfft, depth=cfg.depth, dconv_comp=cfg.dconv_comp,
+                      bottom_channels=cfg.bottom_channels, t_layers=cfg.t_layers, t_heads=cfg.t_heads, samplerate=cfg.samplerate,
+                      segment=fractions.Fraction(cfg.segment_samples, cfg.samplerate), cac=True, wiener_iters=0)
+        pkg = {"klass": HT, "args": (), "kwargs": kwargs, "state": {k: v.half() for k, v in sd.items()}, "training_args": DC({"lr": 3e-4})}
+        if evil:
+            import os
+            pkg["extra"] = os.system                      # a global outside the allow-list
+        torch.save(pkg, path)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_demucs_th_package_is_read_without_importing_it(tmp_path):
+    from audiolab_amd import htdemucs as H, th_reader
+    cfg = H.HTDemucsConfig(sources=("drums", "bass", "other", "vocals"), channels=16, depth=2, nfft=256, bottom_channels=32, t_layers=3, t_heads=4,
+                           dconv_comp=4, segment_samples=2560, samplerate=4000)
+    sd = H.synthetic_state_dict(cfg, 3)
+    path = str(tmp_path / "5c90dfd2-34c22ccb.th")
+    _write_th(path, cfg, sd)
+    import sys
+    assert "demucs" not in sys.modules
+    with pytest.raises(Exception):
+        torch.load(path, map_location="cpu", weights_only=True)          # why a dedicated reader is needed at all
+    pkg = th_reader.read_th(path)
+    assert "demucs" not in sys.modules and pkg["klass"] == "HTDemucs"
+    got_cfg = th_reader.htdemucs_config_from_kwargs(pkg["kwargs"])
+    assert got_cfg == cfg
+    assert set(pkg["state"]) == set(sd) and all(v.dtype == torch.float32 for v in pkg["state"].values())
+    assert all(torch.equal(pkg["state"][k], sd[k].half().float()) for k in sd)
+    # the bag-of-models yaml the reference loads by name (stem_separator.py:466)
+    (tmp_path / "htdemucs_6s.yaml").write_text("models: ['5c90dfd2']\n")
+    assert th_reader.resolve_demucs_yaml(str(tmp_path), "htdemucs_6s.yaml") == path
+    (tmp_path / "htdemucs_ft.yaml").write_text("models: ['a', 'b', 'c', 'd']\nweights: [[1,0,0,0],[0,1,0,0],[0,0,1,0],[0,0,0,1]]\n")
+    with pytest.raises(AlsepError):
+        th_reader.resolve_demucs_yaml(str(tmp_path), "htdemucs_ft.yaml")
+    # an option this build does not implement is refused, not ignored
+    with pytest.raises(AlsepError):
+        th_reader.htdemucs_config_from_kwargs(dict(pkg["kwargs"], t_sparse_self_attn=True))
+    # a package that smuggles another global in is refused before anything runs
+    evil = str(tmp_path / "evil.th")
+    _write_th(evil, cfg, sd, evil=True)
+    with pytest.raises(AlsepError) as e:
+        th_reader.read_th(evil)
+    assert "not allowed" in str(e.value)
+
+
+def test_engine_loads_htdemucs_from_yaml_and_th(emul, tmp_path):
+    """Separator.load_model("htdemucs_6s.yaml") with the reference's files in model_file_dir: provenance "real", hyper-parameters from
+    the package, and the network equal to the oracle on those (half-precision-stored) weights"""
+    from audiolab_amd import htdemucs as H
+    from audiolab_amd.engine import Separator
+    from oracle import htdemucs_oracle as ho
+    import dataclasses
+    import numpy as np
+    cfg = H.HTDemucsConfig(sources=("drums", "bass", "other", "vocals", "guitar", "piano"), channels=16, depth=2, nfft=256, bottom_channels=32,
+                           t_layers=3, t_heads=4, dconv_comp=4, segment_samples=2560, samplerate=4000)
+    sd = H.synthetic_state_dict(cfg, 5)
+    _write_th(str(tmp_path / "5c90dfd2-34c22ccb.th"), cfg, sd)
+    (tmp_path / "htdemucs_6s.yaml").write_text("models: ['5c90dfd2']\n")
+    eng = Separator(model_file_dir=str(tmp_path), ctx=emul, use_autocast=False)
+    eng.load_model("htdemucs_6s.yaml")
+    assert eng.weights_provenance() == "real" and eng.model_instance.demucs.net.cfg == cfg
+    mix = torch.randn(2, 3000, generator=torch.Generator().manual_seed(2)) * 0.2
+    out = eng.separate_array(mix)
+    assert list(out) == ["Drums", "Bass", "Other", "Vocals", "Guitar", "Piano"]
+    ocfg = ho.HTDemucsConfig(**dataclasses.asdict(cfg))
+    want = ho.separate(ocfg, {k: v.half().float() for k, v in sd.items()}, mix, shifts=2, overlap=0.25, seed=0).numpy()
+    for i, k in enumerate(out):
+        assert float(np.max(np.abs(out[k].numpy() - want[i]))) < 1e-4
