@@ -128,6 +128,12 @@ _SIGNATURES = {
     "alsep_vr_split_pred": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "alsep_vr_mirror": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4),
     "alsep_vr_band_spec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8),
+    "alsep_nn_to_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "alsep_nn_gemm_f16w": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                     C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_float, C.c_int]),
+    "alsep_nn_attention_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                         C.c_int64, C.c_int64, C.c_float]),
     "alsep_reverb_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "alsep_reverb_xcorr_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_int64,
                                             C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),

@@ -384,7 +384,8 @@ class Separator:
             seed = int.from_bytes(hashlib.sha256(model_filename.encode()).digest()[:4], "little")
             sd, weights = roformer_synth(cfg, seed=seed), "synthetic"
             logger.warning("%s: no weight file under %s -- SYNTHETIC random-init weights (allow_synthetic=True)", model_filename, self.model_file_dir)
-        net = Roformer(cfg, sd, ctx=self.ctx)
+        # use_autocast=True (the reference's GPU setting, stem_separator.py:106): the network's half-precision mode; float32 otherwise
+        net = Roformer(cfg, sd, ctx=self.ctx, precision="f32" if self.dtype == torch.float32 else "f16")
         labels = tuple(opts.get("labels", ("Vocals",)))[: cfg.num_stems]
         inst = _ModelInstance(model_filename, net, None, labels[0], opts.get("secondary") if cfg.num_stems == 1 else None)
         inst.roformer = RoformerRunner(net, labels)

@@ -151,17 +151,31 @@ def expected_shapes(cfg: "RoformerConfig") -> Dict[str, Tuple[Tuple[int, ...], s
 
 
 class _Lin:
-    def __init__(self, ctx: Context, w: torch.Tensor, b: Optional[torch.Tensor]):
+    def __init__(self, ctx: Context, w: torch.Tensor, b: Optional[torch.Tensor], half: bool = False):
         self.out, self.inp = (int(v) for v in w.shape)
         self.w = w.detach().float().contiguous().to(ctx.device)              # [out, in]: the B operand of alsep_nn_bgemm (rows n, k contiguous)
         self.b = b.detach().float().contiguous().to(ctx.device) if b is not None else None
+        # half-precision mode: the weight matrix once more as IEEE half (rounded on the device, round-to-nearest-even) for the f16 MFMA
+        # kernel -- only for shapes that kernel takes (whole 8-element k-groups, float4 output columns)
+        self.wh = None
+        if half and self.inp % 8 == 0 and self.out % 4 == 0:
+            self.wh = torch.empty((self.out, self.inp), dtype=torch.float16, device=ctx.device)
+            ctx.check(ctx.lib.alsep_nn_to_f16(ctx.handle, _lib.ptr(self.w), _lib.ptr(self.wh), self.w.numel()), "alsep_nn_to_f16")
 
 
 class Roformer:
-    def __init__(self, cfg: RoformerConfig, state_dict: Dict[str, torch.Tensor], ctx: Optional[Context] = None):
+    def __init__(self, cfg: RoformerConfig, state_dict: Dict[str, torch.Tensor], ctx: Optional[Context] = None, precision: str = "f32"):
+        """``precision``: "f32" -- every product on the exact-fp32 MFMA (the 1e-4 parity mode); "f16" -- the arithmetic of the reference's
+        ``use_autocast=True`` (stem_separator.py:106): the Linear layers of the transformer blocks and of the mask estimators and the
+        attention products take IEEE-half operands (csrc/nn_half.hip: f16 MFMA, float32 accumulation, one-pass attention), norms /
+        rotary / softmax statistics / residuals / STFT stay float32.  The per-band input projections (ragged widths) stay float32."""
+        if precision not in ("f32", "f16"):
+            raise AlsepError("Roformer precision must be 'f32' or 'f16'")
         self.cfg = cfg
         self.ctx = ctx if ctx is not None else _lib.default_context(None)
         self.dtype = torch.float32
+        self.precision = precision
+        half = precision == "f16"
         sd = state_dict
         dev = self.ctx.device
         bands = band_indices(cfg)
@@ -198,32 +212,49 @@ class Roformer:
                 pair = []
                 for tr in (0, 1):
                     p = f"layers.{li}.{tr}.layers.0"
-                    pair.append(dict(norm=v(p + ".0.norm.gamma"), qkv=_Lin(self.ctx, sd[p + ".0.to_qkv.weight"], None),
-                                     gates=_Lin(self.ctx, sd[p + ".0.to_gates.weight"], sd[p + ".0.to_gates.bias"]),
-                                     out=_Lin(self.ctx, sd[p + ".0.to_out.0.weight"], None), ffn=v(p + ".1.net.0.gamma"),
-                                     l1=_Lin(self.ctx, sd[p + ".1.net.1.weight"], sd[p + ".1.net.1.bias"]),
-                                     l2=_Lin(self.ctx, sd[p + ".1.net.4.weight"], sd[p + ".1.net.4.bias"])))
+                    pair.append(dict(norm=v(p + ".0.norm.gamma"), qkv=_Lin(self.ctx, sd[p + ".0.to_qkv.weight"], None, half),
+                                     gates=_Lin(self.ctx, sd[p + ".0.to_gates.weight"], sd[p + ".0.to_gates.bias"], half),
+                                     out=_Lin(self.ctx, sd[p + ".0.to_out.0.weight"], None, half), ffn=v(p + ".1.net.0.gamma"),
+                                     l1=_Lin(self.ctx, sd[p + ".1.net.1.weight"], sd[p + ".1.net.1.bias"], half),
+                                     l2=_Lin(self.ctx, sd[p + ".1.net.4.weight"], sd[p + ".1.net.4.bias"], half)))
                 self.layers.append(pair)
             self.final_norm = v("final_norm.gamma")
             self.masks = [[[_Lin(self.ctx, sd[f"mask_estimators.{s}.to_freqs.{i}.0.net.{2 * j}.weight"],
-                                 sd[f"mask_estimators.{s}.to_freqs.{i}.0.net.{2 * j}.bias"]) for j in range(cfg.mask_estimator_depth)]
+                                 sd[f"mask_estimators.{s}.to_freqs.{i}.0.net.{2 * j}.bias"], half) for j in range(cfg.mask_estimator_depth)]
                            for i in range(self.nb)] for s in range(cfg.num_stems)]
         except KeyError as e:
             raise AlsepError(f"state_dict is missing {e} for this RoformerConfig") from e
         self._plans: Dict[int, object] = {}
 
     # -- helpers --------------------------------------------------------------------------------------------
-    def _gemm(self, a_ptr: int, sa, lin: _Lin, c_ptr: int, sc, M: int, act: int = 0, nb1: int = 1, nb2: int = 1, use_bias: bool = True) -> None:
-        """C = act(A W^T + b) with A / C given by (pointer, strides)"""
+    def _gemm(self, a_ptr: int, sa, lin: _Lin, c_ptr: int, sc, M: int, act: int = 0, nb1: int = 1, nb2: int = 1, use_bias: bool = True,
+              res_ptr: Optional[int] = None, res_ld: int = 0) -> None:
+        """C = act(A W^T + b) [+ R] with A / C given by (pointer, strides (b1, b2, row, k)).  A residual is only taken by the half path."""
         ctx = self.ctx
-        arr = C.c_int64 * 4
         bias = _lib.ptr(lin.b) if (lin.b is not None and use_bias) else None
+        if (lin.wh is not None and nb1 == 1 and nb2 == 1 and sa[3] == 1 and sc[3] == 1 and sa[2] % 4 == 0 and sc[2] % 4 == 0
+                and a_ptr % 16 == 0 and c_ptr % 16 == 0):
+            ctx.check(ctx.lib.alsep_nn_gemm_f16w(ctx.handle, C.c_void_p(a_ptr), sa[2], 0, _lib.ptr(lin.wh), lin.inp, 0, C.c_void_p(c_ptr), sc[2], 0,
+                                                 bias, 0, C.c_void_p(res_ptr) if res_ptr else None, res_ld, 0, 1, M, lin.out, lin.inp, 1.0, act),
+                      "alsep_nn_gemm_f16w")
+            return
+        if res_ptr:
+            raise AlsepError("Roformer._gemm: a fused residual needs the half-precision kernel")
+        arr = C.c_int64 * 4
         ctx.check(ctx.lib.alsep_nn_bgemm_bias(ctx.handle, C.c_void_p(a_ptr), _lib.ptr(lin.w), C.c_void_p(c_ptr), nb1, nb2, M, lin.out, lin.inp,
                                               arr(*sa), arr(0, 0, lin.inp, 1), arr(*sc), 1.0, bias, act), "alsep_nn_bgemm_bias")
 
-    def _dense(self, x: torch.Tensor, rows: int, lin: _Lin, act: int = 0) -> torch.Tensor:
+    def _dense(self, x: torch.Tensor, rows: int, lin: _Lin, act: int = 0, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """act(x W^T + b) [+ residual]; the residual add is fused into the half-precision kernel's epilogue, a separate launch otherwise"""
         y = self.ctx.empty((rows, lin.out))
-        self._gemm(x.data_ptr(), (0, 0, lin.inp, 1), lin, y.data_ptr(), (0, 0, lin.out, 1), rows, act)
+        fuse = residual is not None and lin.wh is not None
+        self._gemm(x.data_ptr(), (0, 0, lin.inp, 1), lin, y.data_ptr(), (0, 0, lin.out, 1), rows, act,
+                   res_ptr=residual.data_ptr() if fuse else None, res_ld=lin.out)
+        if residual is not None and not fuse:
+            out = self.ctx.empty((rows, lin.out))
+            self.ctx.check(self.ctx.lib.alsep_nn_scale_add(self.ctx.handle, _lib.ptr(residual), _lib.ptr(y), None, _lib.ptr(out), rows, lin.out),
+                           "alsep_nn_scale_add")
+            return out
         return y
 
     def _rmsnorm(self, x: torch.Tensor, rows: int, Cn: int, gamma: torch.Tensor) -> torch.Tensor:
@@ -250,27 +281,26 @@ class Roformer:
             n_seq, L, seq_stride, row_stride = nb, T, ld, nb * ld
         else:                                                                 # batch (frame, head); rows are ld apart
             n_seq, L, seq_stride, row_stride = T, nb, nb * ld, ld
-        Lp = -(-L // 4) * 4                                                    # score rows padded to 16 bytes: the tiled GEMM's float4 loads
-        scores = ctx.empty((n_seq, Hh, L, Lp))
-        base = qkv.data_ptr()
-        ctx.check(lib.alsep_nn_bgemm(h, C.c_void_p(base), C.c_void_p(base + 4 * inner), _lib.ptr(scores), n_seq, Hh, L, L, d,
-                                     arr(seq_stride, d, row_stride, 1), arr(seq_stride, d, row_stride, 1), arr(Hh * L * Lp, L * Lp, Lp, 1),
-                                     d ** -0.5), "alsep_nn_bgemm")
-        ctx.check(lib.alsep_nn_softmax_rows_ld(h, _lib.ptr(scores), n_seq * Hh * L, L, Lp), "alsep_nn_softmax_rows_ld")
         att = ctx.empty((rows, inner))
         o_seq, o_row = (inner, nb * inner) if over_time else (nb * inner, inner)
-        ctx.check(lib.alsep_nn_bgemm(h, _lib.ptr(scores), C.c_void_p(base + 8 * inner), _lib.ptr(att), n_seq, Hh, L, d, L,
-                                     arr(Hh * L * Lp, L * Lp, Lp, 1), arr(seq_stride, d, 1, row_stride), arr(o_seq, d, o_row, 1), 1.0), "alsep_nn_bgemm")
+        if self.precision == "f16" and d == 64:                               # one pass: scores never reach HBM
+            ctx.check(lib.alsep_nn_attention_f16(h, _lib.ptr(qkv), _lib.ptr(att), n_seq, L, Hh, d, seq_stride, row_stride, o_seq, o_row,
+                                                 d ** -0.5), "alsep_nn_attention_f16")
+        else:
+            Lp = -(-L // 4) * 4                                                # score rows padded to 16 bytes: the tiled GEMM's float4 loads
+            scores = ctx.empty((n_seq, Hh, L, Lp))
+            base = qkv.data_ptr()
+            ctx.check(lib.alsep_nn_bgemm(h, C.c_void_p(base), C.c_void_p(base + 4 * inner), _lib.ptr(scores), n_seq, Hh, L, L, d,
+                                         arr(seq_stride, d, row_stride, 1), arr(seq_stride, d, row_stride, 1), arr(Hh * L * Lp, L * Lp, Lp, 1),
+                                         d ** -0.5), "alsep_nn_bgemm")
+            ctx.check(lib.alsep_nn_softmax_rows_ld(h, _lib.ptr(scores), n_seq * Hh * L, L, Lp), "alsep_nn_softmax_rows_ld")
+            ctx.check(lib.alsep_nn_bgemm(h, _lib.ptr(scores), C.c_void_p(base + 8 * inner), _lib.ptr(att), n_seq, Hh, L, d, L,
+                                         arr(Hh * L * Lp, L * Lp, Lp, 1), arr(seq_stride, d, 1, row_stride), arr(o_seq, d, o_row, 1), 1.0), "alsep_nn_bgemm")
         gates = self._dense(xn, rows, P["gates"])
         ctx.check(lib.alsep_nn_gate(h, _lib.ptr(att), _lib.ptr(gates), rows, Hh, d), "alsep_nn_gate")
-        a = self._dense(att, rows, P["out"])
-        x1 = ctx.empty((rows, dim))
-        ctx.check(lib.alsep_nn_scale_add(h, _lib.ptr(x), _lib.ptr(a), None, _lib.ptr(x1), rows, dim), "alsep_nn_scale_add")
+        x1 = self._dense(att, rows, P["out"], residual=x)
         f = self._dense(self._rmsnorm(x1, rows, dim, P["ffn"]), rows, P["l1"], act=3)
-        f = self._dense(f, rows, P["l2"])
-        x2 = ctx.empty((rows, dim))
-        ctx.check(lib.alsep_nn_scale_add(h, _lib.ptr(x1), _lib.ptr(f), None, _lib.ptr(x2), rows, dim), "alsep_nn_scale_add")
-        return x2
+        return self._dense(f, rows, P["l2"], residual=x1)
 
     def _plan(self, dim_t: int):
         from .mdx import StftPlan

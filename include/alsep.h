@@ -328,6 +328,21 @@ int alsep_vr_mirror(alsep_ctx* ctx, const float* spec_m, const float* he, float*
 int alsep_vr_band_spec(alsep_ctx* ctx, const float* spec_m, const float* extra, const float* gain, float* band, int bins, int l, int Fb, int f0,
                        int h, int o0, int e0, int eh);
 
+/* ---- half-precision MFMA path of the transformer model families (csrc/nn_half.hip): what torch autocast does to the Linear layers and
+ * the attention of the Roformer models the reference loads with use_autocast=True (modules/separator/stem_separator.py:106, :379-382).
+ * Activations stay float32 in HBM; operands are rounded to IEEE half on their way into the MFMA, accumulation is float32. */
+int alsep_nn_to_f16(alsep_ctx* ctx, const float* x, void* y, int64_t n);
+/* C[b][M][N] = act(alpha A[b][M][K] W[b][N][K]^T + bias[b][N]) (+ R[b][M][N]); A / C / R float32, W f16; row strides ld*, batch strides
+ * s*_b in elements (0: shared).  act 0 none, 3 GELU(erf), 5 tanh.  Needs K % 8 == 0, N % 4 == 0 and 16-byte aligned rows
+ * (ALSEP_ERR_ARG otherwise). */
+int alsep_nn_gemm_f16w(alsep_ctx* ctx, const float* A, int64_t lda, int64_t sa_b, const void* W, int64_t ldw, int64_t sw_b, float* C,
+                       int64_t ldc, int64_t sc_b, const float* bias, int64_t bias_b, const float* R, int64_t ldr, int64_t sr_b, int nb, int M,
+                       int N, int K, float alpha, int act);
+/* out = softmax(scale q k^T) v per (sequence, head), one pass (no score matrix in HBM).  qkv: float32 rows of 3 * heads * 64 values
+ * (q | k | v), rotary embedding applied; sequence s = L rows `row_stride` floats apart from s * seq_stride; out rows of heads * 64. */
+int alsep_nn_attention_f16(alsep_ctx* ctx, const float* qkv, float* out, int n_seq, int L, int heads, int dim_head, int64_t seq_stride,
+                           int64_t row_stride, int64_t o_seq_stride, int64_t o_row_stride, float scale);
+
 /* ---- reverb impulse-response extraction: replaces handlers/reverb.py:112-172 (extract_reverb), called from
  * modules/separator/stem_separator.py:822-829 when a de-reverb transform ran on the vocals with store_reverb_ir.  Whole-track FFT work in
  * double precision (csrc/reverb.hip).  Audio arguments: float32 device tensors [channels][n] with row stride ld; the mono signals are

@@ -125,35 +125,55 @@ def _rotary(t: torch.Tensor, dim_head: int) -> torch.Tensor:
     return t * freqs.cos() + rot * freqs.sin()
 
 
-def _attention(cfg, w, p: str, x: torch.Tensor) -> torch.Tensor:
+def _h(t: torch.Tensor) -> torch.Tensor:
+    """an MFMA operand of the half-precision mode: the float32 value rounded to IEEE half (products and sums stay float32)"""
+    return t.half().float()
+
+
+def _linear(x: torch.Tensor, wt: torch.Tensor, bias, half: bool) -> torch.Tensor:
+    """a Linear layer; ``half``: the operand rounding of the f16 MFMA kernel (= autocast's input casts), float32 accumulation and output"""
+    if half and wt.shape[1] % 8 == 0 and wt.shape[0] % 4 == 0:        # the shapes the f16 MFMA kernel takes (whole k-groups, float4 columns)
+        return F.linear(_h(x), _h(wt), bias)
+    return F.linear(x, wt, bias)
+
+
+def _attention(cfg, w, p: str, x: torch.Tensor, half: bool = False) -> torch.Tensor:
     h, d = cfg.heads, cfg.dim_head
     xn = _rmsnorm(w, p + ".norm", x)
-    qkv = F.linear(xn, w[p + ".to_qkv.weight"])
+    qkv = _linear(xn, w[p + ".to_qkv.weight"], None, half)
     b, n, _ = qkv.shape
     q, k, v = qkv.view(b, n, 3, h, d).permute(2, 0, 3, 1, 4)
     q, k = _rotary(q, d), _rotary(k, d)
-    att = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, dim=-1)
-    out = att @ v
-    gates = F.linear(xn, w[p + ".to_gates.weight"], w[p + ".to_gates.bias"])
+    if half:                                                       # the one-pass kernel: q d^-1/2, k, v and the un-normalised probabilities are the
+        s = _h(q * d ** -0.5) @ _h(k).transpose(-1, -2)            # f16 operands; row statistics and the final division are float32
+        e = torch.exp(s - s.amax(dim=-1, keepdim=True))
+        out = (_h(e) @ _h(v)) / e.sum(dim=-1, keepdim=True)
+    else:
+        att = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, dim=-1)
+        out = att @ v
+    gates = _linear(xn, w[p + ".to_gates.weight"], w[p + ".to_gates.bias"], half)
     out = out * gates.permute(0, 2, 1)[..., None].sigmoid()
-    return F.linear(out.permute(0, 2, 1, 3).reshape(b, n, h * d), w[p + ".to_out.0.weight"])
+    return _linear(out.permute(0, 2, 1, 3).reshape(b, n, h * d), w[p + ".to_out.0.weight"], None, half)
 
 
-def _feedforward(w, p: str, x: torch.Tensor) -> torch.Tensor:
+def _feedforward(w, p: str, x: torch.Tensor, half: bool = False) -> torch.Tensor:
     h = _rmsnorm(w, p + ".net.0", x)
-    h = F.gelu(F.linear(h, w[p + ".net.1.weight"], w[p + ".net.1.bias"]))
-    return F.linear(h, w[p + ".net.4.weight"], w[p + ".net.4.bias"])
+    h = F.gelu(_linear(h, w[p + ".net.1.weight"], w[p + ".net.1.bias"], half))
+    return _linear(h, w[p + ".net.4.weight"], w[p + ".net.4.bias"], half)
 
 
-def _transformer(cfg, w, p: str, x: torch.Tensor) -> torch.Tensor:
+def _transformer(cfg, w, p: str, x: torch.Tensor, half: bool = False) -> torch.Tensor:
     """Transformer(depth=1, norm_output=False): x = attn(x) + x; x = ff(x) + x"""
-    x = _attention(cfg, w, p + ".layers.0.0", x) + x
-    return _feedforward(w, p + ".layers.0.1", x) + x
+    x = _attention(cfg, w, p + ".layers.0.0", x, half) + x
+    return _feedforward(w, p + ".layers.0.1", x, half) + x
 
 
 @torch.no_grad()
-def forward(cfg: RoformerConfig, w: Dict[str, torch.Tensor], audio: torch.Tensor) -> torch.Tensor:
-    """audio [B, 2, L] (L a multiple of hop) -> [B, num_stems, 2, L]"""
+def forward(cfg: RoformerConfig, w: Dict[str, torch.Tensor], audio: torch.Tensor, half: bool = False) -> torch.Tensor:
+    """audio [B, 2, L] (L a multiple of hop) -> [B, num_stems, 2, L].  ``half=True`` restates the build's half-precision mode (the
+    arithmetic of the reference's use_autocast=True as csrc/nn_half.hip runs it): the Linear layers of the transformer blocks and the
+    mask estimators and the two attention products take operands rounded to IEEE half, everything else -- including every accumulation
+    and every stored activation -- stays float32; the per-band input projections stay float32."""
     B, S, L = audio.shape
     win = torch.hann_window(cfg.n_fft)
     z = torch.stft(audio.reshape(B * S, L), cfg.n_fft, cfg.hop, win_length=cfg.n_fft, window=win, return_complex=True)
@@ -169,9 +189,9 @@ def forward(cfg: RoformerConfig, w: Dict[str, torch.Tensor], audio: torch.Tensor
     nb = len(bands)
     for li in range(cfg.depth):
         x = x.permute(0, 2, 1, 3).reshape(B * nb, T, cfg.dim)
-        x = _transformer(cfg, w, f"layers.{li}.0", x)
+        x = _transformer(cfg, w, f"layers.{li}.0", x, half)
         x = x.view(B, nb, T, cfg.dim).permute(0, 2, 1, 3).reshape(B * T, nb, cfg.dim)
-        x = _transformer(cfg, w, f"layers.{li}.1", x).view(B, T, nb, cfg.dim)
+        x = _transformer(cfg, w, f"layers.{li}.1", x, half).view(B, T, nb, cfg.dim)
     x = _rmsnorm(w, "final_norm", x)
     zc = torch.view_as_complex(z.contiguous())                                                         # [B, (f s), T]
     outs = []
@@ -182,7 +202,7 @@ def forward(cfg: RoformerConfig, w: Dict[str, torch.Tensor], audio: torch.Tensor
             hcur = x[:, :, i]
             nl = cfg.mask_estimator_depth
             for j in range(nl):
-                hcur = F.linear(hcur, w[f"{p}.{2 * j}.weight"], w[f"{p}.{2 * j}.bias"])
+                hcur = _linear(hcur, w[f"{p}.{2 * j}.weight"], w[f"{p}.{2 * j}.bias"], half)
                 if j + 1 < nl:
                     hcur = torch.tanh(hcur)
             m = F.glu(hcur, dim=-1)                                                                    # [B, T, len(idx) * 2]

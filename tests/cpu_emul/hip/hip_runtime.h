@@ -90,6 +90,7 @@ void wave_sync();
 
 static inline void __syncthreads() { emul::sync_block(); }
 // device math the host libm lacks
+#define __expf(x) std::exp((float)(x))   /* glibc declares, but does not export, a symbol of this name */
 static inline void sincospi(double x, double* s, double* c) { *s = std::sin(M_PI * x); *c = std::cos(M_PI * x); }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                       \
