@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libalsep.so")
 F32, BF16, F16 = 0, 1, 2
 PROF_CONV3X3, PROF_CONV3X3_SMALL, PROF_TDF, PROF_PIX, PROF_POINTWISE, PROF_STFT, PROF_ISTFT = 1, 2, 3, 4, 5, 6, 7
 PROF_CONV3X3_REGW, PROF_CONV3X3_PIPE, PROF_CONV3X3_BIG, PROF_CONV3X3_BIG3 = 8, 9, 10, 11
+PROF_NN_GEMM, PROF_NN_CONV, PROF_NN_GEMM_H, PROF_NN_ATTN_H = 12, 13, 14, 15
 LAYOUT_REF, LAYOUT_NHWC = 0, 1
 ABI_VERSION = 1
 
@@ -50,6 +51,7 @@ _SIGNATURES = {
     "alsep_last_error": (C.c_char_p, [C.c_void_p]),
     "alsep_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "alsep_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "alsep_profile_work": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "alsep_launch_count": (C.c_int64, [C.c_void_p, C.c_char_p]),
     "alsep_launch_counts_reset": (C.c_int, [C.c_void_p]),
     "alsep_plan_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -131,9 +133,11 @@ _SIGNATURES = {
     "alsep_nn_to_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "alsep_nn_gemm_f16w": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                      C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
-                                     C.c_float, C.c_int]),
+                                     C.c_float, C.c_int, C.c_void_p]),
     "alsep_nn_attention_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
-                                         C.c_int64, C.c_int64, C.c_float]),
+                                         C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
+    "alsep_nn_rotary_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "alsep_roformer_bandsplit_in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "alsep_reverb_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "alsep_reverb_xcorr_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_int64,
                                             C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
@@ -229,6 +233,12 @@ class Context:
         ms, n = C.c_double(), C.c_int64()
         self.check(self.lib.alsep_profile_end(self.handle, C.byref(ms), C.byref(n)), "alsep_profile_end")
         return ms.value, n.value
+
+    def profile_work(self):
+        """-> (flops, bytes) the launch sites of the profiled class counted since profile_begin (call before profile_end)"""
+        f, b = C.c_double(), C.c_double()
+        self.check(self.lib.alsep_profile_work(self.handle, C.byref(f), C.byref(b)), "alsep_profile_work")
+        return f.value, b.value
 
     def launch_count(self, kernel: str) -> int:
         """launches of ``kernel`` (name as reported by its launch site) since creation / the last reset"""

@@ -43,6 +43,7 @@ struct alsep_ctx {
     int prof_category = 0;
     std::vector<hipEvent_t> prof_events;     // start/stop pairs
     size_t prof_used = 0;
+    double prof_flops = 0.0, prof_bytes = 0.0;   // work of the bracketed launches, added by their launch sites (ProfScope::work)
     // launches per kernel name since alsep_create / alsep_launch_counts_reset (tests assert WHICH kernel ran)
     std::map<std::string, int64_t> launches;
     int cu_count = 0;                        // multiprocessors of `device`, read once per ctx
@@ -66,6 +67,9 @@ struct ProfScope {
             ctx->prof_events.push_back(b);
         }
         (void)hipEventRecord(ctx->prof_events[ctx->prof_used], ctx->stream);
+    }
+    void work(double flops, double bytes) {
+        if (on) { ctx->prof_flops += flops; ctx->prof_bytes += bytes; }
     }
     ~ProfScope() {
         if (!on) return;

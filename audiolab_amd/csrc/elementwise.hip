@@ -281,6 +281,14 @@ extern "C" int alsep_profile_begin(alsep_ctx* ctx, int category) {
     if (!ctx || category < 0) return ALSEP_ERR_ARG;
     ctx->prof_category = category;
     ctx->prof_used = 0;
+    ctx->prof_flops = ctx->prof_bytes = 0.0;
+    return ALSEP_OK;
+}
+
+extern "C" int alsep_profile_work(alsep_ctx* ctx, double* flops, double* bytes) {
+    if (!ctx || !flops || !bytes) return ALSEP_ERR_ARG;
+    *flops = ctx->prof_flops;
+    *bytes = ctx->prof_bytes;
     return ALSEP_OK;
 }
 

@@ -270,6 +270,8 @@ static bool gemm_ct_ok(const float* C, int N, const GemmStrides& c) {
 static int launch_gemm(alsep_ctx* ctx, const float* A, const float* B, float* C, int nb, int nb2, int M, int N, int K, GemmStrides a,
                        GemmStrides b, GemmStrides c, float alpha, const float* bias, int act) {
     const int mode = gemm_tiled_mode(A, B, M, N, K, a, b);
+    ProfScope prof(ctx, ALSEP_PROF_NN_GEMM);
+    prof.work(2.0 * nb * (double)M * N * K, 4.0 * nb * ((double)M * K + (double)N * K + (double)M * N));
     if (mode) {
         const dim3 grid((unsigned)ceil_div64(N, kGemmBN), (unsigned)ceil_div64(M, kGemmBM), (unsigned)nb);
         const size_t lds = 2 * (size_t)(kGemmBM + kGemmBN) * kGemmLD * sizeof(float);       // (the [16][132] B image is smaller)

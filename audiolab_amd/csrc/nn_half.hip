@@ -44,6 +44,7 @@ struct GemmHArgs {
     int M, N, K;
     float alpha;
     int act;
+    const int* nvec;                              // optional: columns of batch b (<= N): the ragged last layers of the mask estimators
 };
 
 __device__ __forceinline__ int hg_slot(int row, int g) { return row * kHgBK + 8 * (g ^ ((row >> 1) & 3)); }
@@ -60,6 +61,8 @@ nn_gemm_h_kernel(GemmHArgs p) {
     const _Float16* b = p.B + bz * p.sb_b;
     float* c = p.C + bz * p.sc_b;
     const int m0 = blockIdx.y * kHgBM, n0 = blockIdx.x * kHgBN;
+    const int Nb = p.nvec ? p.nvec[bz] : p.N;
+    if (n0 >= Nb) return;                                                    // whole workgroups leave together
     // staging duty per slice: A 512 granules of 8 floats (two per thread), B 512 granules of 8 halves (two per thread)
     const int sr = tid >> 2, sg = tid & 3;                                   // rows sr and sr + 64, k-group sg
     const float* ga[2];
@@ -69,7 +72,7 @@ nn_gemm_h_kernel(GemmHArgs p) {
     for (int h = 0; h < 2; ++h) {
         const int ra = m0 + sr + 64 * h, rb = n0 + sr + 64 * h;
         va[h] = ra < p.M;
-        vb[h] = rb < p.N;
+        vb[h] = rb < Nb;
         ga[h] = a + (int64_t)(va[h] ? ra : 0) * p.lda + 8 * sg;
         gb[h] = b + (int64_t)(vb[h] ? rb : 0) * p.ldb + 8 * sg;
     }
@@ -131,7 +134,7 @@ nn_gemm_h_kernel(GemmHArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = n0 + wn * 64 + j * 16 + 4 * lq;
-            if (col >= p.N) continue;
+            if (col >= Nb) continue;
             f32x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -170,11 +173,39 @@ to_f16_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int64_t n) 
 // The row sums are carried per lane and reduced once at the end.  float32 everywhere outside the two MFMA operands.
 // ------------------------------------------------------------------------------------------------------------------------------------
 constexpr int kAtD = 64, kAtKc = 32, kAtVld = 36;
+
+// rotary embedding of 8 consecutive head-dimension values (4 interleaved pairs) by the table entries (cos, sin) of their position:
+// (a, b) -> (a cos - b sin, b cos + a sin), the arithmetic of nn_rotary_kernel
+__device__ __forceinline__ void rotate8(f32x4& x0, f32x4& x1, const float* __restrict__ cs) {
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs), c1 = *reinterpret_cast<const f32x4*>(cs + 4);     // cos0 sin0 cos1 sin1 | cos2 sin2 cos3 sin3
+    f32x4 r0, r1;
+    r0[0] = x0[0] * c0[0] - x0[1] * c0[1]; r0[1] = x0[1] * c0[0] + x0[0] * c0[1];
+    r0[2] = x0[2] * c0[2] - x0[3] * c0[3]; r0[3] = x0[3] * c0[2] + x0[2] * c0[3];
+    r1[0] = x1[0] * c1[0] - x1[1] * c1[1]; r1[1] = x1[1] * c1[0] + x1[0] * c1[1];
+    r1[2] = x1[2] * c1[2] - x1[3] * c1[3]; r1[3] = x1[3] * c1[2] + x1[2] * c1[3];
+    x0 = r0;
+    x1 = r1;
+}
+
+// table[pos][j] = (cos, sin)(pos / 10000^(2 j / d)), j < d / 2: the angles of nn_rotary_kernel
+__global__ void __launch_bounds__(256)
+rotary_table_kernel(float* __restrict__ table, int L, int d) {
+    const int half = d / 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < L * half; i += gridDim.x * 256) {
+        const int j = i % half;
+        const float pos = (float)(i / half);
+        const float inv = 1.f / powf(10000.f, (float)(2 * j) / (float)d);
+        const float ang = pos * inv;
+        table[2 * i] = cosf(ang);
+        table[2 * i + 1] = sinf(ang);
+    }
+}
 constexpr size_t kAtLds = (size_t)kAtKc * kAtD * sizeof(_Float16) + (size_t)kAtD * kAtVld * sizeof(_Float16);     // 4096 + 4608
 
 __global__ void __launch_bounds__(kHThreads)
 nn_attn_h_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, int heads, int64_t seq_stride, int64_t row_stride,
-                 int64_t o_seq_stride, int64_t o_row_stride, float scale) {
+                 int64_t o_seq_stride, int64_t o_row_stride, float scale, const float* __restrict__ rot, const float* __restrict__ gates,
+                 int64_t g_seq_stride, int64_t g_row_stride) {
     _Float16* Ks = reinterpret_cast<_Float16*>(alsep_smem);                  // [32 keys][64 d], swizzled groups
     _Float16* Vt = Ks + kAtKc * kAtD;                                         // [64 d][36]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -195,6 +226,7 @@ nn_attn_h_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, 
             const float* src = base + (int64_t)q * row_stride + 32 * s + 8 * lq;
             a = *reinterpret_cast<const f32x4*>(src);
             b = *reinterpret_cast<const f32x4*>(src + 4);
+            if (rot) rotate8(a, b, rot + ((int64_t)q * (kAtD / 2) + 16 * s + 4 * lq) * 2);
         }
         qf[s] = to_h8(a * scale, b * scale);
     }
@@ -209,6 +241,7 @@ nn_attn_h_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, 
             const int64_t off = (int64_t)(k0 + skey) * row_stride + 8 * sgrp;
             ka = *reinterpret_cast<const f32x4*>(kbase + off);
             kb = *reinterpret_cast<const f32x4*>(kbase + off + 4);
+            if (rot) rotate8(ka, kb, rot + ((int64_t)(k0 + skey) * (kAtD / 2) + 4 * sgrp) * 2);
             va = *reinterpret_cast<const f32x4*>(vbase + off);
             vb = *reinterpret_cast<const f32x4*>(vbase + off + 4);
         }
@@ -271,14 +304,73 @@ nn_attn_h_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, 
     lsum += __shfl_xor(lsum, 16);
     lsum += __shfl_xor(lsum, 32);
     if (qok) {
-        const float inv = 1.f / lsum;
+        float inv = 1.f / lsum;
+        if (gates) inv *= 1.f / (1.f + expf(-gates[seq * g_seq_stride + (int64_t)q * g_row_stride + head]));    // out * sigmoid(gate[row][head])
         float* dst = out + seq * o_seq_stride + (int64_t)q * o_row_stride + head * kAtD;
 #pragma unroll
         for (int d = 0; d < 4; ++d) *reinterpret_cast<f32x4*>(dst + 16 * d + 4 * lq) = o[d] * inv;      // O^T rows d = 16 d + 4 lq + r
     }
 }
 
+// Roformer band split, input side, for ALL bands in one launch: gather a band's bins of one frame from the spectrogram ([4][F][T] as
+// alsep_stft writes it; merged index m = 2 f + s), RMS-normalise them over the band's true width (lucidrains RMSNorm: x / max(||x||,
+// 1e-12) sqrt(width) gamma, sum of squares in double as nn_rmsnorm_kernel) and store the row zero-padded to kmax: feat[band][t][kmax] is
+// then the A operand of ONE batched Linear over the bands (weights zero-padded alike).  pidx[band][kmax / 2]: merged index or -1;
+// gamma[band][kmax].  One wave per (band, frame).
+__global__ void __launch_bounds__(kHThreads)
+roformer_bandsplit_in_kernel(const float* __restrict__ spec, const int* __restrict__ pidx, const float* __restrict__ gamma,
+                             const int* __restrict__ width, float* __restrict__ feat, int nb, int F, int T, int kmax) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * (kHThreads / 64) + (threadIdx.x >> 6);
+    if (w >= (int64_t)nb * T) return;
+    const int band = (int)(w / T), t = (int)(w % T);
+    const int* pi = pidx + (int64_t)band * (kmax / 2);
+    const float* g = gamma + (int64_t)band * kmax;
+    float* out = feat + w * kmax;
+    const int64_t plane = (int64_t)F * T;
+    constexpr int PER = 5;                                                   // kmax / 2 <= 320 entries per band
+    float re[PER], im[PER];
+    double ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = lane + 64 * k;
+        re[k] = im[k] = 0.f;
+        if (i < kmax / 2) {
+            const int m = pi[i];
+            if (m >= 0) {
+                const int f = m >> 1, sch = m & 1;
+                re[k] = spec[(int64_t)(2 * sch) * plane + (int64_t)f * T + t];
+                im[k] = spec[(int64_t)(2 * sch + 1) * plane + (int64_t)f * T + t];
+                ss += (double)re[k] * (double)re[k] + (double)im[k] * (double)im[k];
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float inv = sqrtf((float)width[band]) / fmaxf((float)sqrt(ss), 1e-12f);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = lane + 64 * k;
+        if (i < kmax / 2) {
+            out[2 * i] = re[k] * inv * g[2 * i];
+            out[2 * i + 1] = im[k] * inv * g[2 * i + 1];
+        }
+    }
+}
+
 }  // namespace
+
+// feat[band][t][kmax] = RMSNorm_band(gathered bins of frame t), zero-padded (see roformer_bandsplit_in_kernel); kmax <= 640, even
+extern "C" int alsep_roformer_bandsplit_in(alsep_ctx* ctx, const float* spec, const int* pidx, const float* gamma, const int* width, float* feat,
+                                           int nb, int F, int T, int kmax) {
+    ALSEP_ENTER(ctx);
+    if (!ctx || !spec || !pidx || !gamma || !width || !feat || nb < 1 || F < 1 || T < 1 || kmax < 2 || kmax % 2 || kmax > 640)
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_roformer_bandsplit_in: bad argument");
+    const int64_t waves = (int64_t)nb * T;
+    hipLaunchKernelGGL(roformer_bandsplit_in_kernel, dim3((unsigned)ceil_div64(waves, kHThreads / 64)), dim3(kHThreads), 0, ctx->stream, spec, pidx,
+                       gamma, width, feat, nb, F, T, kmax);
+    ALSEP_LAUNCH_CHECK(ctx, "roformer_bandsplit_in_kernel");
+    return ALSEP_OK;
+}
 
 extern "C" int alsep_nn_to_f16(alsep_ctx* ctx, const float* x, void* y, int64_t n) {
     ALSEP_ENTER(ctx);
@@ -295,25 +387,38 @@ extern "C" int alsep_nn_to_f16(alsep_ctx* ctx, const float* x, void* y, int64_t 
 // ldr % 4 == 0 and 16-byte aligned bases (returns ALSEP_ERR_ARG otherwise: the caller keeps such products on alsep_nn_bgemm_bias).
 extern "C" int alsep_nn_gemm_f16w(alsep_ctx* ctx, const float* A, int64_t lda, int64_t sa_b, const void* W, int64_t ldw, int64_t sw_b, float* C,
                                   int64_t ldc, int64_t sc_b, const float* bias, int64_t bias_b, const float* R, int64_t ldr, int64_t sr_b,
-                                  int nb, int M, int N, int K, float alpha, int act) {
+                                  int nb, int M, int N, int K, float alpha, int act, const int* n_per_batch) {
     ALSEP_ENTER(ctx);
     if (!ctx || !A || !W || !C || nb < 1 || nb > 65535 || M < 1 || N < 1 || K < 8 || !(act == 0 || act == 3 || act == 5))
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_gemm_f16w: bad argument");
     if (K % 8 || N % 4 || lda % 4 || ldw % 8 || ldc % 4 || sa_b % 4 || sw_b % 8 || sc_b % 4 || lda < K || ldw < K || ldc < N ||
         (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) || (R && (ldr % 4 || sr_b % 4 || ldr < N || ((uintptr_t)R & 15))))
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_gemm_f16w: operands do not meet the alignment this kernel needs");
-    GemmHArgs p{A, lda, sa_b, (const _Float16*)W, ldw, sw_b, C, ldc, sc_b, bias, bias_b, R, ldr, sr_b, M, N, K, alpha, act};
+    GemmHArgs p{A, lda, sa_b, (const _Float16*)W, ldw, sw_b, C, ldc, sc_b, bias, bias_b, R, ldr, sr_b, M, N, K, alpha, act, n_per_batch};
     ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)nn_gemm_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHgLds));
     const dim3 grid((unsigned)ceil_div64(N, kHgBN), (unsigned)ceil_div64(M, kHgBM), (unsigned)nb);
+    ProfScope prof(ctx, ALSEP_PROF_NN_GEMM_H);
+    prof.work(2.0 * nb * (double)M * N * K, (double)nb * (4.0 * M * K + 2.0 * N * K + (R ? 8.0 : 4.0) * M * N));
     hipLaunchKernelGGL(nn_gemm_h_kernel, grid, dim3(kHThreads), kHgLds, ctx->stream, p);
     ALSEP_LAUNCH_CHECK(ctx, "nn_gemm_h_kernel");
     return ALSEP_OK;
 }
 
 // out[seq][row][head][64] = softmax(scale q k^T) v per (sequence, head) of a packed q | k | v projection (see nn_attn_h_kernel).
-// Strides in floats; every row start must be 16-byte aligned (strides % 4 == 0); head dimension 64.
+// Strides in floats; every row start must be 16-byte aligned (strides % 4 == 0); head dimension 64.  rot_table (optional,
+// alsep_nn_rotary_table): q and k are rotary-embedded by their position in the sequence as they are loaded (qkv then holds the raw
+// projection); gates (optional): the result is scaled by sigmoid(gates[seq * g_seq_stride + row * g_row_stride + head]).
+extern "C" int alsep_nn_rotary_table(alsep_ctx* ctx, float* table, int L, int dim_head) {
+    ALSEP_ENTER(ctx);
+    if (!ctx || !table || L < 1 || dim_head < 2 || dim_head % 2) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_rotary_table: bad argument");
+    hipLaunchKernelGGL(rotary_table_kernel, dim3((unsigned)ceil_div64((int64_t)L * dim_head / 2, 256)), dim3(256), 0, ctx->stream, table, L, dim_head);
+    ALSEP_LAUNCH_CHECK(ctx, "rotary_table_kernel");
+    return ALSEP_OK;
+}
+
 extern "C" int alsep_nn_attention_f16(alsep_ctx* ctx, const float* qkv, float* out, int n_seq, int L, int heads, int dim_head, int64_t seq_stride,
-                                      int64_t row_stride, int64_t o_seq_stride, int64_t o_row_stride, float scale) {
+                                      int64_t row_stride, int64_t o_seq_stride, int64_t o_row_stride, float scale, const float* rot_table,
+                                      const float* gates, int64_t g_seq_stride, int64_t g_row_stride) {
     ALSEP_ENTER(ctx);
     if (!ctx || !qkv || !out || n_seq < 1 || n_seq > 65535 || L < 1 || heads < 1 || heads > 65535)
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_attention_f16: bad argument");
@@ -321,8 +426,11 @@ extern "C" int alsep_nn_attention_f16(alsep_ctx* ctx, const float* qkv, float* o
     if (seq_stride % 4 || row_stride % 4 || o_seq_stride % 4 || o_row_stride % 4 || (((uintptr_t)qkv | (uintptr_t)out) & 15))
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_attention_f16: strides / bases must be multiples of 16 bytes");
     const dim3 grid((unsigned)ceil_div64(L, 64), (unsigned)heads, (unsigned)n_seq);
+    ProfScope prof(ctx, ALSEP_PROF_NN_ATTN_H);
+    prof.work(4.0 * n_seq * heads * (double)L * L * kAtD, 4.0 * n_seq * heads * (double)L * kAtD * 4.0);
+    if (rot_table && ((uintptr_t)rot_table & 15)) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_attention_f16: rotary table must be 16-byte aligned");
     hipLaunchKernelGGL(nn_attn_h_kernel, grid, dim3(kHThreads), kAtLds, ctx->stream, qkv, out, L, heads, seq_stride, row_stride, o_seq_stride,
-                       o_row_stride, scale);
+                       o_row_stride, scale, rot_table, gates, g_seq_stride, g_row_stride);
     ALSEP_LAUNCH_CHECK(ctx, "nn_attn_h_kernel");
     return ALSEP_OK;
 }

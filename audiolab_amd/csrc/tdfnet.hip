@@ -3222,6 +3222,7 @@ int launch_conv(alsep_ctx* ctx, const ConvLayer& L, const T* X, T* Y, int64_t B,
     ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_kernel<T, KC, BN, TW>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
     ProfScope prof(ctx, TW == 64 ? ALSEP_PROF_CONV3X3 : ALSEP_PROF_CONV3X3_SMALL);
+    prof.work(18.0 * (double)L.cin * L.cout * B * Th * Fw, (double)sizeof(*X) * B * Th * Fw * (L.cin + L.cout));
     hipLaunchKernelGGL((conv3x3_kernel<T, KC, BN, TW>), dim3((unsigned)ntiles, L.cout / BN), dim3(kThreads),
                        Cf::lds_bytes, ctx->stream, X, Y, (const T*)L.w.p, (const float*)L.scale.p,
                        (const float*)L.shift.p, Th, Fw, L.cin, L.cout, tiles_t, tiles_f, (int)ntiles);
@@ -3270,6 +3271,7 @@ int launch_conv_dma(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)Cf::lds_bytes));
     ProfScope prof(ctx, TW == 64 ? ALSEP_PROF_CONV3X3 : ALSEP_PROF_CONV3X3_SMALL);
+    prof.work(18.0 * (double)L.cin * L.cout * B * Th * Fw, (double)sizeof(*X) * B * Th * Fw * (L.cin + L.cout));
     const int nyc = L.cout / Cf::BN;
     const int ny_fastest = conv_ny_fastest() && ntiles % 8 == 0 && nyc > 1 && ntiles * nyc <= 0x7fffffff;
     hipLaunchKernelGGL((conv3x3_bf16_kernel<TW>), ny_fastest ? dim3((unsigned)(ntiles * nyc)) : dim3((unsigned)ntiles, nyc),
@@ -3294,6 +3296,7 @@ int launch_conv_regw(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t
     int gx = OCC * 256 / ny;                                // OCC workgroups per CU over the whole grid
     if (gx > ntiles) gx = (int)ntiles;
     ProfScope prof(ctx, ALSEP_PROF_CONV3X3_REGW);
+    prof.work(18.0 * (double)L.cin * L.cout * B * Th * Fw, (double)sizeof(*X) * B * Th * Fw * (L.cin + L.cout));
     hipLaunchKernelGGL((conv3x3_bf16_regw_kernel<NQ, RING_, OCC, TW_>), dim3((unsigned)gx, ny), dim3(kThreads), Cf::lds_bytes, ctx->stream, X, Y,
                        (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
                        L.cout, tiles_t, tiles_f, (int)ntiles);
@@ -3313,6 +3316,7 @@ int launch_conv_pipe(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t
                                        (int)Cf::lds_bytes));
     const int gx = ntiles < 256 ? (int)ntiles : 256;        // one persistent workgroup per CU
     ProfScope prof(ctx, ALSEP_PROF_CONV3X3_PIPE);
+    prof.work(18.0 * (double)L.cin * L.cout * B * Th * Fw, (double)sizeof(*X) * B * Th * Fw * (L.cin + L.cout));
     hipLaunchKernelGGL((conv3x3_bf16_pipe_kernel<NY>), dim3((unsigned)gx), dim3(kThreads), Cf::lds_bytes, ctx->stream, X, Y,
                        (const bf16_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, zero_page, Th, Fw, L.cin,
                        L.cout, tiles_t, tiles_f, (int)ntiles);
@@ -3370,6 +3374,7 @@ int launch_conv_big(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     constexpr int swp = 0;
 #endif
     ProfScope prof(ctx, NY == 3 ? ALSEP_PROF_CONV3X3_BIG3 : ALSEP_PROF_CONV3X3_BIG);
+    prof.work(18.0 * (double)L.cin * L.cout * B * Th * Fw, (double)sizeof(*X) * B * Th * Fw * (L.cin + L.cout));
 #if defined(ALSEP_EXPERIMENTS) && !defined(ALSEP_CPU_EMUL)
     // ALSEP_CONV_BIG_STAMP=n (timing experiments): the first n launches run the stamped variant, synchronise and print the per-phase
     // cycle sums (mean over waves, and waves 0 / 7 of workgroup 0) to stderr
@@ -3442,6 +3447,7 @@ int launch_conv_mny(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t*
     ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_bf16_mny_kernel<NY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cf::lds_bytes));
     const int gx = ntiles < 256 ? (int)ntiles : 256;
     ProfScope prof(ctx, NY == 3 ? ALSEP_PROF_CONV3X3_BIG3 : ALSEP_PROF_CONV3X3_BIG);
+    prof.work(18.0 * (double)L.cin * L.cout * B * Th * Fw, (double)sizeof(*X) * B * Th * Fw * (L.cin + L.cout));
 #if defined(ALSEP_EXPERIMENTS) && !defined(ALSEP_CPU_EMUL)
     static int stamp_left = [] { const char* e = getenv("ALSEP_CONV_BIG_STAMP"); return e ? atoi(e) : 0; }();
     if (stamp_left > 0) {
@@ -3488,6 +3494,7 @@ int launch_conv_mq(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* 
     if (!L.w_mq.p || L.cout != Cf::ROWS || L.cin % Cf::KC) return alsep_fail(ctx, ALSEP_ERR_STATE, "conv3x3: no mq weight image for this layer");
     const int gx = ntiles < 256 ? (int)ntiles : 256;
     ProfScope prof(ctx, ALSEP_PROF_CONV3X3_BIG);
+    prof.work(18.0 * (double)L.cin * L.cout * B * Th * Fw, (double)sizeof(*X) * B * Th * Fw * (L.cin + L.cout));
 #if defined(ALSEP_EXPERIMENTS) && !defined(ALSEP_CPU_EMUL)
     static int stamp_left = [] { const char* e = getenv("ALSEP_CONV_BIG_STAMP"); return e ? atoi(e) : 0; }();
     if (stamp_left > 0) {
@@ -3544,6 +3551,7 @@ int launch_conv_m0(alsep_ctx* ctx, const ConvLayer& L, const bf16_t* X, bf16_t* 
     constexpr int defer = 0;
 #endif
     ProfScope prof(ctx, ALSEP_PROF_CONV3X3_REGW);
+    prof.work(18.0 * (double)L.cin * L.cout * B * Th * Fw, (double)sizeof(*X) * B * Th * Fw * (L.cin + L.cout));
 #if defined(ALSEP_EXPERIMENTS) && !defined(ALSEP_CPU_EMUL)
     static int stamp_left = [] { const char* e = getenv("ALSEP_CONV_M0_STAMP"); return e ? atoi(e) : 0; }();
     if (stamp_left > 0) {

@@ -417,6 +417,8 @@ extern "C" int alsep_nn_conv2d(alsep_ctx* ctx, const float* x, const float* w, c
     const int64_t npix = B * Ho * Wo;
     const int64_t gx = ceil_div64(npix, 128);
     if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d: too many pixels");
+    ProfScope prof(ctx, ALSEP_PROF_NN_CONV);
+    prof.work(2.0 * (double)npix * Cout * Cin * KH * KW, 4.0 * ((double)B * H * W * Cin + (double)npix * Cout + (double)KH * KW * Cin * Cout));
     if (conv_tiled_ok(x, w, Cin, Cout, npix) && gx <= 65535) {
         launch_conv_tiled(ctx, x, w, scale, shift, y, npix, H, W, Cin, Cout, Ho, Wo, KH, KW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w,
                           act, y_ctotal, y_coff);

@@ -72,3 +72,37 @@ def all_reduce_partial(acc: torch.Tensor, group: Optional[dist.ProcessGroup] = N
     contribution; one collective (ncclAllReduce on RCCL, gloo in tests)."""
     dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
     return acc
+
+
+def all_gather_ranges(local: torch.Tensor, ranges: List[Tuple[int, int]], total: int,
+                      group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """local: [..., hi - lo] this rank's finished samples of its own range ``ranges[rank]`` (ranges: disjoint, ascending, covering
+    [0, total)) -> [..., total] on every rank.  ONE all-gather of the stem segments (padded to the longest range), as north_star names it."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = ranges[rank]
+    if local.shape[-1] != hi - lo:
+        raise ValueError(f"rank {rank}: local segment has {local.shape[-1]} samples, expected {hi - lo}")
+    width = max(max(h - l for l, h in ranges), 1)
+    lead = local.shape[:-1]
+    send = torch.zeros(lead + (width,), dtype=local.dtype, device=local.device)
+    send[..., : hi - lo] = local
+    recv = torch.empty((world,) + lead + (width,), dtype=local.dtype, device=local.device)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    else:
+        dist.all_gather(list(recv.unbind(0)), send.contiguous(), group=group)
+    out = torch.empty(lead + (total,), dtype=local.dtype, device=local.device)
+    for r, (l, h) in enumerate(ranges):
+        out[..., l:h] = recv[r][..., : h - l]
+    return out
+
+
+def all_gather_fixed(local: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """[...] of the same shape on every rank -> [world, ...] (the seam sums of neighbouring shards: a few MB per rank)"""
+    world = dist.get_world_size(group)
+    recv = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(recv, local.contiguous(), group=group)
+    else:
+        dist.all_gather(list(recv.unbind(0)), local.contiguous(), group=group)
+    return recv

@@ -495,8 +495,11 @@ class Separator:
         return self._separate_pair(m)
 
     def _separate_pair(self, m: torch.Tensor) -> Dict[str, torch.Tensor]:
-        m = m.to(self.ctx.device).contiguous()
         inst = self.model_instance
+        if (self.chunker == "ola" and self.sharded and inst.predictor is not None and not inst.extra and inst.demucs is None
+                and inst.vr is None and inst.roformer is None):
+            return self._separate_pair_ola(m.contiguous(), inst)     # the runner uploads this rank's share only (m may live on the host)
+        m = m.to(self.ctx.device).contiguous()
         if inst.demucs is not None:                             # all sources from one pass; labels as DemucsSeparator names its files
             return {name.capitalize(): t for name, t in inst.demucs.separate(m).items()}
         if inst.vr is not None:                                 # both stems come from the network's spectrogram split; the back end
@@ -534,6 +537,26 @@ class Separator:
         way; the secondary stem is, with ``invert_using_spec`` (AudioLab's setting, stem_separator.py:104), the spectral inversion of
         the primary against the model-path rendition of the mix (the ``is_match_mix`` pass), else ``mix - primary``."""
         from . import ensemble
+        if self.sharded and m.device != self.ctx.device:
+            # host-resident programme, chunks sharded: the gain of the input normalisation is a scalar (global peak, one pass on the host),
+            # applied by each rank to the samples it uploads; the stems come back whole from the runner's all-gather
+            peak = float(m.abs().max()) if m.numel() else 0.0
+            gain = self.normalization / peak if (self.normalization and peak > self.normalization) else 1.0
+            primary = inst.predictor.demix(m, in_scale=gain)
+            if self.normalization:
+                primary = ensemble.normalize(self.ctx, primary, self.normalization)
+            out = {inst.primary_stem_name: primary}
+            if inst.secondary_stem_name:
+                if self.invert_using_spec:
+                    raw_mix = inst.predictor.demix(m, match_mix=True, in_scale=gain)
+                    out[inst.secondary_stem_name] = ensemble.invert_stem(self.ctx, raw_mix, primary)
+                else:
+                    sec = m.to(self.ctx.device, dtype=torch.float32)
+                    self.ctx.check(self.ctx.lib.alsep_axpby(self.ctx.handle, -1.0, _lib.ptr(primary.contiguous()), float(gain), _lib.ptr(sec),
+                                                            sec.numel()), "alsep_axpby")
+                    out[inst.secondary_stem_name] = sec
+            return out
+        m = m.to(self.ctx.device)
         mixn = ensemble.normalize(self.ctx, m.clone(), self.normalization) if self.normalization else m
         primary = inst.predictor.demix(mixn)
         if self.normalization:

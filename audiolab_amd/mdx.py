@@ -290,12 +290,17 @@ class OlaRunner:
         self.overlap, self.zero_low_bins, self.compensate, self.denoise = overlap, zero_low_bins, compensate, denoise
         self.max_batch = max_batch
 
-    def demix(self, mix: torch.Tensor, match_mix: bool = False) -> torch.Tensor:
-        """mix [2,N] float32 on the device -> [2,N].  ``match_mix=True`` is the package's ``is_match_mix`` pass: the same framing
+    def demix(self, mix: torch.Tensor, match_mix: bool = False, in_scale: float = 1.0) -> torch.Tensor:
+        """mix [2,N] float32 (scaled by ``in_scale`` on the device: the engine's input normalisation) -> [2,N] on the device.  ``match_mix=True`` is the package's ``is_match_mix`` pass: the same framing
         without the network at overlap 0.02 -- the mixture as the model path sees it (bins < 3 and >= dim_f removed), which
-        ``invert_using_spec`` subtracts the primary stem from."""
+        ``invert_using_spec`` subtracts the primary stem from.
+
+        Sharded (``sharded=True``): rank r owns a contiguous range of chunks.  It uploads / frames only the samples those
+        chunks cover (``mix`` may live on the host: a 60-minute 8-channel programme need not sit on every GPU), accumulates the
+        windowed sums over ITS span, and owns the output samples from its first chunk's start to the next rank's.  Its chunks reach up
+        to ``chunk - step`` samples into the following ranks' ranges: those seam sums (a few MB) are exchanged by one small all-gather
+        and added locally, each rank divides its own range, and ONE all-gather of the finished stem segments assembles the track."""
         plan, ctx = self.plan, self.ctx
-        mix = mix.contiguous().float()
         n = mix.shape[-1]
         chunk, trim, gen = plan.chunk_size, plan.trim, plan.gen_size
         pad = gen + trim - (n % gen)
@@ -303,36 +308,70 @@ class OlaRunner:
         overlap = 0.02 if match_mix else self.overlap
         step = int((1 - overlap) * chunk)
         n_chunks = (total + step - 1) // step
-        buf_len = (n_chunks - 1) * step + chunk              # chunks cut by the end see zeros
-        mixture = ctx.zeros((2, buf_len), torch.float32)
-        mixture[:, trim:trim + n] = mix
-        c_lo, c_hi = 0, n_chunks
+        use_window = 1 if overlap != 0 else 0
+        compensate = 1.0 if match_mix else float(self.compensate)
+        c_lo, c_hi, world, rank = 0, n_chunks, 1, 0
         if self.sharded:
             import torch.distributed as tdist
             from . import dist as adist
-            c_lo, c_hi = adist.window_range(n_chunks, tdist.get_world_size(self.group), tdist.get_rank(self.group))
+            world, rank = tdist.get_world_size(self.group), tdist.get_rank(self.group)
+            c_lo, c_hi = adist.window_range(n_chunks, world, rank)
         n_local = c_hi - c_lo
+        # the padded mixture over this rank's chunks only: padded coordinates [a0, a0 + buf_len); chunks cut by the end see zeros
+        a0 = c_lo * step
+        buf_len = (max(n_local, 1) - 1) * step + chunk
+        mixture = ctx.zeros((2, buf_len), torch.float32)
+        s_lo, s_hi = max(a0 - trim, 0), min(a0 + buf_len - trim, n)           # the samples of `mix` under it
+        if s_hi > s_lo:
+            mixture[:, s_lo + trim - a0: s_hi + trim - a0] = mix[:, s_lo:s_hi].to(ctx.device, dtype=torch.float32)
+            if in_scale != 1.0:
+                ctx.check(ctx.lib.alsep_axpby(ctx.handle, 0.0, _lib.ptr(mixture), float(in_scale), _lib.ptr(mixture), mixture.numel()), "alsep_axpby")
         waves = ctx.empty((max(n_local, 1), 2, chunk), torch.float32)
         bstep = self.max_batch if self.max_batch > 0 else max(n_local, 1)
         for b0 in range(c_lo, c_hi, bstep):
             nb = min(bstep, c_hi - b0)
-            spek = plan.stft_strided(mixture, buf_len, step, nb, self.net.dtype, _lib.LAYOUT_NHWC, pcm_offset=b0 * step)
+            spek = plan.stft_strided(mixture, buf_len, step, nb, self.net.dtype, _lib.LAYOUT_NHWC, pcm_offset=(b0 - c_lo) * step)
             if self.zero_low_bins:
                 ctx.check(ctx.lib.alsep_zero_low_bins(ctx.handle, _lib.ptr(spek), _lib.dtype_code(spek.dtype), _lib.LAYOUT_NHWC,
                                                       nb, plan.dim_f, plan.dim_t, self.zero_low_bins), "alsep_zero_low_bins")
             pred = spek if match_mix else self.net.forward_nhwc(spek, denoise=self.denoise)
             plan.istft_strided(pred, _lib.LAYOUT_NHWC, waves, chunk, 2 * chunk, 0, chunk, (nb - 1) * 2 * chunk + chunk,
                                out_offset=(b0 - c_lo) * 2 * chunk)
-        out = ctx.empty((2, n), torch.float32)
-        use_window = 1 if overlap != 0 else 0
-        compensate = 1.0 if match_mix else float(self.compensate)
         if not self.sharded:
+            out = ctx.empty((2, n), torch.float32)
             ctx.check(ctx.lib.alsep_ola_combine(ctx.handle, _lib.ptr(waves), n_chunks, chunk, step, total, use_window,
                                                 compensate, _lib.ptr(out), n, trim, n), "alsep_ola_combine")
             return out
-        part = ctx.empty((3, n), torch.float32)
-        ctx.check(ctx.lib.alsep_ola_partial(ctx.handle, _lib.ptr(waves), c_lo, c_hi, chunk, step, total, use_window, _lib.ptr(part),
-                                            trim, n), "alsep_ola_partial")
-        part = adist.all_reduce_partial(part, self.group)
-        ctx.check(ctx.lib.alsep_ola_finish(ctx.handle, _lib.ptr(part), compensate, _lib.ptr(out), n, n), "alsep_ola_finish")
-        return out
+        # own output ranges in padded coordinates, clipped to the kept region [trim, trim + n): rank q owns from its first chunk's start
+        # (rank 0: from trim) to the next rank's (the last rank: to the end)
+        bounds = [adist.window_range(n_chunks, world, q) for q in range(world)]
+        starts = [min(max(b[0] * step, trim), trim + n) for b in bounds] + [trim + n]
+        starts[0] = trim
+        own_lo, own_hi = starts[rank], starts[rank + 1]
+        seam = chunk - step                                                   # how far a rank's chunks reach beyond its own range
+
+        def partial(p_lo, length):
+            part = ctx.zeros((3, max(length, 1)), torch.float32)
+            if n_local > 0 and length > 0:
+                ctx.check(ctx.lib.alsep_ola_partial(ctx.handle, _lib.ptr(waves), c_lo, c_hi, chunk, step, total, use_window, _lib.ptr(part),
+                                                    p_lo, length), "alsep_ola_partial")
+            return part
+        own = partial(own_lo, own_hi - own_lo)
+        tail_lo = min(c_hi * step if n_local > 0 else own_hi, total)          # this rank's sums beyond its own range: [tail_lo, tail_lo + seam)
+        tail_len = max(0, min(seam, total - tail_lo))
+        tail = ctx.zeros((3, max(seam, 1)), torch.float32)
+        if tail_len > 0 and n_local > 0:
+            tail[:, :tail_len] = partial(tail_lo, tail_len)[:, :tail_len]
+        tails = adist.all_gather_fixed(tail, self.group)                      # [world, 3, seam]
+        for q in range(rank):                                                 # earlier ranks whose chunks reach into this rank's range
+            q_lo = min(bounds[q][1] * step, total) if bounds[q][1] > bounds[q][0] else None
+            if q_lo is None:
+                continue
+            lo, hi = max(q_lo, own_lo), min(q_lo + seam, own_hi)
+            if hi > lo:
+                own[:, lo - own_lo: hi - own_lo] += tails[q][:, lo - q_lo: hi - q_lo]
+        seg = ctx.empty((2, max(own_hi - own_lo, 1)), torch.float32)
+        if own_hi > own_lo:
+            ctx.check(ctx.lib.alsep_ola_finish(ctx.handle, _lib.ptr(own), compensate, _lib.ptr(seg), seg.shape[1], own_hi - own_lo), "alsep_ola_finish")
+        ranges = [(starts[q] - trim, starts[q + 1] - trim) for q in range(world)]
+        return adist.all_gather_ranges(seg[:, : own_hi - own_lo].contiguous(), ranges, n, self.group)

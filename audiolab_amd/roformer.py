@@ -168,7 +168,9 @@ class Roformer:
         """``precision``: "f32" -- every product on the exact-fp32 MFMA (the 1e-4 parity mode); "f16" -- the arithmetic of the reference's
         ``use_autocast=True`` (stem_separator.py:106): the Linear layers of the transformer blocks and of the mask estimators and the
         attention products take IEEE-half operands (csrc/nn_half.hip: f16 MFMA, float32 accumulation, one-pass attention), norms /
-        rotary / softmax statistics / residuals / STFT stay float32.  The per-band input projections (ragged widths) stay float32."""
+        rotary / softmax statistics / residuals / STFT stay float32.  The per-band layers (input projections, mask estimators) run as one
+        batched GEMM per layer over all bands (zero-padded to the widest band), the rotary embedding and the head gates inside the
+        attention kernel: ~105 launches per chunk instead of ~600."""
         if precision not in ("f32", "f16"):
             raise AlsepError("Roformer precision must be 'f32' or 'f16'")
         self.cfg = cfg
@@ -185,6 +187,7 @@ class Roformer:
                       *((f"mask_estimators.{s_}.to_freqs.0.0.net.{2 * cfg.mask_estimator_depth}.", f"mask_estimator_depth={cfg.mask_estimator_depth}")
                         for s_ in range(cfg.num_stems))))
         self.nb = len(bands)
+        self._bands = bands
         self.band_len = [len(b) for b in bands]
         self.band_off = np.concatenate([[0], np.cumsum(self.band_len)]).astype(np.int64)      # offsets in merged-index entries
         self.n_idx = int(self.band_off[-1])
@@ -225,6 +228,91 @@ class Roformer:
         except KeyError as e:
             raise AlsepError(f"state_dict is missing {e} for this RoformerConfig") from e
         self._plans: Dict[int, object] = {}
+        self._rot: Dict[int, torch.Tensor] = {}                # rotary tables per sequence length (half mode)
+        self._mask_cols: Dict[int, tuple] = {}                 # mask-kernel column tables of the padded estimator output, per frame count
+        if half:
+            self._build_half_images(sd, bands)
+
+    def _build_half_images(self, sd, bands) -> None:
+        """Half mode runs the per-band layers (input projections, mask estimators) as ONE batched f16 GEMM per layer over all bands:
+        the ragged widths are zero-padded to the widest band (K of the input projections, N of the estimators' last layers; the
+        kernel skips the column tiles beyond a band's true N)."""
+        ctx, cfg, dev = self.ctx, self.cfg, self.ctx.device
+        nb, dim = self.nb, cfg.dim
+
+        def f16(t: torch.Tensor) -> torch.Tensor:
+            src = t.detach().float().contiguous().to(dev)
+            dst = torch.empty(src.shape, dtype=torch.float16, device=dev)
+            ctx.check(ctx.lib.alsep_nn_to_f16(ctx.handle, _lib.ptr(src), _lib.ptr(dst), src.numel()), "alsep_nn_to_f16")
+            return dst
+        widths = [2 * len(b) for b in bands]
+        kmax = -(-max(widths) // 8) * 8
+        if kmax > 640:
+            raise AlsepError("Roformer half mode: a band wider than 320 bins is not supported")
+        pidx = torch.full((nb, kmax // 2), -1, dtype=torch.int32)
+        gam = torch.zeros((nb, kmax))
+        w0 = torch.zeros((nb, dim, kmax))
+        b0 = torch.zeros((nb, dim))
+        for i, idx in enumerate(bands):
+            pidx[i, : len(idx)] = torch.from_numpy(np.asarray(idx, dtype=np.int32))
+            gam[i, : widths[i]] = sd[f"band_split.to_features.{i}.0.gamma"].float()
+            w0[i, :, : widths[i]] = sd[f"band_split.to_features.{i}.1.weight"].float()
+            b0[i] = sd[f"band_split.to_features.{i}.1.bias"].float()
+        self.h_kmax = kmax
+        self.h_pidx, self.h_gamma = pidx.to(dev), gam.contiguous().to(dev)
+        self.h_width = torch.tensor(widths, dtype=torch.int32, device=dev)
+        self.h_split_w, self.h_split_b = f16(w0), b0.contiguous().to(dev)
+        # mask estimators: per stem a list of layers (stacked weights f16 [nb][out][in], bias [nb][out], per-band out or None)
+        nouts = [4 * len(b) for b in bands]
+        self.h_nmax = -(-max(nouts) // 4) * 4
+        self.h_nout = torch.tensor(nouts, dtype=torch.int32, device=dev)
+        self.h_masks = []
+        for s_ in range(cfg.num_stems):
+            layers = []
+            for j in range(cfg.mask_estimator_depth):
+                last = j + 1 == cfg.mask_estimator_depth
+                ws = [sd[f"mask_estimators.{s_}.to_freqs.{i}.0.net.{2 * j}.weight"].float() for i in range(nb)]
+                bs = [sd[f"mask_estimators.{s_}.to_freqs.{i}.0.net.{2 * j}.bias"].float() for i in range(nb)]
+                k_in = ws[0].shape[1]
+                n_out = self.h_nmax if last else ws[0].shape[0]
+                wst, bst = torch.zeros((nb, n_out, k_in)), torch.zeros((nb, n_out))
+                for i in range(nb):
+                    wst[i, : ws[i].shape[0]] = ws[i]
+                    bst[i, : bs[i].shape[0]] = bs[i]
+                layers.append((f16(wst), bst.contiguous().to(dev), n_out, k_in, last))
+            self.h_masks.append(layers)
+
+    def _rot_table(self, L: int) -> torch.Tensor:
+        if L not in self._rot:
+            t = self.ctx.empty((L, self.cfg.dim_head // 2, 2))
+            self.ctx.check(self.ctx.lib.alsep_nn_rotary_table(self.ctx.handle, _lib.ptr(t), L, self.cfg.dim_head), "alsep_nn_rotary_table")
+            self._rot[L] = t
+        return self._rot[L]
+
+    def _padded_mask_cols(self, T: int):
+        """col_a / col_g of roformer_mask for the PADDED estimator output [bands][T][nmax]: entry = band * T * nmax + column in the band"""
+        if T not in self._mask_cols:
+            nmax = self.h_nmax
+            a, g = [], []
+            occ: List[List[Tuple[int, int]]] = [[] for _ in range(2 * self.cfg.n_freq)]
+            for bi, idx in enumerate(self._bands):
+                base, n = bi * T * nmax, 2 * len(idx)
+                for i, m in enumerate(idx):
+                    occ[int(m)].append((base + 2 * i, base + n + 2 * i))
+            for o in occ:
+                for ca, cg in o:
+                    a.append(ca)
+                    g.append(cg)
+            dev = self.ctx.device
+            self._mask_cols[T] = (torch.tensor(a, dtype=torch.int32, device=dev), torch.tensor(g, dtype=torch.int32, device=dev))
+        return self._mask_cols[T]
+
+    def _bgemm_h(self, a: torch.Tensor, lda: int, sa_b: int, w: torch.Tensor, bias: torch.Tensor, c_ptr: int, ldc: int, sc_b: int, M: int, N: int,
+                 K: int, act: int = 0, nvec: Optional[torch.Tensor] = None) -> None:
+        """one batched f16 GEMM over the bands: C[b] = act(A[b] W[b]^T + bias[b])"""
+        ctx = self.ctx
+        ctx.check(ctx.lib.alsep_nn_gemm_f16w(ctx.handle, _lib.ptr(a), lda, sa_b, _lib.ptr(w), K, N * K, C.c_void_p(c_ptr), ldc, sc_b, _lib.ptr(bias), N,
+                                             None, 0, 0, self.nb, M, N, K, 1.0, act, _lib.ptr(nvec) if nvec is not None else None), "alsep_nn_gemm_f16w")
 
     # -- helpers --------------------------------------------------------------------------------------------
     def _gemm(self, a_ptr: int, sa, lin: _Lin, c_ptr: int, sc, M: int, act: int = 0, nb1: int = 1, nb2: int = 1, use_bias: bool = True,
@@ -235,7 +323,7 @@ class Roformer:
         if (lin.wh is not None and nb1 == 1 and nb2 == 1 and sa[3] == 1 and sc[3] == 1 and sa[2] % 4 == 0 and sc[2] % 4 == 0
                 and a_ptr % 16 == 0 and c_ptr % 16 == 0):
             ctx.check(ctx.lib.alsep_nn_gemm_f16w(ctx.handle, C.c_void_p(a_ptr), sa[2], 0, _lib.ptr(lin.wh), lin.inp, 0, C.c_void_p(c_ptr), sc[2], 0,
-                                                 bias, 0, C.c_void_p(res_ptr) if res_ptr else None, res_ld, 0, 1, M, lin.out, lin.inp, 1.0, act),
+                                                 bias, 0, C.c_void_p(res_ptr) if res_ptr else None, res_ld, 0, 1, M, lin.out, lin.inp, 1.0, act, None),
                       "alsep_nn_gemm_f16w")
             return
         if res_ptr:
@@ -272,9 +360,11 @@ class Roformer:
         rows = T * nb
         xn = self._rmsnorm(x, rows, dim, P["norm"])
         qkv = self._dense(xn, rows, P["qkv"])                                 # [rows, 3 inner], columns (qkv, head, d)
+        fused = self.precision == "f16" and d == 64                           # rotary embedding and head gates inside the attention kernel
         pos = (nb, T) if over_time else (1, nb)                               # row r = t * bands + f: position t, or f
-        for off in (0, inner):
-            ctx.check(lib.alsep_nn_rotary(h, _lib.ptr(qkv), rows, 3 * inner, off, Hh, d, pos[0], pos[1]), "alsep_nn_rotary")
+        if not fused:
+            for off in (0, inner):
+                ctx.check(lib.alsep_nn_rotary(h, _lib.ptr(qkv), rows, 3 * inner, off, Hh, d, pos[0], pos[1]), "alsep_nn_rotary")
         arr = C.c_int64 * 4
         ld = 3 * inner
         if over_time:                                                         # batch (band, head); a sequence's rows are bands * ld apart
@@ -283,9 +373,11 @@ class Roformer:
             n_seq, L, seq_stride, row_stride = T, nb, nb * ld, ld
         att = ctx.empty((rows, inner))
         o_seq, o_row = (inner, nb * inner) if over_time else (nb * inner, inner)
-        if self.precision == "f16" and d == 64:                               # one pass: scores never reach HBM
+        if fused:                                                             # one pass: scores never reach HBM
+            gates = self._dense(xn, rows, P["gates"])
+            g_seq, g_row = (Hh, nb * Hh) if over_time else (nb * Hh, Hh)
             ctx.check(lib.alsep_nn_attention_f16(h, _lib.ptr(qkv), _lib.ptr(att), n_seq, L, Hh, d, seq_stride, row_stride, o_seq, o_row,
-                                                 d ** -0.5), "alsep_nn_attention_f16")
+                                                 d ** -0.5, _lib.ptr(self._rot_table(L)), _lib.ptr(gates), g_seq, g_row), "alsep_nn_attention_f16")
         else:
             Lp = -(-L // 4) * 4                                                # score rows padded to 16 bytes: the tiled GEMM's float4 loads
             scores = ctx.empty((n_seq, Hh, L, Lp))
@@ -296,8 +388,9 @@ class Roformer:
             ctx.check(lib.alsep_nn_softmax_rows_ld(h, _lib.ptr(scores), n_seq * Hh * L, L, Lp), "alsep_nn_softmax_rows_ld")
             ctx.check(lib.alsep_nn_bgemm(h, _lib.ptr(scores), C.c_void_p(base + 8 * inner), _lib.ptr(att), n_seq, Hh, L, d, L,
                                          arr(Hh * L * Lp, L * Lp, Lp, 1), arr(seq_stride, d, 1, row_stride), arr(o_seq, d, o_row, 1), 1.0), "alsep_nn_bgemm")
-        gates = self._dense(xn, rows, P["gates"])
-        ctx.check(lib.alsep_nn_gate(h, _lib.ptr(att), _lib.ptr(gates), rows, Hh, d), "alsep_nn_gate")
+        if not fused:
+            gates = self._dense(xn, rows, P["gates"])
+            ctx.check(lib.alsep_nn_gate(h, _lib.ptr(att), _lib.ptr(gates), rows, Hh, d), "alsep_nn_gate")
         x1 = self._dense(att, rows, P["out"], residual=x)
         f = self._dense(self._rmsnorm(x1, rows, dim, P["ffn"]), rows, P["l1"], act=3)
         return self._dense(f, rows, P["l2"], residual=x1)
@@ -322,15 +415,23 @@ class Roformer:
         T, Fq, nb, dim = L // cfg.hop + 1, cfg.n_freq, self.nb, cfg.dim
         plan = self._plan(T)
         spec = plan.stft_strided(audio, L, 2 * L, 1, torch.float32, _lib.LAYOUT_REF)        # [1, 4, Fq, T]
-        feat = ctx.empty((T, 2 * self.n_idx))
-        ctx.check(lib.alsep_roformer_gather(h, _lib.ptr(spec), _lib.ptr(self.midx), _lib.ptr(feat), self.n_idx, Fq, T), "alsep_roformer_gather")
         x = ctx.empty((T, nb, dim))
-        FW = 2 * self.n_idx
-        for i, (gamma, lin) in enumerate(self.split):                         # band split: RMSNorm + Linear per band, on column slices
-            col = 2 * int(self.band_off[i])
-            p = feat.data_ptr() + 4 * col
-            ctx.check(lib.alsep_nn_rmsnorm(h, C.c_void_p(p), C.c_void_p(p), _lib.ptr(gamma), T, lin.inp, FW, FW), "alsep_nn_rmsnorm")
-            self._gemm(p, (0, 0, FW, 1), lin, x.data_ptr() + 4 * i * dim, (0, 0, nb * dim, 1), T)
+        half = self.precision == "f16"
+        if half:                                                              # all bands: one gather + RMSNorm launch, one batched f16 GEMM
+            kmax = self.h_kmax
+            featp = ctx.empty((nb, T, kmax))
+            ctx.check(lib.alsep_roformer_bandsplit_in(h, _lib.ptr(spec), _lib.ptr(self.h_pidx), _lib.ptr(self.h_gamma), _lib.ptr(self.h_width),
+                                                      _lib.ptr(featp), nb, Fq, T, kmax), "alsep_roformer_bandsplit_in")
+            self._bgemm_h(featp, kmax, T * kmax, self.h_split_w, self.h_split_b, x.data_ptr(), nb * dim, dim, T, dim, kmax)
+        else:
+            feat = ctx.empty((T, 2 * self.n_idx))
+            ctx.check(lib.alsep_roformer_gather(h, _lib.ptr(spec), _lib.ptr(self.midx), _lib.ptr(feat), self.n_idx, Fq, T), "alsep_roformer_gather")
+            FW = 2 * self.n_idx
+            for i, (gamma, lin) in enumerate(self.split):                     # band split: RMSNorm + Linear per band, on column slices
+                col = 2 * int(self.band_off[i])
+                p = feat.data_ptr() + 4 * col
+                ctx.check(lib.alsep_nn_rmsnorm(h, C.c_void_p(p), C.c_void_p(p), _lib.ptr(gamma), T, lin.inp, FW, FW), "alsep_nn_rmsnorm")
+                self._gemm(p, (0, 0, FW, 1), lin, x.data_ptr() + 4 * i * dim, (0, 0, nb * dim, 1), T)
         for pair in self.layers:
             x = self._transformer(x, T, pair[0], over_time=True)
             x = self._transformer(x, T, pair[1], over_time=False)
@@ -338,6 +439,19 @@ class Roformer:
         out = ctx.empty((cfg.num_stems, 2, L))
         hidden = cfg.dim * cfg.mlp_expansion_factor
         for s in range(cfg.num_stems):
+            if half:                                                          # every estimator layer: one batched f16 GEMM over the bands
+                cur, lda, sa_b = x, nb * dim, dim                             # layer input [band][T][k]: band i of x sits at column offset i * dim
+                for wst, bst, n_out, k_in, last in self.h_masks[s]:
+                    y = ctx.empty((nb, T, n_out))
+                    self._bgemm_h(cur, lda, sa_b, wst, bst, y.data_ptr(), n_out, T * n_out, T, n_out, k_in, act=0 if last else 5,
+                                  nvec=self.h_nout if last else None)
+                    cur, lda, sa_b = y, n_out, T * n_out
+                col_a, col_g = self._padded_mask_cols(T)
+                masked = ctx.empty((1, 4, Fq, T))
+                ctx.check(lib.alsep_roformer_mask(h, _lib.ptr(spec), _lib.ptr(cur), _lib.ptr(self.occ_start), _lib.ptr(col_a), _lib.ptr(col_g),
+                                                  _lib.ptr(masked), Fq, T, self.h_nmax), "alsep_roformer_mask")
+                plan.istft_strided(masked, _lib.LAYOUT_REF, out[s], L, 2 * L, 0, L, L)
+                continue
             hm = ctx.empty((T, self.H))
             for i in range(nb):
                 cur_ptr, cur_stride = x.data_ptr() + 4 * i * dim, nb * dim

@@ -157,9 +157,67 @@ def cpu_baseline(cfg, sd, mix_np, n_windows: int):
                       f"median of {reps} run(s): {dt:.1f} s wall"}
 
 
+# ---- supplementary workloads: BASELINE configs[2] / [3] / [4] and single models of the reference's roster --------------------------------
+# (category, kernel name(s) of that class, bound, peak, unit): the classes a family's step can be dominated by
+def _kernel_classes(lib_mod):
+    return [
+        ("nn_gemm_h_kernel", lib_mod.PROF_NN_GEMM_H, PEAK_BF16_TFLOPS), ("nn_attn_h_kernel", lib_mod.PROF_NN_ATTN_H, PEAK_BF16_TFLOPS),
+        ("nn_gemm_tn_kernel / nn_bgemm_kernel (f32 MFMA)", lib_mod.PROF_NN_GEMM, PEAK_F32_TFLOPS),
+        ("nn_conv2d_tiled_kernel / nn_conv2d_kernel (f32 MFMA)", lib_mod.PROF_NN_CONV, PEAK_F32_TFLOPS),
+        ("conv3x3_bf16_m0_kernel / regw (level 0)", lib_mod.PROF_CONV3X3_REGW, PEAK_BF16_TFLOPS),
+        ("conv3x3_bf16_mq_kernel (level 1)", lib_mod.PROF_CONV3X3_BIG, PEAK_BF16_TFLOPS),
+        ("conv3x3_bf16_big_kernel<3> (level 2)", lib_mod.PROF_CONV3X3_BIG3, PEAK_BF16_TFLOPS),
+        ("conv3x3_bf16_kernel<64> (levels 3+)", lib_mod.PROF_CONV3X3, PEAK_BF16_TFLOPS),
+    ]
+
+
+def family_roofline(ctx, lib_mod, run_once, fence):
+    """Roofline object of the kernel class with the largest share of one step: one untimed pass per class with that class's launches
+    bracketed by HIP events on the launch stream (alsep_profile_*); flops / minimal bytes as the launch sites count them.  The passes
+    run the model's units one after the other (one lane): kernels of concurrent lanes would share the chip and stretch each other."""
+    best = None
+    for name, cat, peak_tf in _kernel_classes(lib_mod):
+        ctx.profile_begin(cat)
+        run_once()
+        fence()
+        flops, byts = ctx.profile_work()
+        ms, launches = ctx.profile_end()
+        if launches and (best is None or ms > best[1]):
+            best = (name, ms, launches, flops, byts, peak_tf)
+    if best is None:
+        return None
+    name, ms, launches, flops, byts, peak_tf = best
+    tfl, gbs = flops / (ms * 1e-3) / 1e12, byts / (ms * 1e-3) / 1e9
+    ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+    e = {"kernel": name}
+    if flops / max(byts, 1.0) >= ridge:
+        e.update({"bound": "mfma", "achieved": round(tfl, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(tfl / peak_tf, 4), "gbs": round(gbs, 1)})
+    else:
+        e.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                  "tflops": round(tfl, 2)})
+    e.update({"traffic": None, "launches": launches, "avg_us": round(ms * 1e3 / launches, 2), "flops_per_launch": flops / launches,
+              "bytes_per_launch": byts / launches, "class_ms_per_step": round(ms, 2), "lanes": 1})
+    return e
+
+
+def _timed_cpu(fn, stems: float, seconds: float, what: str):
+    """cpu_baseline object: ``fn`` (an oracle run over ``seconds`` of audio yielding ``stems`` stems) timed once after setting the torch
+    thread count to the host's cores (capped at 64: the oracle's convolutions stop scaling there, see the mdx4 line's sweep)"""
+    cores = os.cpu_count() or 1
+    th = min(cores, 64)
+    torch.set_num_threads(th)
+    t0 = time.perf_counter()
+    fn()
+    dt = time.perf_counter() - t0
+    return {"value": round(stems * seconds / dt, 4), "unit": "stems*x_realtime", "cores": th, "kind": "port",
+            "host": f"{_cpu_model()} ({cores} logical cores; {th} torch threads)", "sample": f"{what}; one run: {dt:.1f} s wall"}
+
+
 def other_workload(args) -> None:
-    """Supplementary bench lines for BASELINE configs[2] / [3] / [4] (same JSON shape; no per-kernel roofline: these runs exist to
-    put a measured number and the multi-GPU structure next to each config, the graded line is the mdx4 default)."""
+    """Bench lines for BASELINE configs[2] / [3] / [4] and for single models of the reference's roster (``--workload model --model NAME``:
+    e.g. the two Roformers the unchanged wrapper runs by default, stem_separator.py:379-381, 998).  Same JSON shape as the mdx4 line,
+    with the roofline of the step's dominant kernel class and a bounded CPU baseline (the oracle of that family on the host)."""
+    import hashlib
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -173,7 +231,7 @@ def other_workload(args) -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     from audiolab_amd import _lib
-    from audiolab_amd.engine import Separator
+    from audiolab_amd.engine import MODEL_ROSTER, Separator
     from audiolab_amd.synth import synth_mix
     device = torch.device("cuda", local_rank)
     ctx = _lib.Context(device)
@@ -181,6 +239,21 @@ def other_workload(args) -> None:
     weak = args.scaling == "weak"
     if args.batch <= 0:
         args.batch = 32                                        # windows / chunks per network launch of the MDX-Net models here
+    seed_of = lambda name: int.from_bytes(hashlib.sha256(name.encode()).digest()[:4], "little")
+    cpu_fn = None                                              # () -> cpu_baseline object, rank 0 at N = 1 only
+
+    def one_lane_engine(**kw):                                 # the engine of the roofline passes: one unit at a time
+        saved = {k: os.environ.get(k) for k in ("ALSEP_RUNNER_LANES", "ALSEP_DEMUCS_LANES")}
+        os.environ["ALSEP_RUNNER_LANES"] = os.environ["ALSEP_DEMUCS_LANES"] = "1"
+        try:
+            return Separator(ctx=ctx, allow_synthetic=True, **kw)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
     if wl == "demucs6":                                       # configs[2]: htdemucs 6-stem, 10 min, overlap 0.25, segments sharded
         seconds = args.seconds if args.seconds != TRACK_SECONDS else 600
         n = seconds * SR * (world if weak else 1)
@@ -193,14 +266,28 @@ def other_workload(args) -> None:
 
         def step():
             return eng.separate_array(mix)
+
+        def make_prof():
+            e1 = one_lane_engine(use_autocast=False)
+            e1.load_model("htdemucs_6s.yaml")
+            short = mix[:, : min(n, 60 * SR)]
+            return lambda: e1.separate_array(short)
+
+        def cpu_fn():
+            from oracle import htdemucs_oracle as ho
+            ocfg = ho.HTDemucsConfig()
+            sd = ho.synthetic_state_dict(ocfg, seed_of("htdemucs_6s.yaml"))
+            k = ocfg.segment_samples
+            x = torch.from_numpy(synth_mix(k))
+            return _timed_cpu(lambda: ho.separate(ocfg, sd, x, shifts=2, overlap=0.25, seed=0), 6, k / SR,
+                              f"oracle/htdemucs_oracle.separate on one {k / SR:.1f} s segment (two shifted passes), torch-CPU fp32")
     elif wl == "tracks":                                      # configs[3]: a batch of tracks, MDX ensemble + Demucs per track, replicas
         from audiolab_amd.separator.stem_separator import EnsembleDemucsMDXMusicSeparationModel
         seconds = args.seconds if args.seconds != TRACK_SECONDS else 180
         n = seconds * SR
         tracks = [torch.from_numpy(synth_mix(n, seed=1000 + rank * 100 + k)).to(device) for k in range(args.tracks)]
-        from audiolab_amd.engine import MODEL_ROSTER
         # configs[3] is "MDX+Demucs": the roster is cut to the MDX-Net files and htdemucs, so that the first two ensemble members the
-        # orchestrator finds are the reference's MDX-Net vocal models (with the full roster they are its two Roformers, fp32)
+        # orchestrator finds are the reference's MDX-Net vocal models (with the full roster they are its two Roformers)
         mdx_demucs = {k: v for k, v in MODEL_ROSTER.items() if k.endswith(".onnx") or v[0] == "demucs"}
         eng = Separator(ctx=ctx, dtype=torch.bfloat16, allow_synthetic=True, max_batch=args.batch, roster=mdx_demucs)
         model = EnsembleDemucsMDXMusicSeparationModel({"ensemble_strength": 2, "vocals_only": False}, separator=eng)
@@ -209,26 +296,108 @@ def other_workload(args) -> None:
                 f"htdemucs_6s on the mix (fp32): vocals, instrumental + 5 Demucs stems per track")
         dtype_name, sharding = "bf16+f32", f"track replicas x{world}, no data-path collective"
 
-        def step():
-            files = [{"base_name": f"t{k}", "mix": t, "sr": SR, "output_folder": "/mem"} for k, t in enumerate(tracks)]
-            res = model._ensemble_separate_all(files)
-            model._multistem_separation_all(res)
+        def run_tracks(m, tl):
+            files = [{"base_name": f"t{k}", "mix": t, "sr": SR, "output_folder": "/mem"} for k, t in enumerate(tl)]
+            res = m._ensemble_separate_all(files)
+            m._multistem_separation_all(res)
             return res
-    else:                                                     # configs[4]: 60 min 48 kHz 8 channels, overlap 0.75
+
+        def step():
+            return run_tracks(model, tracks)
+
+        def make_prof():
+            e1 = one_lane_engine(dtype=torch.bfloat16, max_batch=args.batch, roster=mdx_demucs)
+            m1 = EnsembleDemucsMDXMusicSeparationModel({"ensemble_strength": 2, "vocals_only": False}, separator=e1)
+            return lambda: run_tracks(m1, tracks[:1])
+
+        def cpu_fn():
+            from oracle import htdemucs_oracle as ho, mdx_oracle, tdfnet_oracle
+            from audiolab_amd.synth import synthetic_state_dict
+            cfg = mdx_demucs["UVR-MDX-NET-Voc_FT.onnx"][2]
+            g = mdx_oracle.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
+            k = g.gen_size - 1                                 # one model window
+            x = synth_mix(k)
+            sds = [synthetic_state_dict(cfg, seed=seed_of(m)) for m in ("UVR-MDX-NET-Voc_FT.onnx", "Kim_Vocal_2.onnx")]
+            ocfg = ho.HTDemucsConfig()
+            dsd = ho.synthetic_state_dict(ocfg, seed_of("htdemucs_6s.yaml"))
+
+            def run():
+                for sd in sds:
+                    mdx_oracle.demix(x, g, lambda sp, sd=sd: tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(sp, dtype=np.float32)),
+                                                                                   cfg.num_blocks, cfg.l, cfg.bn).numpy(), chunks=0, margin=SR, dtype=np.float32)
+                ho.separate(ocfg, dsd, torch.from_numpy(x), shifts=2, overlap=0.25, seed=0)
+            return _timed_cpu(run, 7, k / SR, f"one {k / SR:.2f} s track through both MDX-Net vocal models (oracle/mdx_oracle + tdfnet_oracle, one "
+                                              f"window each) and htdemucs_6s (oracle/htdemucs_oracle), torch-CPU fp32; blend / de-bleed not timed")
+    elif wl == "longform":                                    # configs[4]: 60 min 48 kHz 8 channels, overlap 0.75
         seconds = args.seconds if args.seconds != TRACK_SECONDS else 3600
         sr = 48000
         n = seconds * sr * (world if weak else 1)
         mix8 = torch.from_numpy(np.concatenate([synth_mix(n, sr=sr, seed=50 + c) for c in range(4)])).to(device)
+        lf_roster = {"longform_vocals.onnx": ("Vocals", "Instrumental", _bench_cfg())}
         eng = Separator(ctx=ctx, dtype=torch.float16, allow_synthetic=True, max_batch=args.batch, chunker="ola", overlap=0.75,
-                        sharded=world > 1, roster={"longform_vocals.onnx": ("Vocals", "Instrumental", _bench_cfg())})
+                        sharded=world > 1, roster=lf_roster)
         eng.load_model("longform_vocals.onnx")
         stems, audio_s = 2, n / sr
         desc = (f"8 channels (4 stereo pairs) x {seconds} s at 48 kHz (native rate), one MDX-Net model (bench geometry, fp16 storage + f16 MFMA), "
-                f"Hann overlap-add at overlap 0.75, chunks sharded")
+                f"Hann overlap-add at overlap 0.75, normalisation 0.9 + spectral inversion for the second stem, chunks sharded")
         dtype_name, sharding = "f16", f"chunks/{world} + all_reduce of the seam sums"
 
         def step():
             return eng.separate_array(mix8)
+
+        def make_prof():
+            short = mix8[:2, : min(n, 120 * sr)].contiguous()
+            return lambda: eng.separate_array(short)
+
+        def cpu_fn():
+            from oracle import mdx_oracle, tdfnet_oracle
+            from audiolab_amd.synth import synthetic_state_dict
+            cfg = _bench_cfg()
+            sd = synthetic_state_dict(cfg, seed=seed_of("longform_vocals.onnx"))
+            g = mdx_oracle.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
+            k = 100000
+            x = synth_mix(k, sr=sr, seed=50)
+            run = lambda sp: tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(sp, dtype=np.float32)), cfg.num_blocks, cfg.l, cfg.bn).numpy()
+            return _timed_cpu(lambda: mdx_oracle.separate_ola(x, g, run, overlap=0.75, compensate=1.0), 2, k / sr,
+                              f"oracle/mdx_oracle.separate_ola on one stereo pair, {k / sr:.2f} s ({len(mdx_oracle.ola_plan(k, g, 0.75)['starts'])} "
+                              f"chunks at overlap 0.75), torch-CPU fp32")
+    else:                                                     # one model of the roster (--model), e.g. the default ensemble's Roformers
+        name = args.model
+        if name not in MODEL_ROSTER:
+            raise SystemExit(f"--model {name!r} is not in the roster: {sorted(MODEL_ROSTER)}")
+        seconds = args.seconds if args.seconds != TRACK_SECONDS else 120
+        sr = SR
+        n = seconds * SR
+        mix = torch.from_numpy(synth_mix(n)).to(device)
+        half = args.dtype != "f32"
+        eng = Separator(ctx=ctx, use_autocast=half, allow_synthetic=True)
+        eng.load_model(name)
+        fam = MODEL_ROSTER[name][0] if isinstance(MODEL_ROSTER[name][0], str) and MODEL_ROSTER[name][0] in ("roformer", "mdx23c", "vr", "demucs") else "mdx"
+        probe = eng.separate_array(mix[:, : min(n, 10 * SR)])
+        stems, audio_s = len(probe), n / SR
+        mode = "IEEE-half MFMA operands (the reference's use_autocast=True)" if (half and fam in ("roformer", "mdx")) else "fp32"
+        desc = f"{name} ({fam}), {seconds} s 44.1 kHz stereo, {mode}, {stems} stems out, world {world}: replicas"
+        dtype_name, sharding = ("f16" if (half and fam in ("roformer", "mdx")) else "f32"), f"replicas x{world}"
+
+        def step():
+            return eng.separate_array(mix)
+
+        def make_prof():
+            e1 = one_lane_engine(use_autocast=half)
+            e1.load_model(name)
+            short = mix[:, : min(n, 30 * SR)]
+            return lambda: e1.separate_array(short)
+
+        if fam == "roformer":
+            def cpu_fn():
+                import dataclasses
+                from oracle import roformer_oracle as ro
+                ocfg = ro.RoformerConfig(**dataclasses.asdict(MODEL_ROSTER[name][1]))
+                sd = ro.synthetic_state_dict(ocfg, seed_of(name))
+                x = torch.from_numpy(synth_mix(ocfg.chunk_size))
+                return _timed_cpu(lambda: ro.forward(ocfg, sd, x[None]), stems, ocfg.chunk_size / SR * (ocfg.chunk_size // ocfg.num_overlap) / ocfg.chunk_size,
+                                  f"oracle/roformer_oracle.forward on one {ocfg.chunk_size / SR:.0f} s chunk (the runner advances "
+                                  f"{ocfg.chunk_size // ocfg.num_overlap / SR:.0f} s per chunk: the rate counts that), torch-CPU fp32")
 
     def fence():
         if world > 1:
@@ -246,6 +415,14 @@ def other_workload(args) -> None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
+    roofline = cpu = None
+    if rank == 0 and world == 1:
+        run_once = make_prof()
+        run_once()                                             # builds the one-lane engine's plans / workspaces
+        fence()
+        roofline = family_roofline(ctx, _lib, run_once, fence)
+        if cpu_fn is not None and not args.no_cpu_baseline:
+            cpu = cpu_fn()
     if rank == 0:
         mult = 4 if wl == "longform" else 1                    # stereo pairs count as separate 2-channel programmes
         print(json.dumps({
@@ -254,7 +431,8 @@ def other_workload(args) -> None:
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": desc, "stems": stems, "audio_seconds": audio_s, "sample_rate": sr, "sharding": sharding},
-            "roofline": None, "cpu_baseline": None}), flush=True)
+            "realtime_factor": round(mult * audio_s * args.steps / dt, 2),
+            "roofline": roofline, "cpu_baseline": cpu}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -281,7 +459,8 @@ def main() -> None:
     ap.add_argument("--cpu-windows", type=int, default=2)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: N x --seconds of audio on N GPUs (per-GPU work fixed); strong: --seconds in total")
-    ap.add_argument("--workload", default="mdx4", choices=["mdx4", "demucs6", "tracks", "longform"],
+    ap.add_argument("--model", default="vocals_mel_band_roformer.ckpt", help="roster name of the model workload")
+    ap.add_argument("--workload", default="mdx4", choices=["mdx4", "demucs6", "tracks", "longform", "model"],
                     help="mdx4 (default): BASELINE configs[1], the graded line.  Supplementary lines for the other configs: demucs6 = "
                          "configs[2] (htdemucs 6-stem, segments sharded over the ranks), tracks = configs[3] (batch of tracks per GPU, MDX "
                          "ensemble + htdemucs, replicas), longform = configs[4] (48 kHz 8-channel, Hann overlap-add at 0.75, chunks sharded)")

@@ -72,10 +72,17 @@ enum {
     ALSEP_PROF_CONV3X3_REGW = 8, /* conv3x3_bf16_regw_kernel (persistent, level 0) */
     ALSEP_PROF_CONV3X3_PIPE = 9, /* conv3x3_bf16_pipe_kernel (opt-in) */
     ALSEP_PROF_CONV3X3_BIG = 10, /* conv3x3_bf16_big_kernel<2> (8-wave 8x64 tile, 96 channels: level 1) */
-    ALSEP_PROF_CONV3X3_BIG3 = 11 /* conv3x3_bf16_big_kernel<3> (same kernel, 144 channels: level 2) */
+    ALSEP_PROF_CONV3X3_BIG3 = 11,/* conv3x3_bf16_big_kernel<3> (same kernel, 144 channels: level 2) */
+    ALSEP_PROF_NN_GEMM = 12,     /* nn_gemm_tn_kernel / nn_bgemm_kernel (float32 MFMA products of the transformer / Demucs / MDX23C families) */
+    ALSEP_PROF_NN_CONV = 13,     /* nn_conv2d_tiled_kernel / vr_conv2d_kernel through alsep_nn_conv2d */
+    ALSEP_PROF_NN_GEMM_H = 14,   /* nn_gemm_h_kernel (f16 MFMA Linear) */
+    ALSEP_PROF_NN_ATTN_H = 15    /* nn_attn_h_kernel (one-pass f16 attention) */
 };
 int alsep_profile_begin(alsep_ctx* ctx, int category);
 int alsep_profile_end(alsep_ctx* ctx, double* total_ms, int64_t* launches);
+/* arithmetic / minimal HBM traffic of the launches bracketed since alsep_profile_begin, as their launch sites count them (the NN_*
+ * categories: 2 M N K per product, operands + result once); call before alsep_profile_end */
+int alsep_profile_work(alsep_ctx* ctx, double* flops, double* bytes);
 /* Launches of one kernel since alsep_create / alsep_launch_counts_reset, by the name the launch site reports
  * ("conv3x3_bf16_big_kernel<2>", "conv3x3_bf16_regw_kernel", "tdf_bf16_wide_kernel<res>", "us_stream_kernel",
  * "istft_r16_kernel" ...): lets a parity test prove WHICH kernel produced the result it checked.  -1 on a null argument. */
@@ -337,11 +344,19 @@ int alsep_nn_to_f16(alsep_ctx* ctx, const float* x, void* y, int64_t n);
  * (ALSEP_ERR_ARG otherwise). */
 int alsep_nn_gemm_f16w(alsep_ctx* ctx, const float* A, int64_t lda, int64_t sa_b, const void* W, int64_t ldw, int64_t sw_b, float* C,
                        int64_t ldc, int64_t sc_b, const float* bias, int64_t bias_b, const float* R, int64_t ldr, int64_t sr_b, int nb, int M,
-                       int N, int K, float alpha, int act);
+                       int N, int K, float alpha, int act, const int* n_per_batch /* device, optional: columns of batch b (<= N) */);
 /* out = softmax(scale q k^T) v per (sequence, head), one pass (no score matrix in HBM).  qkv: float32 rows of 3 * heads * 64 values
  * (q | k | v), rotary embedding applied; sequence s = L rows `row_stride` floats apart from s * seq_stride; out rows of heads * 64. */
 int alsep_nn_attention_f16(alsep_ctx* ctx, const float* qkv, float* out, int n_seq, int L, int heads, int dim_head, int64_t seq_stride,
-                           int64_t row_stride, int64_t o_seq_stride, int64_t o_row_stride, float scale);
+                           int64_t row_stride, int64_t o_seq_stride, int64_t o_row_stride, float scale, const float* rot_table,
+                           const float* gates, int64_t g_seq_stride, int64_t g_row_stride);
+/* Roformer band split, input side, all bands in one launch: feat[band][t][kmax] = RMSNorm over the band's `width[band]` gathered
+ * spectrogram values of frame t (spec [4][F][T]; pidx[band][kmax / 2] merged bin index 2 f + s or -1; gamma[band][kmax]), zero-padded */
+int alsep_roformer_bandsplit_in(alsep_ctx* ctx, const float* spec, const int* pidx, const float* gamma, const int* width, float* feat, int nb,
+                                int F, int T, int kmax);
+/* table[pos][j] = (cos, sin)(pos / 10000^(2 j / dim_head)), pos < L, j < dim_head / 2 (rotary_embedding_torch, interleaved pairs): with
+ * it alsep_nn_attention_f16 rotates q and k on load, and -- with gates -- applies the head gates in its epilogue */
+int alsep_nn_rotary_table(alsep_ctx* ctx, float* table, int L, int dim_head);
 
 /* ---- reverb impulse-response extraction: replaces handlers/reverb.py:112-172 (extract_reverb), called from
  * modules/separator/stem_separator.py:822-829 when a de-reverb transform ran on the vocals with store_reverb_ir.  Whole-track FFT work in

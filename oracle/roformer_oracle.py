@@ -130,9 +130,10 @@ def _h(t: torch.Tensor) -> torch.Tensor:
     return t.half().float()
 
 
-def _linear(x: torch.Tensor, wt: torch.Tensor, bias, half: bool) -> torch.Tensor:
-    """a Linear layer; ``half``: the operand rounding of the f16 MFMA kernel (= autocast's input casts), float32 accumulation and output"""
-    if half and wt.shape[1] % 8 == 0 and wt.shape[0] % 4 == 0:        # the shapes the f16 MFMA kernel takes (whole k-groups, float4 columns)
+def _linear(x: torch.Tensor, wt: torch.Tensor, bias, half: bool, padded: bool = False) -> torch.Tensor:
+    """a Linear layer; ``half``: the operand rounding of the f16 MFMA kernel (= autocast's input casts), float32 accumulation and output.
+    The kernel takes whole 8-element k-groups and float4 columns; the per-band layers reach it zero-padded (``padded``: any shape)."""
+    if half and (padded or (wt.shape[1] % 8 == 0 and wt.shape[0] % 4 == 0)):
         return F.linear(_h(x), _h(wt), bias)
     return F.linear(x, wt, bias)
 
@@ -173,7 +174,7 @@ def forward(cfg: RoformerConfig, w: Dict[str, torch.Tensor], audio: torch.Tensor
     """audio [B, 2, L] (L a multiple of hop) -> [B, num_stems, 2, L].  ``half=True`` restates the build's half-precision mode (the
     arithmetic of the reference's use_autocast=True as csrc/nn_half.hip runs it): the Linear layers of the transformer blocks and the
     mask estimators and the two attention products take operands rounded to IEEE half, everything else -- including every accumulation
-    and every stored activation -- stays float32; the per-band input projections stay float32."""
+    and every stored activation -- stays float32."""
     B, S, L = audio.shape
     win = torch.hann_window(cfg.n_fft)
     z = torch.stft(audio.reshape(B * S, L), cfg.n_fft, cfg.hop, win_length=cfg.n_fft, window=win, return_complex=True)
@@ -184,7 +185,7 @@ def forward(cfg: RoformerConfig, w: Dict[str, torch.Tensor], audio: torch.Tensor
     for i, idx in enumerate(bands):
         feat = z[:, torch.from_numpy(idx)].permute(0, 2, 1, 3).reshape(B, T, -1)                     # 'b f t c -> b t (f c)'
         feat = _rmsnorm(w, f"band_split.to_features.{i}.0", feat)
-        x_bands.append(F.linear(feat, w[f"band_split.to_features.{i}.1.weight"], w[f"band_split.to_features.{i}.1.bias"]))
+        x_bands.append(_linear(feat, w[f"band_split.to_features.{i}.1.weight"], w[f"band_split.to_features.{i}.1.bias"], half, padded=True))
     x = torch.stack(x_bands, dim=-2)                                                                   # [B, T, bands, dim]
     nb = len(bands)
     for li in range(cfg.depth):
@@ -202,7 +203,7 @@ def forward(cfg: RoformerConfig, w: Dict[str, torch.Tensor], audio: torch.Tensor
             hcur = x[:, :, i]
             nl = cfg.mask_estimator_depth
             for j in range(nl):
-                hcur = _linear(hcur, w[f"{p}.{2 * j}.weight"], w[f"{p}.{2 * j}.bias"], half)
+                hcur = _linear(hcur, w[f"{p}.{2 * j}.weight"], w[f"{p}.{2 * j}.bias"], half, padded=True)
                 if j + 1 < nl:
                     hcur = torch.tanh(hcur)
             m = F.glu(hcur, dim=-1)                                                                    # [B, T, len(idx) * 2]

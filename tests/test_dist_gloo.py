@@ -104,6 +104,25 @@ def _worker_ola_demucs(rank, world, port, emul_so, out_path):
         return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)), cfg.num_blocks, cfg.l, cfg.bn).numpy()
     want = mo.demix_ola(mix, g, run, overlap=0.75, denoise=False, zero_low_bins=3, compensate=1.02)
     errs.append(float(np.max(np.abs(got - want))))
+    # the engine's sequence on a HOST-resident loud programme: each rank uploads only the samples under its chunks, the seam sums are
+    # exchanged, the stem segments all-gathered; normalisation 0.9 and the spectral inversion of the second stem as in one process
+    from audiolab_amd.engine import Separator
+    loud = (mix * (1.4 / np.max(np.abs(mix)))).astype(np.float32)
+    eng = Separator(ctx=ctx, use_autocast=False, allow_synthetic=True, roster={"m.onnx": ("Vocals", "Instrumental", cfg)}, max_batch=2,
+                    chunker="ola", overlap=0.75, compensate=1.02, sharded=True)
+    eng.load_model("m.onnx")
+    import hashlib
+    sd2 = synthetic_state_dict(cfg, seed=int.from_bytes(hashlib.sha256(b"m.onnx").digest()[:4], "little"))
+
+    def run2(spek):
+        return tdfnet_oracle.forward(sd2, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)), cfg.num_blocks, cfg.l, cfg.bn).numpy()
+    out2 = eng.separate_array(torch.from_numpy(loud))
+    w1, w2 = mo.separate_ola(loud, g, run2, overlap=0.75, compensate=1.02)
+    errs[-1] = max(errs[-1], float(np.max(np.abs(out2["Vocals"].numpy() - w1))), float(np.max(np.abs(out2["Instrumental"].numpy() - w2))))
+    # a track so short that a rank's chunks reach across the whole range of the next one (and ranks without any chunk)
+    tiny = synth_mix(300, seed=5)
+    got_t = OlaRunner(net, ctx=ctx, overlap=0.75, compensate=1.0, max_batch=2, sharded=True).demix(torch.from_numpy(tiny)).numpy()
+    errs[-1] = max(errs[-1], float(np.max(np.abs(got_t - mo.demix_ola(tiny, g, run, overlap=0.75, zero_low_bins=3, compensate=1.0)))))
     ocfg = ho.HTDemucsConfig(sources=("drums", "bass"), channels=16, nfft=256, depth=2, dconv_comp=4, bottom_channels=32, t_layers=2,
                              t_heads=4, segment_samples=2560, samplerate=4000)
     hsd = ho.synthetic_state_dict(ocfg, 5)

@@ -140,7 +140,7 @@ def test_half_gemm_vs_float64(dev, M, N, K, act, res):
     assert torch.equal(wh.cpu(), w.half())
     c = torch.zeros((M, ldc), device=dev.device)
     dev.check(dev.lib.alsep_nn_gemm_f16w(dev.handle, _lib.ptr(ad), lda, 0, _lib.ptr(wh), K, 0, _lib.ptr(c), ldc, 0, _lib.ptr(bd), 0,
-                                         _lib.ptr(rd) if res else None, ldc, 0, 1, M, N, K, 0.5, act), "alsep_nn_gemm_f16w")
+                                         _lib.ptr(rd) if res else None, ldc, 0, 1, M, N, K, 0.5, act, None), "alsep_nn_gemm_f16w")
     want = 0.5 * (a[:, :K].half().double() @ w.half().double().t()) + bias.double()
     if act == 3:
         want = torch.nn.functional.gelu(want)
@@ -153,7 +153,25 @@ def test_half_gemm_vs_float64(dev, M, N, K, act, res):
     assert np.all(got[:, N:] == 0)                             # nothing written beyond the N columns
     # shapes the kernel does not take are refused (the caller keeps them on the fp32 kernel)
     assert dev.lib.alsep_nn_gemm_f16w(dev.handle, _lib.ptr(ad), lda, 0, _lib.ptr(wh), K, 0, _lib.ptr(c), ldc, 0, None, 0, None, 0, 0, 1, M, N - 1,
-                                      K, 1.0, 0) != 0
+                                      K, 1.0, 0, None) != 0
+    # batched over 3 "bands" with ragged column counts: batch b keeps nvec[b] columns, the tiles beyond are skipped
+    if N >= 8:
+        nb_ = 3
+        a3 = torch.randn(nb_, M, K, generator=g)
+        w3 = torch.randn(nb_, N, K, generator=g) / K ** 0.5
+        b3 = torch.randn(nb_, N, generator=g)
+        nvec = torch.tensor([N, 4, max(4, (N // 2) // 4 * 4)], dtype=torch.int32)
+        w3h = torch.empty((nb_, N, K), dtype=torch.float16, device=dev.device)
+        dev.check(dev.lib.alsep_nn_to_f16(dev.handle, _lib.ptr(on(dev, w3)), _lib.ptr(w3h), w3.numel()), "alsep_nn_to_f16")
+        c3 = torch.full((nb_, M, N), 7.0, device=dev.device)
+        dev.check(dev.lib.alsep_nn_gemm_f16w(dev.handle, _lib.ptr(on(dev, a3)), K, M * K, _lib.ptr(w3h), K, N * K, _lib.ptr(c3), N, M * N,
+                                             _lib.ptr(on(dev, b3)), N, None, 0, 0, nb_, M, N, K, 1.0, 0, _lib.ptr(on(dev, nvec))), "alsep_nn_gemm_f16w")
+        got3 = host(c3)
+        for b in range(nb_):
+            nv = int(nvec[b])
+            want3 = (a3[b].half().double() @ w3[b].half().double().t() + b3[b].double()).numpy()
+            assert np.max(np.abs(got3[b][:, :nv] - want3[:, :nv])) < 2e-5 * max(1.0, float(np.abs(want3).max()))
+            assert np.all(got3[b][:, nv:] == 7.0)
     _ = C
 
 
@@ -180,11 +198,27 @@ def test_half_attention_vs_float64(dev, over_time, L, n_seq):
     want = (e.float().half().double() @ v) / e.sum(-1, keepdim=True)          # [seq, head, L, d]
     out = torch.zeros((rows, inner), device=dev.device)
     dev.check(dev.lib.alsep_nn_attention_f16(dev.handle, _lib.ptr(on(dev, qkv)), _lib.ptr(out), n_seq, L, heads, d, seq_stride, row_stride, o_seq,
-                                             o_row, d ** -0.5), "alsep_nn_attention_f16")
+                                             o_row, d ** -0.5, None, None, 0, 0), "alsep_nn_attention_f16")
     got = host(out)
-    got = (got.reshape(L, n_seq, heads, d).transpose(1, 2, 0, 3) if over_time else got.reshape(n_seq, L, heads, d).transpose(0, 2, 1, 3))
+    unpack = lambda a: (a.reshape(L, n_seq, heads, d).transpose(1, 2, 0, 3) if over_time else a.reshape(n_seq, L, heads, d).transpose(0, 2, 1, 3))
     # the kernel rounds exp(s - RUNNING max) to half and rescales in float32, the restatement rounds exp(s - final max): 2^-11 relative apart
-    assert np.max(np.abs(got - want.numpy())) < 2e-3 * float(want.abs().max())
+    assert np.max(np.abs(unpack(got) - want.numpy())) < 2e-3 * float(want.abs().max())
+    # the same with the rotary embedding applied to q / k on load (table of alsep_nn_rotary_table) and the head gates in the epilogue
+    table = torch.zeros((L, d // 2, 2), device=dev.device)
+    dev.check(dev.lib.alsep_nn_rotary_table(dev.handle, _lib.ptr(table), L, d), "alsep_nn_rotary_table")
+    gates = torch.randn(rows, heads, generator=g)
+    g_seq, g_row = (heads, n_seq * heads) if over_time else (L * heads, heads)
+    out2 = torch.zeros((rows, inner), device=dev.device)
+    dev.check(dev.lib.alsep_nn_attention_f16(dev.handle, _lib.ptr(on(dev, qkv)), _lib.ptr(out2), n_seq, L, heads, d, seq_stride, row_stride, o_seq,
+                                             o_row, d ** -0.5, _lib.ptr(table), _lib.ptr(on(dev, gates)), g_seq, g_row), "alsep_nn_attention_f16")
+    qr, kr = ro._rotary(view[0].float(), d), ro._rotary(view[1].float(), d)
+    q2, k2 = (qr * d ** -0.5).half().double(), kr.half().double()
+    s2 = q2 @ k2.transpose(-1, -2)
+    e2 = torch.exp(s2 - s2.amax(dim=-1, keepdim=True))
+    want2 = (e2.float().half().double() @ v) / e2.sum(-1, keepdim=True)
+    gv = gates.view(L, n_seq, heads).permute(1, 2, 0) if over_time else gates.view(n_seq, L, heads).permute(0, 2, 1)      # [seq, head, L]
+    want2 = want2 * torch.sigmoid(gv.double())[..., None]
+    assert np.max(np.abs(unpack(host(out2)) - want2.numpy())) < 2e-3 * float(want2.abs().max())
 
 
 @pytest.mark.parametrize("kind", ["bs", "mel"])
