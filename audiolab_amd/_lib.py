@@ -131,9 +131,10 @@ _SIGNATURES = {
     "alsep_vr_mirror": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4),
     "alsep_vr_band_spec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8),
     "alsep_nn_to_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
-    "alsep_nn_gemm_f16w": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
-                                     C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
-                                     C.c_float, C.c_int, C.c_void_p]),
+    "alsep_nn_rmsnorm_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64]),
+    "alsep_nn_gemm_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int64,
+                                    C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_float, C.c_int, C.c_void_p]),
     "alsep_nn_attention_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                          C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
     "alsep_nn_rotary_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),

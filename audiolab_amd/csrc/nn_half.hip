@@ -1,12 +1,20 @@
 // Half-precision MFMA kernels of the transformer model families (Mel-Band / BS Roformer; the reference runs them under torch autocast,
 // modules/separator/stem_separator.py:106 ``use_autocast=True``: Linear layers and attention in IEEE half, everything else in float32).
-// gfx950 only.  Activations stay float32 in HBM; the GEMM operands are rounded to f16 on their way into LDS (weights once, at load),
-// products on v_mfma_f32_16x16x32_f16 with float32 accumulation, results stored as float32 -- i.e. autocast's rounding points for the
-// inputs of a Linear, none for its output.
+// gfx950 only.
 //
-//   nn_gemm_h_kernel   C[M][N] = act(alpha A[M][K] W[N][K]^T + bias) (+ residual), A float32, W f16.
-//   nn_attn_h_kernel   softmax(Q K^T) V for the packed, rotary-embedded q | k | v projection of a Roformer layer, one pass (no score
-//                      matrix in HBM): online softmax in registers, S^T = K Q^T so that P feeds the second MFMA as it lies.
+// Storage follows autocast: the residual stream and every statistic stay float32; what a Linear or the attention READS is IEEE half in
+// HBM -- the RMSNorm output, the q | k | v projection, the attention output, the GELU / tanh hidden activations -- written in that
+// type by the kernel that produces it (one rounding, where autocast rounds), products on v_mfma_f32_16x16x32_f16 with float32
+// accumulation.  Why storage and not just operand rounding: these GEMMs have K = 384 ... 1536 against M = 48 060 rows, so they live on
+// the per-CU intake path (~70 GB/s per CU from L2, MI355X_MICROARCH.md): measured with float32 activations converted on the way into
+// LDS, the 128 x 128 tile moved 40 KB per 1.05 MFLOP (every 128-byte line of A fetched twice, half used each time) and ran at 0.26
+// PFLOP/s with the MFMA pipe 10 % busy; half-precision activations in whole 128-byte lines are 32 KB per 2.1 MFLOP.
+//
+//   nn_rmsnorm_h_kernel  float32 rows -> RMS-normalised f16 rows (the A operand of the next Linear)
+//   nn_gemm_hh_kernel    C[M][N] = act(alpha A[M][K] W[N][K]^T + bias) (+ residual): A, W f16; C f16 or float32; batched, ragged N
+//   nn_attn_h_kernel     softmax(Q K^T) V of a packed f16 q | k | v projection in one pass (no score matrix in HBM), rotary embedding on
+//                        load, head gates in the epilogue, f16 out
+//   roformer_bandsplit_in_kernel   gather + RMSNorm of every band of a frame -> zero-padded f16 rows of one batched Linear
 #include "alsep_common.h"
 
 namespace {
@@ -16,7 +24,15 @@ typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kHThreads = 256;
 
-__device__ __forceinline__ float gelu_erf_h(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+// GELU(erf) with erf by Abramowitz & Stegun 7.1.26 (|error| < 1.5e-7 -- three orders below the half rounding of the stored result): one
+// exponential and a degree-5 polynomial instead of erff's branchy 40-instruction expansion (40 of the 162 us of the 48 060 x 1536 Linear)
+__device__ __forceinline__ float gelu_erf_h(float v) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = 1.f / fmaf(0.3275911f, x, 1.f);
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float erf_abs = 1.f - poly * __expf(-x * x);
+    return 0.5f * v * (1.f + copysignf(erf_abs, v));
+}
 
 __device__ __forceinline__ h16x8 to_h8(const f32x4& a, const f32x4& b) {
     h16x8 r;
@@ -26,131 +42,198 @@ __device__ __forceinline__ h16x8 to_h8(const f32x4& a, const f32x4& b) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
-// GEMM.  Workgroup tile 128 (M) x 128 (N), 4 waves as 2 x 2 (64 x 64 each: 16 accumulator blocks), K in slices of 32 = one MFMA step.
-// LDS image of a slice: rows of 32 halves (64 bytes = four 16-byte k-groups), group g of row r stored at g ^ ((r >> 1) & 3): the
-// ds_read_b128 of 16 consecutive rows x one group is conflict-free, as is the 16-byte staging store.  Two slices are resident (the next
-// one's global loads are in flight during the 16 MFMAs of the current one, converted and stored after them; one barrier per slice).
-// Operand roles are swapped (D rows = n, D columns = m): a lane ends up with four consecutive n of one m -- one float4 store.
+// GEMM.  Workgroup tile 128 (M) x 128 (N), 4 waves as 2 x 2 (64 x 64 each: 16 accumulator blocks), K in slices of 64 = two MFMA steps =
+// one whole 128-byte line of every operand row.  LDS image of a slice: rows of 64 halves (eight 16-byte k-groups), group g of row r at
+// g ^ (r & 7): the ds_read_b128 of 16 consecutive rows x one group and the staging ds_write_b128 are conflict-free
+// (SQ_LDS_BANK_CONFLICT = 0).  Operand roles are swapped (D rows = n, D columns = m): a lane ends up with four consecutive n of one m.
+//
+// Pipeline: the global loads of slice kt + 2 are issued at the top of iteration kt into the register set that iteration kt - 1 emptied,
+// slice kt + 1 (requested one iteration earlier) is stored to the other LDS buffer after the MFMAs of slice kt -- by then it has had a
+// whole iteration to arrive, and the wait for it is a counted vmcnt that leaves the newer slice in flight.  Every load is UNCONDITIONAL
+// (rows / k-groups outside the matrices read a clamped, valid address and are zeroed when they are stored): a load under a branch makes
+// hipcc wait vmcnt(0) at the join and the prefetch distance collapses to zero; scheduling fences keep hipcc from hoisting the next
+// iteration's register reads (and with them the wait) above the barrier.
+// Grid: 1-D over (batch, m tile, n tile), n fastest, dealt to the XCDs in contiguous runs (consecutive workgroup ids go round-robin
+// over the 8 XCDs): the N / 128 workgroups that read the same 128 rows of A run on ONE XCD and share its L2 (PMC: A fetched once).
 // ------------------------------------------------------------------------------------------------------------------------------------
-constexpr int kHgBM = 128, kHgBN = 128, kHgBK = 32;
-constexpr size_t kHgLds = 2 * (size_t)(kHgBM + kHgBN) * kHgBK * sizeof(_Float16);      // 32 KiB
+constexpr int kHgBM = 128, kHgBN = 128, kHgBK = 64;
+constexpr size_t kHgLds = 2 * (size_t)(kHgBM + kHgBN) * kHgBK * sizeof(_Float16);      // 64 KiB: two workgroups per CU
 
 struct GemmHArgs {
-    const float* A; int64_t lda, sa_b;
+    const _Float16* A; int64_t lda, sa_b;
     const _Float16* B; int64_t ldb, sb_b;
-    float* C; int64_t ldc, sc_b;
+    void* C; int64_t ldc, sc_b;
     const float* bias; int64_t bias_b;
-    const float* R; int64_t ldr, sr_b;            // optional residual added after the activation: C = act(...) + R
+    const float* R; int64_t ldr, sr_b;            // optional float32 residual added after the activation: C = act(...) + R
     int M, N, K;
     float alpha;
-    int act;
     const int* nvec;                              // optional: columns of batch b (<= N): the ragged last layers of the mask estimators
 };
 
-__device__ __forceinline__ int hg_slot(int row, int g) { return row * kHgBK + 8 * (g ^ ((row >> 1) & 3)); }
+__device__ __forceinline__ int hg_slot(int row, int g) { return row * kHgBK + 8 * (g ^ (row & 7)); }
 
+// one slice's worth of a thread's staging registers: four A granules and four W granules of 8 halves
+struct HgStage {
+    h16x8 a[4], b[4];
+};
+
+template <int ACT>
+__device__ __forceinline__ float hg_act(float t) {
+    if (ACT == 3) return gelu_erf_h(t);
+    if (ACT == 5) return tanhf(t);
+    return t;
+}
+
+template <int ACT, bool CF16>
 __global__ void __launch_bounds__(kHThreads, 2)
-nn_gemm_h_kernel(GemmHArgs p) {
-    _Float16* As = reinterpret_cast<_Float16*>(alsep_smem);                  // [2][128][32]
-    _Float16* Bs = As + 2 * kHgBM * kHgBK;                                    // [2][128][32]
+nn_gemm_hh_kernel(GemmHArgs p) {
+    _Float16* As = reinterpret_cast<_Float16*>(alsep_smem);                  // [2][128][64]
+    _Float16* Bs = As + 2 * kHgBM * kHgBK;                                    // [2][128][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-    const int bz = blockIdx.z;
-    const float* a = p.A + bz * p.sa_b;
+    const int tiles_n = (p.N + kHgBN - 1) / kHgBN, tiles_m = (p.M + kHgBM - 1) / kHgBM;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int bz = wg / (tiles_n * tiles_m);
+    const int tm = (wg / tiles_n) % tiles_m, tn = wg % tiles_n;
+    const _Float16* a = p.A + bz * p.sa_b;
     const _Float16* b = p.B + bz * p.sb_b;
-    float* c = p.C + bz * p.sc_b;
-    const int m0 = blockIdx.y * kHgBM, n0 = blockIdx.x * kHgBN;
+    const int m0 = tm * kHgBM, n0 = tn * kHgBN;
     const int Nb = p.nvec ? p.nvec[bz] : p.N;
     if (n0 >= Nb) return;                                                    // whole workgroups leave together
-    // staging duty per slice: A 512 granules of 8 floats (two per thread), B 512 granules of 8 halves (two per thread)
-    const int sr = tid >> 2, sg = tid & 3;                                   // rows sr and sr + 64, k-group sg
-    const float* ga[2];
-    const _Float16* gb[2];
-    bool va[2], vb[2];
+    // staging duty per slice: 1024 granules per operand, four per thread: rows sr + 32 h, k-group sg (8 lanes = one 128-byte line)
+    const int sr = tid >> 3, sg = tid & 7;
+    const _Float16* ga[4];
+    const _Float16* gb[4];
+    bool va[4], vb[4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int ra = m0 + sr + 64 * h, rb = n0 + sr + 64 * h;
+    for (int h = 0; h < 4; ++h) {
+        const int ra = m0 + sr + 32 * h, rb = n0 + sr + 32 * h;
         va[h] = ra < p.M;
         vb[h] = rb < Nb;
-        ga[h] = a + (int64_t)(va[h] ? ra : 0) * p.lda + 8 * sg;
-        gb[h] = b + (int64_t)(vb[h] ? rb : 0) * p.ldb + 8 * sg;
+        ga[h] = a + (int64_t)(va[h] ? ra : 0) * p.lda;
+        gb[h] = b + (int64_t)(vb[h] ? rb : 0) * p.ldb;
     }
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 ra0[2], ra1[2];
-    h16x8 rbv[2];
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
     h16x8 zh;
 #pragma unroll
     for (int e = 0; e < 8; ++e) zh[e] = (_Float16)0.f;
-    auto gload = [&](int k0) {                                               // K % 8 == 0: a granule is inside K or outside it
+    auto gload = [&](HgStage& r, int k0) {                                   // K % 8 == 0: a granule is inside K or outside it
+        const int kq = k0 + 8 * sg;
+        const int ks = kq < p.K ? kq : 0;                                    // clamped: always a valid address (zeroed in lstore)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const bool in = k0 + 8 * sg < p.K;
-            ra0[h] = (va[h] && in) ? *reinterpret_cast<const f32x4*>(ga[h] + k0) : z4;
-            ra1[h] = (va[h] && in) ? *reinterpret_cast<const f32x4*>(ga[h] + k0 + 4) : z4;
-            rbv[h] = (vb[h] && in) ? *reinterpret_cast<const h16x8*>(gb[h] + k0) : zh;
+        for (int h = 0; h < 4; ++h) {
+            r.a[h] = *reinterpret_cast<const h16x8*>(ga[h] + ks);
+            r.b[h] = *reinterpret_cast<const h16x8*>(gb[h] + ks);
         }
     };
-    auto lstore = [&](int buf) {
+    // the registers are first TOUCHED here, an iteration after their loads were issued
+    auto lstore = [&](const HgStage& r, int buf, int k0) {
+        const bool in = k0 + 8 * sg < p.K;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int row = sr + 64 * h;
-            *reinterpret_cast<h16x8*>(As + (size_t)buf * kHgBM * kHgBK + hg_slot(row, sg)) = to_h8(ra0[h], ra1[h]);
-            *reinterpret_cast<h16x8*>(Bs + (size_t)buf * kHgBN * kHgBK + hg_slot(row, sg)) = rbv[h];
+        for (int h = 0; h < 4; ++h) {
+            const int row = sr + 32 * h;
+            *reinterpret_cast<h16x8*>(As + (size_t)buf * kHgBM * kHgBK + hg_slot(row, sg)) = (va[h] && in) ? r.a[h] : zh;
+            *reinterpret_cast<h16x8*>(Bs + (size_t)buf * kHgBN * kHgBK + hg_slot(row, sg)) = (vb[h] && in) ? r.b[h] : zh;
         }
     };
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            h16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const h16x8*>(As + (size_t)buf * kHgBM * kHgBK + hg_slot(wm * 64 + i * 16 + l15, 4 * st + lq));
+                bf[i] = *reinterpret_cast<const h16x8*>(Bs + (size_t)buf * kHgBN * kHgBK + hg_slot(wn * 64 + i * 16 + l15, 4 * st + lq));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
     const int nk = (p.K + kHgBK - 1) / kHgBK;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * kHgBK);
-        h16x8 af[4], bf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            af[i] = *reinterpret_cast<const h16x8*>(As + (size_t)buf * kHgBM * kHgBK + hg_slot(wm * 64 + i * 16 + l15, lq));
-            bf[i] = *reinterpret_cast<const h16x8*>(Bs + (size_t)buf * kHgBN * kHgBK + hg_slot(wn * 64 + i * 16 + l15, lq));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        if (kt + 1 < nk) lstore(buf ^ 1);
+    HgStage r0, r1;
+    gload(r0, 0);
+    gload(r1, kHgBK);                                                        // beyond K: clamped address, zeroed when stored
+    lstore(r0, 0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even iteration: r0 is free (slice kt sits in LDS buffer 0), r1 holds slice kt + 1
+        gload(r0, (kt + 2) * kHgBK);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(r1, 1, (kt + 1) * kHgBK);
         __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 >= nk) break;
+        // odd iteration: r1 is free, r0 holds slice kt + 2
+        gload(r1, (kt + 3) * kHgBK);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(r0, 0, (kt + 2) * kHgBK);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // epilogue: D rows = n (4 lq + r), D columns = m (l15): C[m][n .. n + 3] is one float4 (N % 4 == 0: all four inside or none)
+    // epilogue: D rows = n (4 lq + r), D columns = m (l15): C[m][n .. n + 3] is one 16- / 8-byte store (N % 4 == 0)
     const float* bias = p.bias ? p.bias + bz * p.bias_b : nullptr;
     const float* res = p.R ? p.R + bz * p.sr_b : nullptr;
+    f32x4 bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + 4 * lq;
+        bv[j] = (bias && col < Nb) ? *reinterpret_cast<const f32x4*>(bias + col) : z4;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = m0 + wm * 64 + i * 16 + l15;
         if (row >= p.M) continue;
+        f32x4 rv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn * 64 + j * 16 + 4 * lq;
+            rv[j] = (res && col < Nb) ? *reinterpret_cast<const f32x4*>(res + (int64_t)row * p.ldr + col) : z4;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = n0 + wn * 64 + j * 16 + 4 * lq;
             if (col >= Nb) continue;
             f32x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t = p.alpha * acc[i][j][r];
-                if (bias) t += bias[col + r];
-                if (p.act == 3) t = gelu_erf_h(t);
-                else if (p.act == 5) t = tanhf(t);
-                v[r] = t;
+            for (int r = 0; r < 4; ++r) v[r] = hg_act<ACT>(p.alpha * acc[i][j][r] + bv[j][r]) + rv[j][r];
+            if (CF16) {
+                h16x4 hv;
+                hv[0] = (_Float16)v[0]; hv[1] = (_Float16)v[1]; hv[2] = (_Float16)v[2]; hv[3] = (_Float16)v[3];
+                *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(p.C) + bz * p.sc_b + (int64_t)row * p.ldc + col) = hv;
+            } else {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + bz * p.sc_b + (int64_t)row * p.ldc + col) = v;
             }
-            if (res) {
-                const f32x4 rv = *reinterpret_cast<const f32x4*>(res + (int64_t)row * p.ldr + col);
-                v += rv;
-            }
-            *reinterpret_cast<f32x4*>(c + (int64_t)row * p.ldc + col) = v;
         }
     }
+}
+
+// lucidrains RMSNorm (y = x / max(||x||_2, 1e-12) sqrt(C) gamma, sum of squares in double as nn_rmsnorm_kernel) with the result stored
+// as IEEE half: the A operand of the Linear that follows.  One wave per row.
+__global__ void __launch_bounds__(kHThreads)
+nn_rmsnorm_h_kernel(const float* __restrict__ x, _Float16* __restrict__ y, const float* __restrict__ gamma, int64_t rows, int C, int64_t x_stride,
+                    int64_t y_stride) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (kHThreads / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * x_stride;
+    double ss = 0.0;
+    for (int c = lane; c < C; c += 64) ss += (double)xr[c] * (double)xr[c];
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float inv = sqrtf((float)C) / fmaxf((float)sqrt(ss), 1e-12f);
+    _Float16* yr = y + row * y_stride;
+    for (int c = lane; c < C; c += 64) yr[c] = (_Float16)(xr[c] * inv * gamma[c]);
 }
 
 __global__ void __launch_bounds__(kHThreads)
@@ -159,9 +242,11 @@ to_f16_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int64_t n) 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
-// Attention.  qkv: float32 rows of 3 * heads * 64 values (q | k | v, head-major inside each), rotary embedding already applied; a
-// sequence is L rows `row_stride` floats apart starting at seq * seq_stride.  out: float32 rows of heads * 64, same row order through
-// (o_seq_stride, o_row_stride).  head dimension 64.
+// Attention.  qkv: IEEE-half rows of 3 * heads * 64 values (q | k | v, head-major inside each) as the projection wrote them; a
+// sequence is L rows `row_stride` elements apart starting at seq * seq_stride.  q and k are rotary-embedded by their position in the
+// sequence as they are loaded (float32 arithmetic on the stored halves, table of rotary_table_kernel), q scaled by d^-1/2; the result is
+// scaled by sigmoid(gates[row][head]) and stored as IEEE half (the A operand of the output projection) through (o_seq_stride,
+// o_row_stride).  head dimension 64.
 //
 // One workgroup = 64 queries of one (sequence, head), four waves of 16 queries; keys / values in chunks of 32 staged through LDS for
 // all four waves (K rows of 64 halves, 16-byte groups XOR-swizzled by row & 7: conflict-free ds_read_b128; V TRANSPOSED, rows of 32
@@ -202,30 +287,38 @@ rotary_table_kernel(float* __restrict__ table, int L, int d) {
 }
 constexpr size_t kAtLds = (size_t)kAtKc * kAtD * sizeof(_Float16) + (size_t)kAtD * kAtVld * sizeof(_Float16);     // 4096 + 4608
 
+// 8 halves -> two float4
+__device__ __forceinline__ void h8_to_f(const h16x8& v, f32x4& a, f32x4& b) {
+    a[0] = (float)v[0]; a[1] = (float)v[1]; a[2] = (float)v[2]; a[3] = (float)v[3];
+    b[0] = (float)v[4]; b[1] = (float)v[5]; b[2] = (float)v[6]; b[3] = (float)v[7];
+}
+
 __global__ void __launch_bounds__(kHThreads)
-nn_attn_h_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, int heads, int64_t seq_stride, int64_t row_stride,
+nn_attn_h_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out, int L, int heads, int64_t seq_stride, int64_t row_stride,
                  int64_t o_seq_stride, int64_t o_row_stride, float scale, const float* __restrict__ rot, const float* __restrict__ gates,
                  int64_t g_seq_stride, int64_t g_row_stride) {
     _Float16* Ks = reinterpret_cast<_Float16*>(alsep_smem);                  // [32 keys][64 d], swizzled groups
     _Float16* Vt = Ks + kAtKc * kAtD;                                         // [64 d][36]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int head = blockIdx.y, seq = blockIdx.z;
+    // 1-D grid over (sequence, head, query block), query block fastest, dealt to the XCDs in contiguous runs: the workgroups that read the
+    // same keys / values share one L2
+    const int qblocks = (L + 63) / 64;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = wg % qblocks, head = (wg / qblocks) % heads, seq = wg / (qblocks * heads);
     const int inner = heads * kAtD;
-    const float* base = qkv + seq * seq_stride + head * kAtD;
-    const float* kbase = base + inner;
-    const float* vbase = base + 2 * inner;
-    const int q = blockIdx.x * 64 + wave * 16 + l15;                          // this lane's query (the MFMA column)
+    const _Float16* base = qkv + seq * seq_stride + head * kAtD;
+    const _Float16* kbase = base + inner;
+    const _Float16* vbase = base + 2 * inner;
+    const int q = qb * 64 + wave * 16 + l15;                                  // this lane's query (the MFMA column)
     const bool qok = q < L;
-    // Q fragments: B operand of S^T = K Q^T: lane (col = query l15, quarter lq) holds Q[q][32 s + 8 lq .. + 7]
+    // Q fragments: B operand of S^T = K Q^T: lane (col = query l15, quarter lq) holds Q[q][32 s + 8 lq .. + 7], rotated and scaled
     h16x8 qf[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
         if (qok) {
-            const float* src = base + (int64_t)q * row_stride + 32 * s + 8 * lq;
-            a = *reinterpret_cast<const f32x4*>(src);
-            b = *reinterpret_cast<const f32x4*>(src + 4);
+            h8_to_f(*reinterpret_cast<const h16x8*>(base + (int64_t)q * row_stride + 32 * s + 8 * lq), a, b);
             if (rot) rotate8(a, b, rot + ((int64_t)q * (kAtD / 2) + 16 * s + 4 * lq) * 2);
         }
         qf[s] = to_h8(a * scale, b * scale);
@@ -235,23 +328,25 @@ nn_attn_h_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, 
     for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     float mrun = -3.0e38f, lsum = 0.f;                                        // running max (shared by the query's 4 lanes), this lane's partial sum
     const int skey = tid >> 3, sgrp = tid & 7;                                // staging duty: key skey, 8 d values from 8 sgrp
-    for (int k0 = 0; k0 < L; k0 += kAtKc) {
-        f32x4 ka = f32x4{0.f, 0.f, 0.f, 0.f}, kb = ka, va = ka, vb = ka;
-        if (k0 + skey < L) {
-            const int64_t off = (int64_t)(k0 + skey) * row_stride + 8 * sgrp;
-            ka = *reinterpret_cast<const f32x4*>(kbase + off);
-            kb = *reinterpret_cast<const f32x4*>(kbase + off + 4);
-            if (rot) rotate8(ka, kb, rot + ((int64_t)(k0 + skey) * (kAtD / 2) + 4 * sgrp) * 2);
-            va = *reinterpret_cast<const f32x4*>(vbase + off);
-            vb = *reinterpret_cast<const f32x4*>(vbase + off + 4);
-        }
-        __syncthreads();                                                      // every wave is done with the previous chunk
-        *reinterpret_cast<h16x8*>(Ks + skey * kAtD + 8 * (sgrp ^ (skey & 7))) = to_h8(ka, kb);
+    h16x8 zh;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            Vt[(8 * sgrp + e) * kAtVld + skey] = (_Float16)va[e];
-            Vt[(8 * sgrp + 4 + e) * kAtVld + skey] = (_Float16)vb[e];
+    for (int e = 0; e < 8; ++e) zh[e] = (_Float16)0.f;
+    for (int k0 = 0; k0 < L; k0 += kAtKc) {
+        const bool kin = k0 + skey < L;
+        const int64_t off = (int64_t)(kin ? k0 + skey : 0) * row_stride + 8 * sgrp;   // clamped: the loads are unconditional
+        h16x8 kv = *reinterpret_cast<const h16x8*>(kbase + off);
+        h16x8 vv = *reinterpret_cast<const h16x8*>(vbase + off);
+        if (rot) {
+            f32x4 ka, kb;
+            h8_to_f(kv, ka, kb);
+            rotate8(ka, kb, rot + ((int64_t)(kin ? k0 + skey : 0) * (kAtD / 2) + 4 * sgrp) * 2);
+            kv = to_h8(ka, kb);
         }
+        if (!kin) { kv = zh; vv = zh; }
+        __syncthreads();                                                      // every wave is done with the previous chunk
+        *reinterpret_cast<h16x8*>(Ks + skey * kAtD + 8 * (sgrp ^ (skey & 7))) = kv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vt[(8 * sgrp + e) * kAtVld + skey] = vv[e];
         __syncthreads();
         // S^T blocks: keys 16 kb + (4 lq + r), query l15
         f32x4 s[2];
@@ -306,27 +401,31 @@ nn_attn_h_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, 
     if (qok) {
         float inv = 1.f / lsum;
         if (gates) inv *= 1.f / (1.f + expf(-gates[seq * g_seq_stride + (int64_t)q * g_row_stride + head]));    // out * sigmoid(gate[row][head])
-        float* dst = out + seq * o_seq_stride + (int64_t)q * o_row_stride + head * kAtD;
+        _Float16* dst = out + seq * o_seq_stride + (int64_t)q * o_row_stride + head * kAtD;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) *reinterpret_cast<f32x4*>(dst + 16 * d + 4 * lq) = o[d] * inv;      // O^T rows d = 16 d + 4 lq + r
+        for (int d = 0; d < 4; ++d) {                                         // O^T rows d = 16 d + 4 lq + r
+            h16x4 hv;
+            hv[0] = (_Float16)(o[d][0] * inv); hv[1] = (_Float16)(o[d][1] * inv); hv[2] = (_Float16)(o[d][2] * inv); hv[3] = (_Float16)(o[d][3] * inv);
+            *reinterpret_cast<h16x4*>(dst + 16 * d + 4 * lq) = hv;
+        }
     }
 }
 
 // Roformer band split, input side, for ALL bands in one launch: gather a band's bins of one frame from the spectrogram ([4][F][T] as
 // alsep_stft writes it; merged index m = 2 f + s), RMS-normalise them over the band's true width (lucidrains RMSNorm: x / max(||x||,
-// 1e-12) sqrt(width) gamma, sum of squares in double as nn_rmsnorm_kernel) and store the row zero-padded to kmax: feat[band][t][kmax] is
+// 1e-12) sqrt(width) gamma, sum of squares in double as nn_rmsnorm_kernel) and store the row zero-padded to kmax, as IEEE half: feat[band][t][kmax] is
 // then the A operand of ONE batched Linear over the bands (weights zero-padded alike).  pidx[band][kmax / 2]: merged index or -1;
 // gamma[band][kmax].  One wave per (band, frame).
 __global__ void __launch_bounds__(kHThreads)
 roformer_bandsplit_in_kernel(const float* __restrict__ spec, const int* __restrict__ pidx, const float* __restrict__ gamma,
-                             const int* __restrict__ width, float* __restrict__ feat, int nb, int F, int T, int kmax) {
+                             const int* __restrict__ width, _Float16* __restrict__ feat, int nb, int F, int T, int kmax) {
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * (kHThreads / 64) + (threadIdx.x >> 6);
     if (w >= (int64_t)nb * T) return;
     const int band = (int)(w / T), t = (int)(w % T);
     const int* pi = pidx + (int64_t)band * (kmax / 2);
     const float* g = gamma + (int64_t)band * kmax;
-    float* out = feat + w * kmax;
+    _Float16* out = feat + w * kmax;
     const int64_t plane = (int64_t)F * T;
     constexpr int PER = 5;                                                   // kmax / 2 <= 320 entries per band
     float re[PER], im[PER];
@@ -351,8 +450,8 @@ roformer_bandsplit_in_kernel(const float* __restrict__ spec, const int* __restri
     for (int k = 0; k < PER; ++k) {
         const int i = lane + 64 * k;
         if (i < kmax / 2) {
-            out[2 * i] = re[k] * inv * g[2 * i];
-            out[2 * i + 1] = im[k] * inv * g[2 * i + 1];
+            out[2 * i] = (_Float16)(re[k] * inv * g[2 * i]);
+            out[2 * i + 1] = (_Float16)(im[k] * inv * g[2 * i + 1]);
         }
     }
 }
@@ -360,14 +459,14 @@ roformer_bandsplit_in_kernel(const float* __restrict__ spec, const int* __restri
 }  // namespace
 
 // feat[band][t][kmax] = RMSNorm_band(gathered bins of frame t), zero-padded (see roformer_bandsplit_in_kernel); kmax <= 640, even
-extern "C" int alsep_roformer_bandsplit_in(alsep_ctx* ctx, const float* spec, const int* pidx, const float* gamma, const int* width, float* feat,
+extern "C" int alsep_roformer_bandsplit_in(alsep_ctx* ctx, const float* spec, const int* pidx, const float* gamma, const int* width, void* feat,
                                            int nb, int F, int T, int kmax) {
     ALSEP_ENTER(ctx);
     if (!ctx || !spec || !pidx || !gamma || !width || !feat || nb < 1 || F < 1 || T < 1 || kmax < 2 || kmax % 2 || kmax > 640)
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_roformer_bandsplit_in: bad argument");
     const int64_t waves = (int64_t)nb * T;
     hipLaunchKernelGGL(roformer_bandsplit_in_kernel, dim3((unsigned)ceil_div64(waves, kHThreads / 64)), dim3(kHThreads), 0, ctx->stream, spec, pidx,
-                       gamma, width, feat, nb, F, T, kmax);
+                       gamma, width, (_Float16*)feat, nb, F, T, kmax);
     ALSEP_LAUNCH_CHECK(ctx, "roformer_bandsplit_in_kernel");
     return ALSEP_OK;
 }
@@ -382,32 +481,52 @@ extern "C" int alsep_nn_to_f16(alsep_ctx* ctx, const float* x, void* y, int64_t 
     return ALSEP_OK;
 }
 
-// C[b][M][N] = act(alpha A[b][M][K] W[b][N][K]^T + bias[b][N]) (+ R[b][M][N]); A / C / R float32 (row strides lda / ldc / ldr, batch
-// strides in elements, 0 = shared), W f16 (row stride ldw).  Needs K % 8 == 0, N % 4 == 0, lda % 4 == 0, ldw % 8 == 0, ldc % 4 == 0,
-// ldr % 4 == 0 and 16-byte aligned bases (returns ALSEP_ERR_ARG otherwise: the caller keeps such products on alsep_nn_bgemm_bias).
-extern "C" int alsep_nn_gemm_f16w(alsep_ctx* ctx, const float* A, int64_t lda, int64_t sa_b, const void* W, int64_t ldw, int64_t sw_b, float* C,
-                                  int64_t ldc, int64_t sc_b, const float* bias, int64_t bias_b, const float* R, int64_t ldr, int64_t sr_b,
-                                  int nb, int M, int N, int K, float alpha, int act, const int* n_per_batch) {
+// C[b][M][N] = act(alpha A[b][M][K] W[b][N][K]^T + bias[b][N]) (+ R[b][M][N]): A, W IEEE half; C half (c_f16) or float32; bias, R float32.
+// Row strides ld*, batch strides s*_b in elements (0 = shared).  Needs K % 8 == 0, N % 4 == 0, lda % 8 == 0, ldw % 8 == 0, ldc % 4 == 0,
+// ldr % 4 == 0 and 16-byte (C half: 8-byte) aligned bases (ALSEP_ERR_ARG otherwise).  n_per_batch (device, optional): columns of
+// batch b.
+extern "C" int alsep_nn_gemm_f16(alsep_ctx* ctx, const void* A, int64_t lda, int64_t sa_b, const void* W, int64_t ldw, int64_t sw_b, void* C,
+                                 int c_f16, int64_t ldc, int64_t sc_b, const float* bias, int64_t bias_b, const float* R, int64_t ldr,
+                                 int64_t sr_b, int nb, int M, int N, int K, float alpha, int act, const int* n_per_batch) {
     ALSEP_ENTER(ctx);
-    if (!ctx || !A || !W || !C || nb < 1 || nb > 65535 || M < 1 || N < 1 || K < 8 || !(act == 0 || act == 3 || act == 5))
-        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_gemm_f16w: bad argument");
-    if (K % 8 || N % 4 || lda % 4 || ldw % 8 || ldc % 4 || sa_b % 4 || sw_b % 8 || sc_b % 4 || lda < K || ldw < K || ldc < N ||
-        (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) || (R && (ldr % 4 || sr_b % 4 || ldr < N || ((uintptr_t)R & 15))))
-        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_gemm_f16w: operands do not meet the alignment this kernel needs");
-    GemmHArgs p{A, lda, sa_b, (const _Float16*)W, ldw, sw_b, C, ldc, sc_b, bias, bias_b, R, ldr, sr_b, M, N, K, alpha, act, n_per_batch};
-    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)nn_gemm_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHgLds));
-    const dim3 grid((unsigned)ceil_div64(N, kHgBN), (unsigned)ceil_div64(M, kHgBM), (unsigned)nb);
+    if (!ctx || !A || !W || !C || nb < 1 || M < 1 || N < 1 || K < 8 || !(act == 0 || act == 3 || act == 5))
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_gemm_f16: bad argument");
+    if (K % 8 || N % 4 || lda % 8 || ldw % 8 || ldc % 4 || sa_b % 8 || sw_b % 8 || sc_b % 4 || bias_b % 4 || lda < K || ldw < K || ldc < N ||
+        (((uintptr_t)A | (uintptr_t)W) & 15) || ((uintptr_t)C & (c_f16 ? 7 : 15)) || (bias && ((uintptr_t)bias & 15)) ||
+        (R && (ldr % 4 || sr_b % 4 || ldr < N || ((uintptr_t)R & 15))))
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_gemm_f16: operands do not meet the alignment this kernel needs");
+    GemmHArgs p{(const _Float16*)A, lda, sa_b, (const _Float16*)W, ldw, sw_b, C, ldc, sc_b, bias, bias_b, R, ldr, sr_b, M, N, K, alpha, n_per_batch};
+    const int64_t n_wg = ceil_div64(N, kHgBN) * ceil_div64(M, kHgBM) * nb;
+    if (n_wg > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_gemm_f16: too many tiles");
+    const dim3 grid((unsigned)n_wg);
     ProfScope prof(ctx, ALSEP_PROF_NN_GEMM_H);
-    prof.work(2.0 * nb * (double)M * N * K, (double)nb * (4.0 * M * K + 2.0 * N * K + (R ? 8.0 : 4.0) * M * N));
-    hipLaunchKernelGGL(nn_gemm_h_kernel, grid, dim3(kHThreads), kHgLds, ctx->stream, p);
-    ALSEP_LAUNCH_CHECK(ctx, "nn_gemm_h_kernel");
+    prof.work(2.0 * nb * (double)M * N * K, (double)nb * (2.0 * M * K + 2.0 * N * K + ((c_f16 ? 2.0 : 4.0) + (R ? 4.0 : 0.0)) * M * N));
+#define ALSEP_HG_GO(ACT_, CF_)                                                                                                              \
+    do {                                                                                                                                    \
+        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)nn_gemm_hh_kernel<ACT_, CF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHgLds)); \
+        hipLaunchKernelGGL((nn_gemm_hh_kernel<ACT_, CF_>), grid, dim3(kHThreads), kHgLds, ctx->stream, p);                                  \
+    } while (0)
+    if (c_f16) {
+        if (act == 3) ALSEP_HG_GO(3, true); else if (act == 5) ALSEP_HG_GO(5, true); else ALSEP_HG_GO(0, true);
+    } else {
+        if (act == 3) ALSEP_HG_GO(3, false); else if (act == 5) ALSEP_HG_GO(5, false); else ALSEP_HG_GO(0, false);
+    }
+#undef ALSEP_HG_GO
+    ALSEP_LAUNCH_CHECK(ctx, "nn_gemm_hh_kernel");
     return ALSEP_OK;
 }
 
-// out[seq][row][head][64] = softmax(scale q k^T) v per (sequence, head) of a packed q | k | v projection (see nn_attn_h_kernel).
-// Strides in floats; every row start must be 16-byte aligned (strides % 4 == 0); head dimension 64.  rot_table (optional,
-// alsep_nn_rotary_table): q and k are rotary-embedded by their position in the sequence as they are loaded (qkv then holds the raw
-// projection); gates (optional): the result is scaled by sigmoid(gates[seq * g_seq_stride + row * g_row_stride + head]).
+// y[r][C] (IEEE half) = RMSNorm(x[r][C]) gamma (see nn_rmsnorm_h_kernel); strides in elements
+extern "C" int alsep_nn_rmsnorm_f16(alsep_ctx* ctx, const float* x, void* y, const float* gamma, int64_t rows, int C, int64_t x_stride,
+                                    int64_t y_stride) {
+    ALSEP_ENTER(ctx);
+    if (!ctx || !x || !y || !gamma || rows < 1 || C < 1 || x_stride < C || y_stride < C) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_rmsnorm_f16: bad argument");
+    hipLaunchKernelGGL(nn_rmsnorm_h_kernel, dim3((unsigned)ceil_div64(rows, kHThreads / 64)), dim3(kHThreads), 0, ctx->stream, x, (_Float16*)y, gamma,
+                       rows, C, x_stride, y_stride);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_rmsnorm_h_kernel");
+    return ALSEP_OK;
+}
+
 extern "C" int alsep_nn_rotary_table(alsep_ctx* ctx, float* table, int L, int dim_head) {
     ALSEP_ENTER(ctx);
     if (!ctx || !table || L < 1 || dim_head < 2 || dim_head % 2) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_rotary_table: bad argument");
@@ -416,21 +535,23 @@ extern "C" int alsep_nn_rotary_table(alsep_ctx* ctx, float* table, int L, int di
     return ALSEP_OK;
 }
 
-extern "C" int alsep_nn_attention_f16(alsep_ctx* ctx, const float* qkv, float* out, int n_seq, int L, int heads, int dim_head, int64_t seq_stride,
+extern "C" int alsep_nn_attention_f16(alsep_ctx* ctx, const void* qkv, void* out, int n_seq, int L, int heads, int dim_head, int64_t seq_stride,
                                       int64_t row_stride, int64_t o_seq_stride, int64_t o_row_stride, float scale, const float* rot_table,
                                       const float* gates, int64_t g_seq_stride, int64_t g_row_stride) {
     ALSEP_ENTER(ctx);
-    if (!ctx || !qkv || !out || n_seq < 1 || n_seq > 65535 || L < 1 || heads < 1 || heads > 65535)
+    if (!ctx || !qkv || !out || n_seq < 1 || L < 1 || heads < 1)
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_attention_f16: bad argument");
     if (dim_head != kAtD) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_attention_f16: head dimension %d (64 is implemented)", dim_head);
-    if (seq_stride % 4 || row_stride % 4 || o_seq_stride % 4 || o_row_stride % 4 || (((uintptr_t)qkv | (uintptr_t)out) & 15))
-        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_attention_f16: strides / bases must be multiples of 16 bytes");
-    const dim3 grid((unsigned)ceil_div64(L, 64), (unsigned)heads, (unsigned)n_seq);
+    if (seq_stride % 8 || row_stride % 8 || o_seq_stride % 4 || o_row_stride % 4 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7))
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_attention_f16: strides / bases must be multiples of 16 (qkv) / 8 (out) bytes");
+    const int64_t n_wg = ceil_div64(L, 64) * heads * n_seq;
+    if (n_wg > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_attention_f16: too many workgroups");
+    const dim3 grid((unsigned)n_wg);
     ProfScope prof(ctx, ALSEP_PROF_NN_ATTN_H);
-    prof.work(4.0 * n_seq * heads * (double)L * L * kAtD, 4.0 * n_seq * heads * (double)L * kAtD * 4.0);
+    prof.work(4.0 * n_seq * heads * (double)L * L * kAtD, 2.0 * n_seq * heads * (double)L * kAtD * 4.0);
     if (rot_table && ((uintptr_t)rot_table & 15)) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_attention_f16: rotary table must be 16-byte aligned");
-    hipLaunchKernelGGL(nn_attn_h_kernel, grid, dim3(kHThreads), kAtLds, ctx->stream, qkv, out, L, heads, seq_stride, row_stride, o_seq_stride,
-                       o_row_stride, scale, rot_table, gates, g_seq_stride, g_row_stride);
+    hipLaunchKernelGGL(nn_attn_h_kernel, grid, dim3(kHThreads), kAtLds, ctx->stream, (const _Float16*)qkv, (_Float16*)out, L, heads, seq_stride,
+                       row_stride, o_seq_stride, o_row_stride, scale, rot_table, gates, g_seq_stride, g_row_stride);
     ALSEP_LAUNCH_CHECK(ctx, "nn_attn_h_kernel");
     return ALSEP_OK;
 }

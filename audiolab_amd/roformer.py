@@ -157,10 +157,18 @@ class _Lin:
         self.b = b.detach().float().contiguous().to(ctx.device) if b is not None else None
         # half-precision mode: the weight matrix once more as IEEE half (rounded on the device, round-to-nearest-even) for the f16 MFMA
         # kernel -- only for shapes that kernel takes (whole 8-element k-groups, float4 output columns)
-        self.wh = None
-        if half and self.inp % 8 == 0 and self.out % 4 == 0:
-            self.wh = torch.empty((self.out, self.inp), dtype=torch.float16, device=ctx.device)
-            ctx.check(ctx.lib.alsep_nn_to_f16(ctx.handle, _lib.ptr(self.w), _lib.ptr(self.wh), self.w.numel()), "alsep_nn_to_f16")
+        # (output rows zero-padded to a multiple of 4: the kernel stores whole 4-column groups)
+        self.wh, self.out_p, self.bh = None, -(-self.out // 4) * 4, None
+        if half:
+            if self.inp % 8:
+                raise AlsepError(f"Roformer half mode: a Linear with {self.inp} inputs (must be a multiple of 8)")
+            wp = torch.zeros((self.out_p, self.inp), device=ctx.device)
+            wp[: self.out] = self.w
+            self.wh = torch.empty((self.out_p, self.inp), dtype=torch.float16, device=ctx.device)
+            ctx.check(ctx.lib.alsep_nn_to_f16(ctx.handle, _lib.ptr(wp), _lib.ptr(self.wh), wp.numel()), "alsep_nn_to_f16")
+            if self.b is not None:
+                self.bh = torch.zeros((self.out_p,), device=ctx.device)
+                self.bh[: self.out] = self.b
 
 
 class Roformer:
@@ -178,6 +186,8 @@ class Roformer:
         self.dtype = torch.float32
         self.precision = precision
         half = precision == "f16"
+        if half and cfg.dim_head != 64:
+            raise AlsepError("Roformer half mode: the one-pass attention kernel is written for dim_head 64")
         sd = state_dict
         dev = self.ctx.device
         bands = band_indices(cfg)
@@ -307,43 +317,72 @@ class Roformer:
             self._mask_cols[T] = (torch.tensor(a, dtype=torch.int32, device=dev), torch.tensor(g, dtype=torch.int32, device=dev))
         return self._mask_cols[T]
 
-    def _bgemm_h(self, a: torch.Tensor, lda: int, sa_b: int, w: torch.Tensor, bias: torch.Tensor, c_ptr: int, ldc: int, sc_b: int, M: int, N: int,
-                 K: int, act: int = 0, nvec: Optional[torch.Tensor] = None) -> None:
-        """one batched f16 GEMM over the bands: C[b] = act(A[b] W[b]^T + bias[b])"""
+    def _bgemm_h(self, a16: torch.Tensor, lda: int, sa_b: int, w: torch.Tensor, bias: torch.Tensor, c: torch.Tensor, c_off: int, ldc: int, sc_b: int,
+                 M: int, N: int, K: int, act: int = 0, nvec: Optional[torch.Tensor] = None) -> None:
+        """one batched f16 GEMM over the bands: C[b] = act(A[b] W[b]^T + bias[b]); C half or float32 by its dtype, written from element c_off"""
         ctx = self.ctx
-        ctx.check(ctx.lib.alsep_nn_gemm_f16w(ctx.handle, _lib.ptr(a), lda, sa_b, _lib.ptr(w), K, N * K, C.c_void_p(c_ptr), ldc, sc_b, _lib.ptr(bias), N,
-                                             None, 0, 0, self.nb, M, N, K, 1.0, act, _lib.ptr(nvec) if nvec is not None else None), "alsep_nn_gemm_f16w")
+        half_out = c.dtype == torch.float16
+        ctx.check(ctx.lib.alsep_nn_gemm_f16(ctx.handle, _lib.ptr(a16), lda, sa_b, _lib.ptr(w), K, N * K,
+                                            C.c_void_p(c.data_ptr() + c_off * (2 if half_out else 4)), 1 if half_out else 0, ldc, sc_b, _lib.ptr(bias), N,
+                                            None, 0, 0, self.nb, M, N, K, 1.0, act, _lib.ptr(nvec) if nvec is not None else None), "alsep_nn_gemm_f16")
 
     # -- helpers --------------------------------------------------------------------------------------------
-    def _gemm(self, a_ptr: int, sa, lin: _Lin, c_ptr: int, sc, M: int, act: int = 0, nb1: int = 1, nb2: int = 1, use_bias: bool = True,
-              res_ptr: Optional[int] = None, res_ld: int = 0) -> None:
-        """C = act(A W^T + b) [+ R] with A / C given by (pointer, strides (b1, b2, row, k)).  A residual is only taken by the half path."""
+    def _gemm(self, a_ptr: int, sa, lin: _Lin, c_ptr: int, sc, M: int, act: int = 0, nb1: int = 1, nb2: int = 1, use_bias: bool = True) -> None:
+        """float32 mode: C = act(A W^T + b) with A / C given by (pointer, strides (b1, b2, row, k))"""
         ctx = self.ctx
-        bias = _lib.ptr(lin.b) if (lin.b is not None and use_bias) else None
-        if (lin.wh is not None and nb1 == 1 and nb2 == 1 and sa[3] == 1 and sc[3] == 1 and sa[2] % 4 == 0 and sc[2] % 4 == 0
-                and a_ptr % 16 == 0 and c_ptr % 16 == 0):
-            ctx.check(ctx.lib.alsep_nn_gemm_f16w(ctx.handle, C.c_void_p(a_ptr), sa[2], 0, _lib.ptr(lin.wh), lin.inp, 0, C.c_void_p(c_ptr), sc[2], 0,
-                                                 bias, 0, C.c_void_p(res_ptr) if res_ptr else None, res_ld, 0, 1, M, lin.out, lin.inp, 1.0, act, None),
-                      "alsep_nn_gemm_f16w")
-            return
-        if res_ptr:
-            raise AlsepError("Roformer._gemm: a fused residual needs the half-precision kernel")
         arr = C.c_int64 * 4
+        bias = _lib.ptr(lin.b) if (lin.b is not None and use_bias) else None
         ctx.check(ctx.lib.alsep_nn_bgemm_bias(ctx.handle, C.c_void_p(a_ptr), _lib.ptr(lin.w), C.c_void_p(c_ptr), nb1, nb2, M, lin.out, lin.inp,
                                               arr(*sa), arr(0, 0, lin.inp, 1), arr(*sc), 1.0, bias, act), "alsep_nn_bgemm_bias")
 
     def _dense(self, x: torch.Tensor, rows: int, lin: _Lin, act: int = 0, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """act(x W^T + b) [+ residual]; the residual add is fused into the half-precision kernel's epilogue, a separate launch otherwise"""
+        """float32 mode: act(x W^T + b) [+ residual]"""
         y = self.ctx.empty((rows, lin.out))
-        fuse = residual is not None and lin.wh is not None
-        self._gemm(x.data_ptr(), (0, 0, lin.inp, 1), lin, y.data_ptr(), (0, 0, lin.out, 1), rows, act,
-                   res_ptr=residual.data_ptr() if fuse else None, res_ld=lin.out)
-        if residual is not None and not fuse:
+        self._gemm(x.data_ptr(), (0, 0, lin.inp, 1), lin, y.data_ptr(), (0, 0, lin.out, 1), rows, act)
+        if residual is not None:
             out = self.ctx.empty((rows, lin.out))
             self.ctx.check(self.ctx.lib.alsep_nn_scale_add(self.ctx.handle, _lib.ptr(residual), _lib.ptr(y), None, _lib.ptr(out), rows, lin.out),
                            "alsep_nn_scale_add")
             return out
         return y
+
+    # -- half mode: IEEE-half activations between the kernels, float32 residual stream -------------------------------------------------
+    def _dense_h(self, x16: torch.Tensor, rows: int, lin: _Lin, act: int = 0, out_half: bool = True, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """act(x W^T + b) [+ residual] on the f16 MFMA: x16 [rows, in] half -> [rows, out padded to 4] half or float32"""
+        ctx = self.ctx
+        y = ctx.empty((rows, lin.out_p), torch.float16 if out_half else torch.float32)
+        ctx.check(ctx.lib.alsep_nn_gemm_f16(ctx.handle, _lib.ptr(x16), lin.inp, 0, _lib.ptr(lin.wh), lin.inp, 0, _lib.ptr(y), 1 if out_half else 0,
+                                            lin.out_p, 0, _lib.ptr(lin.bh) if lin.bh is not None else None, 0,
+                                            _lib.ptr(residual) if residual is not None else None, lin.out_p, 0, 1, rows, lin.out_p, lin.inp, 1.0, act,
+                                            None), "alsep_nn_gemm_f16")
+        return y
+
+    def _rmsnorm_h(self, x: torch.Tensor, rows: int, Cn: int, gamma: torch.Tensor) -> torch.Tensor:
+        ctx = self.ctx
+        y = ctx.empty((rows, Cn), torch.float16)
+        ctx.check(ctx.lib.alsep_nn_rmsnorm_f16(ctx.handle, _lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), rows, Cn, Cn, Cn), "alsep_nn_rmsnorm_f16")
+        return y
+
+    def _transformer_h(self, x: torch.Tensor, T: int, P, over_time: bool) -> torch.Tensor:
+        """one transformer block in the half mode: 8 launches (RMSNorm, q | k | v, gates, attention with the rotary embedding and the head
+        gates inside, output projection + residual, RMSNorm, GELU Linear, Linear + residual)"""
+        ctx, cfg = self.ctx, self.cfg
+        nb, dim, Hh, d = self.nb, cfg.dim, cfg.heads, cfg.dim_head
+        inner, rows = Hh * d, T * nb
+        xn = self._rmsnorm_h(x, rows, dim, P["norm"])
+        qkv = self._dense_h(xn, rows, P["qkv"])                               # half [rows, 3 inner], columns (qkv, head, d)
+        gates = self._dense_h(xn, rows, P["gates"], out_half=False)           # float32 [rows, heads padded to 4]
+        ld, gp = 3 * inner, P["gates"].out_p
+        if over_time:                                                         # batch (band, head); a sequence's rows are bands * ld apart
+            n_seq, L, seq_stride, row_stride, o_seq, o_row, g_seq, g_row = nb, T, ld, nb * ld, inner, nb * inner, gp, nb * gp
+        else:                                                                 # batch (frame, head); rows are ld apart
+            n_seq, L, seq_stride, row_stride, o_seq, o_row, g_seq, g_row = T, nb, nb * ld, ld, nb * inner, inner, nb * gp, gp
+        att = ctx.empty((rows, inner), torch.float16)
+        ctx.check(ctx.lib.alsep_nn_attention_f16(ctx.handle, _lib.ptr(qkv), _lib.ptr(att), n_seq, L, Hh, d, seq_stride, row_stride, o_seq, o_row,
+                                                 d ** -0.5, _lib.ptr(self._rot_table(L)), _lib.ptr(gates), g_seq, g_row), "alsep_nn_attention_f16")
+        x1 = self._dense_h(att, rows, P["out"], out_half=False, residual=x)
+        f = self._dense_h(self._rmsnorm_h(x1, rows, dim, P["ffn"]), rows, P["l1"], act=3)
+        return self._dense_h(f, rows, P["l2"], out_half=False, residual=x1)
 
     def _rmsnorm(self, x: torch.Tensor, rows: int, Cn: int, gamma: torch.Tensor) -> torch.Tensor:
         ctx = self.ctx
@@ -353,6 +392,8 @@ class Roformer:
 
     def _transformer(self, x: torch.Tensor, T: int, P, over_time: bool) -> torch.Tensor:
         """x [T, bands, dim] -> same.  over_time: sequences are the frames of one band; else the bands of one frame."""
+        if self.precision == "f16":
+            return self._transformer_h(x, T, P, over_time)
         ctx, cfg = self.ctx, self.cfg
         lib, h = ctx.lib, ctx.handle
         nb, dim, Hh, d = self.nb, cfg.dim, cfg.heads, cfg.dim_head
@@ -360,11 +401,9 @@ class Roformer:
         rows = T * nb
         xn = self._rmsnorm(x, rows, dim, P["norm"])
         qkv = self._dense(xn, rows, P["qkv"])                                 # [rows, 3 inner], columns (qkv, head, d)
-        fused = self.precision == "f16" and d == 64                           # rotary embedding and head gates inside the attention kernel
         pos = (nb, T) if over_time else (1, nb)                               # row r = t * bands + f: position t, or f
-        if not fused:
-            for off in (0, inner):
-                ctx.check(lib.alsep_nn_rotary(h, _lib.ptr(qkv), rows, 3 * inner, off, Hh, d, pos[0], pos[1]), "alsep_nn_rotary")
+        for off in (0, inner):
+            ctx.check(lib.alsep_nn_rotary(h, _lib.ptr(qkv), rows, 3 * inner, off, Hh, d, pos[0], pos[1]), "alsep_nn_rotary")
         arr = C.c_int64 * 4
         ld = 3 * inner
         if over_time:                                                         # batch (band, head); a sequence's rows are bands * ld apart
@@ -373,24 +412,17 @@ class Roformer:
             n_seq, L, seq_stride, row_stride = T, nb, nb * ld, ld
         att = ctx.empty((rows, inner))
         o_seq, o_row = (inner, nb * inner) if over_time else (nb * inner, inner)
-        if fused:                                                             # one pass: scores never reach HBM
-            gates = self._dense(xn, rows, P["gates"])
-            g_seq, g_row = (Hh, nb * Hh) if over_time else (nb * Hh, Hh)
-            ctx.check(lib.alsep_nn_attention_f16(h, _lib.ptr(qkv), _lib.ptr(att), n_seq, L, Hh, d, seq_stride, row_stride, o_seq, o_row,
-                                                 d ** -0.5, _lib.ptr(self._rot_table(L)), _lib.ptr(gates), g_seq, g_row), "alsep_nn_attention_f16")
-        else:
-            Lp = -(-L // 4) * 4                                                # score rows padded to 16 bytes: the tiled GEMM's float4 loads
-            scores = ctx.empty((n_seq, Hh, L, Lp))
-            base = qkv.data_ptr()
-            ctx.check(lib.alsep_nn_bgemm(h, C.c_void_p(base), C.c_void_p(base + 4 * inner), _lib.ptr(scores), n_seq, Hh, L, L, d,
-                                         arr(seq_stride, d, row_stride, 1), arr(seq_stride, d, row_stride, 1), arr(Hh * L * Lp, L * Lp, Lp, 1),
-                                         d ** -0.5), "alsep_nn_bgemm")
-            ctx.check(lib.alsep_nn_softmax_rows_ld(h, _lib.ptr(scores), n_seq * Hh * L, L, Lp), "alsep_nn_softmax_rows_ld")
-            ctx.check(lib.alsep_nn_bgemm(h, _lib.ptr(scores), C.c_void_p(base + 8 * inner), _lib.ptr(att), n_seq, Hh, L, d, L,
-                                         arr(Hh * L * Lp, L * Lp, Lp, 1), arr(seq_stride, d, 1, row_stride), arr(o_seq, d, o_row, 1), 1.0), "alsep_nn_bgemm")
-        if not fused:
-            gates = self._dense(xn, rows, P["gates"])
-            ctx.check(lib.alsep_nn_gate(h, _lib.ptr(att), _lib.ptr(gates), rows, Hh, d), "alsep_nn_gate")
+        Lp = -(-L // 4) * 4                                                    # score rows padded to 16 bytes: the tiled GEMM's float4 loads
+        scores = ctx.empty((n_seq, Hh, L, Lp))
+        base = qkv.data_ptr()
+        ctx.check(lib.alsep_nn_bgemm(h, C.c_void_p(base), C.c_void_p(base + 4 * inner), _lib.ptr(scores), n_seq, Hh, L, L, d,
+                                     arr(seq_stride, d, row_stride, 1), arr(seq_stride, d, row_stride, 1), arr(Hh * L * Lp, L * Lp, Lp, 1),
+                                     d ** -0.5), "alsep_nn_bgemm")
+        ctx.check(lib.alsep_nn_softmax_rows_ld(h, _lib.ptr(scores), n_seq * Hh * L, L, Lp), "alsep_nn_softmax_rows_ld")
+        ctx.check(lib.alsep_nn_bgemm(h, _lib.ptr(scores), C.c_void_p(base + 8 * inner), _lib.ptr(att), n_seq, Hh, L, d, L,
+                                     arr(Hh * L * Lp, L * Lp, Lp, 1), arr(seq_stride, d, 1, row_stride), arr(o_seq, d, o_row, 1), 1.0), "alsep_nn_bgemm")
+        gates = self._dense(xn, rows, P["gates"])
+        ctx.check(lib.alsep_nn_gate(h, _lib.ptr(att), _lib.ptr(gates), rows, Hh, d), "alsep_nn_gate")
         x1 = self._dense(att, rows, P["out"], residual=x)
         f = self._dense(self._rmsnorm(x1, rows, dim, P["ffn"]), rows, P["l1"], act=3)
         return self._dense(f, rows, P["l2"], residual=x1)
@@ -419,10 +451,10 @@ class Roformer:
         half = self.precision == "f16"
         if half:                                                              # all bands: one gather + RMSNorm launch, one batched f16 GEMM
             kmax = self.h_kmax
-            featp = ctx.empty((nb, T, kmax))
+            featp = ctx.empty((nb, T, kmax), torch.float16)
             ctx.check(lib.alsep_roformer_bandsplit_in(h, _lib.ptr(spec), _lib.ptr(self.h_pidx), _lib.ptr(self.h_gamma), _lib.ptr(self.h_width),
                                                       _lib.ptr(featp), nb, Fq, T, kmax), "alsep_roformer_bandsplit_in")
-            self._bgemm_h(featp, kmax, T * kmax, self.h_split_w, self.h_split_b, x.data_ptr(), nb * dim, dim, T, dim, kmax)
+            self._bgemm_h(featp, kmax, T * kmax, self.h_split_w, self.h_split_b, x, 0, nb * dim, dim, T, dim, kmax)
         else:
             feat = ctx.empty((T, 2 * self.n_idx))
             ctx.check(lib.alsep_roformer_gather(h, _lib.ptr(spec), _lib.ptr(self.midx), _lib.ptr(feat), self.n_idx, Fq, T), "alsep_roformer_gather")
@@ -435,15 +467,15 @@ class Roformer:
         for pair in self.layers:
             x = self._transformer(x, T, pair[0], over_time=True)
             x = self._transformer(x, T, pair[1], over_time=False)
-        x = self._rmsnorm(x, T * nb, dim, self.final_norm)
+        x = (self._rmsnorm_h if half else self._rmsnorm)(x, T * nb, dim, self.final_norm)
         out = ctx.empty((cfg.num_stems, 2, L))
         hidden = cfg.dim * cfg.mlp_expansion_factor
         for s in range(cfg.num_stems):
             if half:                                                          # every estimator layer: one batched f16 GEMM over the bands
                 cur, lda, sa_b = x, nb * dim, dim                             # layer input [band][T][k]: band i of x sits at column offset i * dim
                 for wst, bst, n_out, k_in, last in self.h_masks[s]:
-                    y = ctx.empty((nb, T, n_out))
-                    self._bgemm_h(cur, lda, sa_b, wst, bst, y.data_ptr(), n_out, T * n_out, T, n_out, k_in, act=0 if last else 5,
+                    y = ctx.empty((nb, T, n_out), torch.float32 if last else torch.float16)
+                    self._bgemm_h(cur, lda, sa_b, wst, bst, y, 0, n_out, T * n_out, T, n_out, k_in, act=0 if last else 5,
                                   nvec=self.h_nout if last else None)
                     cur, lda, sa_b = y, n_out, T * n_out
                 col_a, col_g = self._padded_mask_cols(T)
@@ -490,10 +522,13 @@ def view_on_stream(net, ctx: Context):
 class RoformerRunner:
     """chunked inference (``demix_track`` of the training project the checkpoints come from): mix [2, L] -> {label: [2, L]}"""
 
-    def __init__(self, net, labels: Tuple[str, ...], lanes: Optional[int] = None):
+    def __init__(self, net, labels: Tuple[str, ...], lanes: Optional[int] = None, graphs: Optional[bool] = None):
         """``net``: a Roformer, or any network of the same training project with ``cfg.chunk_size / num_overlap / num_stems`` and
         ``forward([2, chunk]) -> [num_stems, 2, chunk]`` (MDX23C).  ``lanes``: chunks in flight at once, each on a HIP stream of its
-        own (default ``ALSEP_RUNNER_LANES`` or 4 on a GPU, 1 elsewhere); per-lane weighted sums are added at the end."""
+        own (default ``ALSEP_RUNNER_LANES`` or 4 on a GPU, 1 elsewhere); per-lane weighted sums are added at the end.
+        ``graphs`` (default ``ALSEP_RUNNER_GRAPH`` or on, GPU only): a chunk is ~100-600 small launches issued from Python, which the host
+        cannot issue as fast as the GPU retires them; every lane therefore captures ONE chunk forward into a HIP graph (its launches go
+        to the lane's stream, which is the capturing stream) and replays it per chunk: static input / output buffers, one graph launch."""
         self.net, self.ctx, self.labels = net, net.ctx, labels
         if len(labels) != net.cfg.num_stems:
             raise AlsepError("one label per stem")
@@ -502,15 +537,43 @@ class RoformerRunner:
         if lanes is None:
             lanes = int(os.environ.get("ALSEP_RUNNER_LANES", "4")) if gpu else 1
         self.lanes = max(1, int(lanes)) if gpu else 1
+        if graphs is None:
+            graphs = os.environ.get("ALSEP_RUNNER_GRAPH", "1") != "0"
+        self.graphs = bool(graphs) and gpu
         self._lane_nets: List[tuple] = []
+        self._graphs: Dict[int, tuple] = {}                    # lane index -> (graph, static input, static output)
 
     def _lanes(self):
         if not self._lane_nets:
-            self._lane_nets = [(self.net, None)]
-            for _ in range(1, self.lanes):
-                st = torch.cuda.Stream(device=self.ctx.device)
-                self._lane_nets.append((view_on_stream(self.net, Context(self.ctx.device, stream=st.cuda_stream)), st))
+            if self.graphs:                                    # capture needs a non-default stream: every lane gets its own
+                for _ in range(self.lanes):
+                    st = torch.cuda.Stream(device=self.ctx.device)
+                    self._lane_nets.append((view_on_stream(self.net, Context(self.ctx.device, stream=st.cuda_stream)), st))
+            else:
+                self._lane_nets = [(self.net, None)]
+                for _ in range(1, self.lanes):
+                    st = torch.cuda.Stream(device=self.ctx.device)
+                    self._lane_nets.append((view_on_stream(self.net, Context(self.ctx.device, stream=st.cuda_stream)), st))
         return self._lane_nets
+
+    def _forward_chunk(self, k: int, lane_net, st, chunk: torch.Tensor) -> torch.Tensor:
+        """the network on one [2, Cn] chunk on lane k's stream: eagerly, or -- from the lane's second chunk on -- as a replay of the HIP
+        graph captured on that stream"""
+        if not self.graphs:
+            return lane_net.forward(chunk)
+        if k not in self._graphs:
+            y = lane_net.forward(chunk)                         # eager first: builds plans, tables and kernel attributes outside a capture
+            st.synchronize()
+            static_in = chunk.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                static_out = lane_net.forward(static_in)
+            self._graphs[k] = (g, static_in, static_out)
+            return y
+        g, static_in, static_out = self._graphs[k]
+        static_in.copy_(chunk)
+        g.replay()
+        return static_out
 
     def demix(self, mix: torch.Tensor) -> torch.Tensor:
         ctx, net = self.ctx, self.net
@@ -538,13 +601,14 @@ class RoformerRunner:
         S = cfg.num_stems
         starts = list(range(0, total, step))
         lanes = self._lanes()[: max(1, min(self.lanes, len(starts)))]
-        results = [ctx.zeros((S * 2, total)) for _ in lanes]     # one weighted sum per lane (lane 0: this context's stream)
+        results = [ctx.zeros((S * 2, total)) for _ in lanes]     # one weighted sum per lane
         counter = torch.zeros(total)
-        main = torch.cuda.current_stream(ctx.device) if len(lanes) > 1 else None
-        for _, st in lanes[1:]:
-            st.wait_stream(main)
+        main = torch.cuda.current_stream(ctx.device) if (len(lanes) > 1 or self.graphs) else None
+        for _, st in lanes:
+            if st is not None:
+                st.wait_stream(main)
 
-        def run_chunk(lane_net, res, i):
+        def run_chunk(k, lane_net, st, res, i):
             lctx = lane_net.ctx
             length = min(Cn, total - i)
             part = mix[:, i:i + length]
@@ -558,23 +622,26 @@ class RoformerRunner:
                     chunk[:, :length] = part
             else:
                 chunk = part.contiguous()
-            y = lane_net.forward(chunk)                                      # [S, 2, Cn]
-            k = 0 if i == 0 else (2 if i + step >= total else 1)
-            lctx.check(lctx.lib.alsep_nn_vec_fma(lctx.handle, C.c_void_p(res.data_ptr() + 4 * i), _lib.ptr(y), _lib.ptr(wins[k]), S * 2,
+            y = self._forward_chunk(k, lane_net, st, chunk)                  # [S, 2, Cn]
+            kind = 0 if i == 0 else (2 if i + step >= total else 1)
+            lctx.check(lctx.lib.alsep_nn_vec_fma(lctx.handle, C.c_void_p(res.data_ptr() + 4 * i), _lib.ptr(y), _lib.ptr(wins[kind]), S * 2,
                                                  length, total, Cn), "alsep_nn_vec_fma")
-            counter[i:i + length] += (w_start, w_mid, w_fin)[k][:length]
+            counter[i:i + length] += (w_start, w_mid, w_fin)[kind][:length]
 
         for n, i in enumerate(starts):
-            lane_net, st = lanes[n % len(lanes)]
+            k = n % len(lanes)
+            lane_net, st = lanes[k]
             if st is None:
-                run_chunk(lane_net, results[0], i)
+                run_chunk(k, lane_net, st, results[0], i)
             else:
                 with torch.cuda.stream(st):
-                    run_chunk(lane_net, results[n % len(lanes)], i)
+                    run_chunk(k, lane_net, st, results[k], i)
         result = results[0]
-        for k, (_, st) in enumerate(lanes[1:], start=1):
-            main.wait_stream(st)
-            ctx.check(lib.alsep_axpby(h, 1.0, _lib.ptr(results[k]), 1.0, _lib.ptr(result), result.numel()), "alsep_axpby")
+        for k, (_, st) in enumerate(lanes):
+            if st is not None:
+                main.wait_stream(st)
+            if k > 0:
+                ctx.check(lib.alsep_axpby(h, 1.0, _lib.ptr(results[k]), 1.0, _lib.ptr(result), result.numel()), "alsep_axpby")
         cnt = counter.to(ctx.device)
         ctx.check(lib.alsep_nn_vec_div(h, _lib.ptr(result), _lib.ptr(cnt), S * 2, total), "alsep_nn_vec_div")
         out = result.view(S, 2, total)

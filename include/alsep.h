@@ -337,25 +337,29 @@ int alsep_vr_band_spec(alsep_ctx* ctx, const float* spec_m, const float* extra, 
 
 /* ---- half-precision MFMA path of the transformer model families (csrc/nn_half.hip): what torch autocast does to the Linear layers and
  * the attention of the Roformer models the reference loads with use_autocast=True (modules/separator/stem_separator.py:106, :379-382).
- * Activations stay float32 in HBM; operands are rounded to IEEE half on their way into the MFMA, accumulation is float32. */
+ * The residual stream and all statistics are float32; whatever a Linear or the attention reads is IEEE half in HBM, written in that
+ * type by its producer; products on the f16 MFMA with float32 accumulation. */
 int alsep_nn_to_f16(alsep_ctx* ctx, const float* x, void* y, int64_t n);
-/* C[b][M][N] = act(alpha A[b][M][K] W[b][N][K]^T + bias[b][N]) (+ R[b][M][N]); A / C / R float32, W f16; row strides ld*, batch strides
- * s*_b in elements (0: shared).  act 0 none, 3 GELU(erf), 5 tanh.  Needs K % 8 == 0, N % 4 == 0 and 16-byte aligned rows
- * (ALSEP_ERR_ARG otherwise). */
-int alsep_nn_gemm_f16w(alsep_ctx* ctx, const float* A, int64_t lda, int64_t sa_b, const void* W, int64_t ldw, int64_t sw_b, float* C,
-                       int64_t ldc, int64_t sc_b, const float* bias, int64_t bias_b, const float* R, int64_t ldr, int64_t sr_b, int nb, int M,
-                       int N, int K, float alpha, int act, const int* n_per_batch /* device, optional: columns of batch b (<= N) */);
-/* out = softmax(scale q k^T) v per (sequence, head), one pass (no score matrix in HBM).  qkv: float32 rows of 3 * heads * 64 values
- * (q | k | v), rotary embedding applied; sequence s = L rows `row_stride` floats apart from s * seq_stride; out rows of heads * 64. */
-int alsep_nn_attention_f16(alsep_ctx* ctx, const float* qkv, float* out, int n_seq, int L, int heads, int dim_head, int64_t seq_stride,
+/* y[r][C] (half) = lucidrains RMSNorm of x[r][C] (float32) times gamma; strides in elements */
+int alsep_nn_rmsnorm_f16(alsep_ctx* ctx, const float* x, void* y, const float* gamma, int64_t rows, int C, int64_t x_stride, int64_t y_stride);
+/* C[b][M][N] = act(alpha A[b][M][K] W[b][N][K]^T + bias[b][N]) (+ R[b][M][N]); A, W half; C half (c_f16 != 0) or float32; bias, R float32;
+ * row strides ld*, batch strides s*_b in elements (0: shared).  act 0 none, 3 GELU(erf), 5 tanh.  Needs K % 8 == 0, N % 4 == 0 and aligned
+ * rows (ALSEP_ERR_ARG otherwise).  n_per_batch (device, optional): columns of batch b (<= N). */
+int alsep_nn_gemm_f16(alsep_ctx* ctx, const void* A, int64_t lda, int64_t sa_b, const void* W, int64_t ldw, int64_t sw_b, void* C, int c_f16,
+                      int64_t ldc, int64_t sc_b, const float* bias, int64_t bias_b, const float* R, int64_t ldr, int64_t sr_b, int nb, int M,
+                      int N, int K, float alpha, int act, const int* n_per_batch);
+/* out (half) = softmax(scale q k^T) v per (sequence, head), one pass (no score matrix in HBM).  qkv: half rows of 3 * heads * 64 values
+ * (q | k | v); sequence s = L rows `row_stride` elements apart from s * seq_stride; out rows of heads * 64.  rot_table (optional,
+ * alsep_nn_rotary_table): q and k are rotary-embedded by their position as they are loaded; gates (optional, float32): the result is
+ * scaled by sigmoid(gates[seq * g_seq_stride + row * g_row_stride + head]). */
+int alsep_nn_attention_f16(alsep_ctx* ctx, const void* qkv, void* out, int n_seq, int L, int heads, int dim_head, int64_t seq_stride,
                            int64_t row_stride, int64_t o_seq_stride, int64_t o_row_stride, float scale, const float* rot_table,
                            const float* gates, int64_t g_seq_stride, int64_t g_row_stride);
-/* Roformer band split, input side, all bands in one launch: feat[band][t][kmax] = RMSNorm over the band's `width[band]` gathered
+/* Roformer band split, input side, all bands in one launch: feat[band][t][kmax] (half) = RMSNorm over the band's `width[band]` gathered
  * spectrogram values of frame t (spec [4][F][T]; pidx[band][kmax / 2] merged bin index 2 f + s or -1; gamma[band][kmax]), zero-padded */
-int alsep_roformer_bandsplit_in(alsep_ctx* ctx, const float* spec, const int* pidx, const float* gamma, const int* width, float* feat, int nb,
+int alsep_roformer_bandsplit_in(alsep_ctx* ctx, const float* spec, const int* pidx, const float* gamma, const int* width, void* feat, int nb,
                                 int F, int T, int kmax);
-/* table[pos][j] = (cos, sin)(pos / 10000^(2 j / dim_head)), pos < L, j < dim_head / 2 (rotary_embedding_torch, interleaved pairs): with
- * it alsep_nn_attention_f16 rotates q and k on load, and -- with gates -- applies the head gates in its epilogue */
+/* table[pos][j] = (cos, sin)(pos / 10000^(2 j / dim_head)), pos < L, j < dim_head / 2 (rotary_embedding_torch, interleaved pairs) */
 int alsep_nn_rotary_table(alsep_ctx* ctx, float* table, int L, int dim_head);
 
 /* ---- reverb impulse-response extraction: replaces handlers/reverb.py:112-172 (extract_reverb), called from

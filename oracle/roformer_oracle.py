@@ -131,9 +131,10 @@ def _h(t: torch.Tensor) -> torch.Tensor:
 
 
 def _linear(x: torch.Tensor, wt: torch.Tensor, bias, half: bool, padded: bool = False) -> torch.Tensor:
-    """a Linear layer; ``half``: the operand rounding of the f16 MFMA kernel (= autocast's input casts), float32 accumulation and output.
-    The kernel takes whole 8-element k-groups and float4 columns; the per-band layers reach it zero-padded (``padded``: any shape)."""
-    if half and (padded or (wt.shape[1] % 8 == 0 and wt.shape[0] % 4 == 0)):
+    """a Linear layer; ``half``: its input (stored as IEEE half by the producing kernel) and its weights are half, products exact,
+    accumulation and output float32 (an output that is stored as half is rounded by the caller).  ``padded`` is documentation: the
+    per-band layers reach the kernel zero-padded, which changes nothing in the arithmetic."""
+    if half:
         return F.linear(_h(x), _h(wt), bias)
     return F.linear(x, wt, bias)
 
@@ -142,6 +143,8 @@ def _attention(cfg, w, p: str, x: torch.Tensor, half: bool = False) -> torch.Ten
     h, d = cfg.heads, cfg.dim_head
     xn = _rmsnorm(w, p + ".norm", x)
     qkv = _linear(xn, w[p + ".to_qkv.weight"], None, half)
+    if half:
+        qkv = _h(qkv)                                              # the projection is stored as IEEE half (what the attention kernel reads)
     b, n, _ = qkv.shape
     q, k, v = qkv.view(b, n, 3, h, d).permute(2, 0, 3, 1, 4)
     q, k = _rotary(q, d), _rotary(k, d)
@@ -153,7 +156,7 @@ def _attention(cfg, w, p: str, x: torch.Tensor, half: bool = False) -> torch.Ten
         att = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, dim=-1)
         out = att @ v
     gates = _linear(xn, w[p + ".to_gates.weight"], w[p + ".to_gates.bias"], half)
-    out = out * gates.permute(0, 2, 1)[..., None].sigmoid()
+    out = out * gates.permute(0, 2, 1)[..., None].sigmoid()            # (stored as IEEE half in the half mode: the rounding of _linear's input)
     return _linear(out.permute(0, 2, 1, 3).reshape(b, n, h * d), w[p + ".to_out.0.weight"], None, half)
 
 

@@ -181,6 +181,7 @@ static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline void __builtin_amdgcn_s_barrier() { emul::sync_block(); }
 static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // callers pass wave-uniform values only
 // lanes are separate fibers here: a wave-level ordering point must actually rendezvous
 static inline void __builtin_amdgcn_wave_barrier() { emul::wave_sync(); }
