@@ -368,6 +368,7 @@ def test_full_size_mdx_f16_vs_oracle(ctx):
 HALF_BOUNDS = {
     "bf16": {1: (4.5e-3, 1.15e-2), 3: (1.7e-2, 3.1e-2), 5: (2.4e-2, 4.4e-2), 7: (3.6e-2, 6.5e-2), 9: (6.7e-2, 1.2e-1), 11: (1.6e-1, 2.6e-1)},
     "f16": {1: (7.0e-4, 1.4e-3), 3: (2.3e-3, 4.0e-3), 5: (3.4e-3, 5.4e-3), 7: (5.0e-3, 8.6e-3), 9: (9.5e-3, 1.7e-2), 11: (2.7e-2, 4.4e-2)},
+}
 
 
 @pytest.mark.parametrize("storage", ["bf16", "f16"])
