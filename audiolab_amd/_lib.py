@@ -76,6 +76,8 @@ _SIGNATURES = {
     "alsep_net_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int64]),
     "alsep_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_int64, C.c_float, C.c_float, C.c_float]),
+    "alsep_net_forward_pcm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                        C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int]),
     "alsep_axpby": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64]),
     "alsep_peak_abs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "alsep_scale_by_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_float]),

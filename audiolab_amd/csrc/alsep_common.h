@@ -152,3 +152,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 
 // internal entry points shared between files
 int alsep_plan_tables(alsep_ctx* ctx, alsep_plan* plan);
+// fft.hip / fft_f16.hip: STFT with the first 1x1 convolution of the network in its epilogue (ALSEP_ERR_STATE: no such kernel for this plan)
+int ALSEP_TU_NAME(alsep_stft_first_conv)(alsep_ctx* ctx, const alsep_plan* plan, const float* pcm, int64_t ch_stride, int64_t chunk_stride,
+                                         int64_t n_chunks, void* act, const float* w, const float* scale, const float* shift, int g, float in_scale,
+                                         int zero_low);

@@ -624,7 +624,7 @@ static int launch_stft(alsep_ctx* ctx, const alsep_plan* p, const float* pcm, in
                 const int64_t spec_off = b0 * 4 * (int64_t)p->dim_f * p->dim_t;
                 hipLaunchKernelGGL((r16::stft_r16_kernel<N / 256, OutT, LAYOUT>), dim3(p->dim_t, (unsigned)nb),
                                    dim3(r16::kThreads), lds, ctx->stream, pcm + b0 * chunk_stride, ch_stride, chunk_stride,
-                                   p->chunk, p->hop, p->dim_f, p->dim_t, (const float2*)p->tw, (OutT*)spec + spec_off);
+                                   p->chunk, p->hop, p->dim_f, p->dim_t, (const float2*)p->tw, (OutT*)spec + spec_off, r16::FirstConvArgs{});
             }
             ALSEP_LAUNCH_CHECK(ctx, "stft_r16_kernel");
             return ALSEP_OK;
@@ -643,6 +643,42 @@ static int launch_stft(alsep_ctx* ctx, const alsep_plan* p, const float* pcm, in
     }
     ALSEP_LAUNCH_CHECK(ctx, "stft_kernel");
     return ALSEP_OK;
+}
+
+// STFT with the network's first 1x1 convolution in its epilogue (r16::stft_r16_kernel<..., FUSE>): act [n_chunks][T][dim_f][48] in the
+// half-precision storage type of this translation unit.  Internal: called by alsep_net_forward_pcm (tdfnet.hip).  Returns
+// ALSEP_ERR_STATE for a geometry without a three-pass kernel (the caller then runs stft + first conv separately).
+template <int N>
+static int launch_stft_first_conv(alsep_ctx* ctx, const alsep_plan* p, const float* pcm, int64_t ch_stride, int64_t chunk_stride, int64_t n_chunks,
+                                  bf16_t* act, const r16::FirstConvArgs& fc) {
+    typedef bf16_t OutT;
+    const size_t lds = r16::stft_lds_bytes<N / 256>() + r16::kFirstConvLdsFloats * sizeof(float);
+    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)r16::stft_r16_kernel<N / 256, OutT, ALSEP_LAYOUT_NHWC, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope prof(ctx, ALSEP_PROF_STFT);
+    prof.work(0.0, (double)n_chunks * (2.0 * p->chunk * 4 + (double)p->dim_f * p->dim_t * r16::kFirstConvG * sizeof(OutT)));
+    for (int64_t b0 = 0; b0 < n_chunks; b0 += 32768) {
+        const int64_t nb = std::min<int64_t>(32768, n_chunks - b0);
+        const int64_t off = b0 * (int64_t)r16::kFirstConvG * p->dim_f * p->dim_t;
+        hipLaunchKernelGGL((r16::stft_r16_kernel<N / 256, OutT, ALSEP_LAYOUT_NHWC, true>), dim3(p->dim_t, (unsigned)nb), dim3(r16::kThreads), lds,
+                           ctx->stream, pcm + b0 * chunk_stride, ch_stride, chunk_stride, p->chunk, p->hop, p->dim_f, p->dim_t,
+                           (const float2*)p->tw, act + off, fc);
+    }
+    ALSEP_LAUNCH_CHECK(ctx, "stft_first_conv_kernel");
+    return ALSEP_OK;
+}
+
+int ALSEP_TU_NAME(alsep_stft_first_conv)(alsep_ctx* ctx, const alsep_plan* plan, const float* pcm, int64_t ch_stride, int64_t chunk_stride,
+                                         int64_t n_chunks, void* act, const float* w, const float* scale, const float* shift, int g, float in_scale,
+                                         int zero_low) {
+    if (!ctx || !plan || !pcm || !act || !w || !scale || !shift) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_stft_first_conv: null argument");
+    if (g != r16::kFirstConvG || plan->dim_f > plan->n_fft / 2 || !stft_r16_enabled()) return ALSEP_ERR_STATE;
+    if (n_chunks <= 0) return ALSEP_OK;
+    const r16::FirstConvArgs fc{w, scale, shift, in_scale, zero_low};
+    if (plan->n_fft == 4096) return launch_stft_first_conv<4096>(ctx, plan, pcm, ch_stride, chunk_stride, n_chunks, (bf16_t*)act, fc);
+    if (plan->n_fft == 6144) return launch_stft_first_conv<6144>(ctx, plan, pcm, ch_stride, chunk_stride, n_chunks, (bf16_t*)act, fc);
+    if (plan->n_fft == 7680) return launch_stft_first_conv<7680>(ctx, plan, pcm, ch_stride, chunk_stride, n_chunks, (bf16_t*)act, fc);
+    return ALSEP_ERR_STATE;
 }
 
 extern "C" int ALSEP_TU_NAME(alsep_stft)(alsep_ctx* ctx, const alsep_plan* plan, const float* pcm, int64_t ch_stride,

@@ -3891,9 +3891,17 @@ WsLayout ws_layout(const alsep_net* net, int64_t B) {
     return w;
 }
 
+// the PCM side of a fused front end: frames of `plan` cut from pcm as alsep_stft cuts them
+struct PcmFront {
+    const alsep_plan* plan;
+    const float* pcm;
+    int64_t ch_stride, chunk_stride;
+    int zero_low;
+};
+
 template <typename T>
 int forward_impl(alsep_ctx* ctx, const alsep_net* net, const T* in, T* out, int64_t B, char* ws, float in_scale,
-                 float out_alpha, float out_beta) {
+                 float out_alpha, float out_beta, const PcmFront* front = nullptr) {
     const alsep_net_config& cfg = net->cfg;
     const WsLayout L = ws_layout(net, B);
     T* P[3] = {(T*)(ws + L.p0), (T*)(ws + L.p1), (T*)(ws + L.p2)};
@@ -3901,7 +3909,13 @@ int forward_impl(alsep_ctx* ctx, const alsep_net* net, const T* in, T* out, int6
     int Th = cfg.dim_t, Fw = cfg.dim_f, c = cfg.g;
     const int64_t npix0 = B * Th * Fw;
     int rc;
-    {
+    if (front) {
+        // STFT + first 1x1 convolution in one kernel: the level-0 activation straight from the PCM, no spectrogram in HBM
+        if ((rc = ALSEP_TU_NAME(alsep_stft_first_conv)(ctx, front->plan, front->pcm, front->ch_stride, front->chunk_stride, B, P[0],
+                                                       (const float*)net->first_w.p, (const float*)net->first_scale.p,
+                                                       (const float*)net->first_shift.p, cfg.g, in_scale, front->zero_low)))
+            return rc;
+    } else {
         ProfScope prof(ctx, ALSEP_PROF_POINTWISE);
         const int ppb = kFirstThreads / (cfg.g / Vec16<T>::N);
         const int64_t nblk = std::min<int64_t>(ceil_div64(npix0, ppb), 256 * 16);
@@ -4026,4 +4040,30 @@ extern "C" int ALSEP_TU_NAME(alsep_net_forward)(alsep_ctx* ctx, const alsep_net*
     if (net->cfg.dtype == ALSEP_F32)
         return forward_impl<float>(ctx, net, (const float*)spec_in, (float*)spec_out, B, (char*)workspace, in_scale, out_alpha, out_beta);
     return forward_impl<bf16_t>(ctx, net, (const bf16_t*)spec_in, (bf16_t*)spec_out, B, (char*)workspace, in_scale, out_alpha, out_beta);
+}
+
+extern "C" int alsep_net_forward_pcm_f16tu(alsep_ctx*, const alsep_net*, const alsep_plan*, const float*, int64_t, int64_t, void*, int64_t, void*,
+                                           int64_t, float, float, float, int);
+
+// alsep_stft + alsep_net_forward in one call for the half-precision networks, with the STFT and the network's first layer fused into ONE
+// kernel (fft_r16.h, FUSE): the same results bit for bit, without the spectrogram's HBM round trip.  ALSEP_ERR_STATE when this
+// (plan, network) pair has no fused kernel (float32 network, g != 48, n_fft other than 4096 / 6144 / 7680): call the two functions then.
+extern "C" int ALSEP_TU_NAME(alsep_net_forward_pcm)(alsep_ctx* ctx, const alsep_net* net, const alsep_plan* plan, const float* pcm,
+                                                    int64_t ch_stride, int64_t chunk_stride, void* spec_out, int64_t B, void* workspace,
+                                                    int64_t workspace_bytes, float in_scale, float out_alpha, float out_beta, int zero_low_bins) {
+    ALSEP_ENTER(ctx);
+#ifndef ALSEP_F16_TU
+    if (net && net->cfg.dtype == ALSEP_F16)
+        return alsep_net_forward_pcm_f16tu(ctx, net, plan, pcm, ch_stride, chunk_stride, spec_out, B, workspace, workspace_bytes, in_scale,
+                                           out_alpha, out_beta, zero_low_bins);
+#endif
+    if (!ctx || !net || !plan || !pcm || !spec_out || !workspace) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_forward_pcm: null argument");
+    if (net->cfg.dtype == ALSEP_F32) return ALSEP_ERR_STATE;
+    if (B == 0) return ALSEP_OK;
+    if (B < 0 || zero_low_bins < 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_forward_pcm: bad argument");
+    if (workspace_bytes < ALSEP_TU_NAME(alsep_net_workspace_bytes)(net, B))
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_forward_pcm: workspace too small");
+    if (((uintptr_t)workspace & 255) != 0) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_forward_pcm: workspace must be 256-byte aligned");
+    const PcmFront front{plan, pcm, ch_stride, chunk_stride, zero_low_bins};
+    return forward_impl<bf16_t>(ctx, net, (const bf16_t*)nullptr, (bf16_t*)spec_out, B, (char*)workspace, in_scale, out_alpha, out_beta, &front);
 }

@@ -255,8 +255,12 @@ class Predictor:
             limit = min(n_sample, s_lo + n_local) - w0 * gen
             if hasattr(self.model, "forward_nhwc"):
                 net = self.model
-                spek = plan.stft_strided(mix_p, total, gen, nb, net.dtype, _lib.LAYOUT_NHWC, pcm_offset=w0 * gen)
-                pred = net.forward_nhwc(spek, denoise=bool(self.args.denoise))
+                pred = None
+                if not self.args.denoise and hasattr(net, "forward_pcm"):     # STFT + first layer as one kernel (half-precision networks)
+                    pred = net.forward_pcm(plan, mix_p, total, gen, nb, pcm_offset=w0 * gen)
+                if pred is None:
+                    spek = plan.stft_strided(mix_p, total, gen, nb, net.dtype, _lib.LAYOUT_NHWC, pcm_offset=w0 * gen)
+                    pred = net.forward_nhwc(spek, denoise=bool(self.args.denoise))
                 plan.istft_strided(pred, _lib.LAYOUT_NHWC, seg_out, ld, gen, trim, plan.chunk_size - trim,
                                    limit, out_offset=w0 * gen - s_lo)
             else:
@@ -330,11 +334,15 @@ class OlaRunner:
         bstep = self.max_batch if self.max_batch > 0 else max(n_local, 1)
         for b0 in range(c_lo, c_hi, bstep):
             nb = min(bstep, c_hi - b0)
-            spek = plan.stft_strided(mixture, buf_len, step, nb, self.net.dtype, _lib.LAYOUT_NHWC, pcm_offset=(b0 - c_lo) * step)
-            if self.zero_low_bins:
-                ctx.check(ctx.lib.alsep_zero_low_bins(ctx.handle, _lib.ptr(spek), _lib.dtype_code(spek.dtype), _lib.LAYOUT_NHWC,
-                                                      nb, plan.dim_f, plan.dim_t, self.zero_low_bins), "alsep_zero_low_bins")
-            pred = spek if match_mix else self.net.forward_nhwc(spek, denoise=self.denoise)
+            pred = None
+            if not match_mix and not self.denoise and hasattr(self.net, "forward_pcm"):   # STFT + zeroed low bins + first layer as one kernel
+                pred = self.net.forward_pcm(plan, mixture, buf_len, step, nb, pcm_offset=(b0 - c_lo) * step, zero_low_bins=self.zero_low_bins)
+            if pred is None:
+                spek = plan.stft_strided(mixture, buf_len, step, nb, self.net.dtype, _lib.LAYOUT_NHWC, pcm_offset=(b0 - c_lo) * step)
+                if self.zero_low_bins:
+                    ctx.check(ctx.lib.alsep_zero_low_bins(ctx.handle, _lib.ptr(spek), _lib.dtype_code(spek.dtype), _lib.LAYOUT_NHWC,
+                                                          nb, plan.dim_f, plan.dim_t, self.zero_low_bins), "alsep_zero_low_bins")
+                pred = spek if match_mix else self.net.forward_nhwc(spek, denoise=self.denoise)
             plan.istft_strided(pred, _lib.LAYOUT_NHWC, waves, chunk, 2 * chunk, 0, chunk, (nb - 1) * 2 * chunk + chunk,
                                out_offset=(b0 - c_lo) * 2 * chunk)
         if not self.sharded:

@@ -204,6 +204,34 @@ class TDFNet:
                 self._forward(x, y)
         return out
 
+    def forward_pcm(self, plan, pcm: torch.Tensor, ch_stride: int, chunk_stride: int, n_chunks: int, pcm_offset: int = 0,
+                    zero_low_bins: int = 0) -> Optional[torch.Tensor]:
+        """STFT of ``n_chunks`` chunks framed out of the flat float32 buffer ``pcm`` (as StftPlan.stft_strided) + the network, with the STFT
+        and the network's first 1x1 convolution fused into one kernel (alsep_net_forward_pcm: no spectrogram in HBM; bit-identical to
+        stft_strided + forward_nhwc).  -> [n_chunks, dim_t, dim_f, 4] in the model dtype, or None when this (plan, network) pair has no
+        fused kernel (float32 networks, other n_fft / g): the caller then runs the two steps."""
+        if self.dtype == torch.float32 or pcm.dtype != torch.float32:
+            return None
+        cfg = self.cfg
+        if (plan.n_fft, plan.hop, plan.dim_f, plan.dim_t) != (cfg.n_fft, cfg.hop, cfg.dim_f, cfg.dim_t):
+            raise AlsepError("forward_pcm: the plan's geometry is not the network's")
+        need = ch_stride + (n_chunks - 1) * chunk_stride + plan.chunk_size + pcm_offset
+        if n_chunks > 0 and pcm.numel() < need:
+            raise AlsepError(f"pcm buffer too small: {pcm.numel()} < {need}")
+        out = self.ctx.empty((n_chunks, cfg.dim_t, cfg.dim_f, 4), self.dtype)
+        step = self.max_batch if self.max_batch > 0 else n_chunks
+        for b0 in range(0, n_chunks, step):
+            nb = min(step, n_chunks - b0)
+            ws = self.workspace(nb)
+            base = (ws.data_ptr() + 255) & ~255
+            rc = self.ctx.lib.alsep_net_forward_pcm(self.ctx.handle, self.handle, plan.handle,
+                                                    C.c_void_p(_lib.ptr(pcm) + 4 * (pcm_offset + b0 * chunk_stride)), ch_stride, chunk_stride,
+                                                    _lib.ptr(out[b0:b0 + nb]), nb, C.c_void_p(base), ws.numel() - 256, 1.0, 1.0, 0.0, int(zero_low_bins))
+            if rc == -4 and b0 == 0:                       # ALSEP_ERR_STATE: no fused kernel for this pair
+                return None
+            self.ctx.check(rc, "alsep_net_forward_pcm")
+        return out
+
     def run(self, _names, feed):
         """ORT-session surface (mdxnet.py:170-176, patch_separate.py:52): reference layout in/out."""
         from .mdx import StftPlan

@@ -634,6 +634,31 @@ def main() -> None:
                                   "algorithmic_bytes_per_launch": alg * nb}
 
     fft_stage_lines(preds[0].model_.plan, "")
+    # the front end as the step actually runs it: STFT + the network's first 1x1 convolution in ONE kernel (no spectrogram in HBM).
+    # Algorithmic bytes: the PCM read + the level-0 activation the network needs anyway (dim_t x dim_f x 48 channels).
+    if half:
+        plan0 = preds[0].model_.plan
+        p_gen = plan0.chunk_size - 2 * plan0.trim
+        nb = min(n_samples // p_gen + 1, args.batch)
+        pad_len = plan0.trim * 2 + nb * p_gen + plan0.chunk_size
+        buf = torch.zeros((2, pad_len), device=device)
+        buf[:, plan0.trim:plan0.trim + min(n_samples, pad_len - 2 * plan0.trim)] = mix[:, :min(n_samples, pad_len - 2 * plan0.trim)]
+        if nets[0].forward_pcm(plan0, buf, pad_len, p_gen, nb) is not None:
+            torch.cuda.synchronize()
+            reps = 5
+            ctx.profile_begin(_lib.PROF_STFT)
+            for _ in range(reps):
+                nets[0].forward_pcm(plan0, buf, pad_len, p_gen, nb)
+            ms, launches = ctx.profile_end()
+            alg = 2 * plan0.chunk_size * 4 + plan0.dim_f * plan0.dim_t * cfg.g * es
+            gbs = alg * nb * reps / (ms * 1e-3) / 1e9
+            stages["stft_first_conv"] = {"kernel": "stft_r16_kernel<FUSE> (STFT + first 1x1 conv + BN + ReLU)", "bound": "hbm", "achieved": round(gbs, 1),
+                                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "n_fft": plan0.n_fft,
+                                         "bytes_per_chunk": alg, "chunks_per_launch": nb, "us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
+                                         "us_per_chunk": round(ms * 1e3 / max(launches, 1) / nb, 3), "traffic": None,
+                                         "algorithmic_bytes_per_launch": alg * nb,
+                                         "note": "replaces stages.stft + first_conv_kernel in the timed step; bit-identical to them"}
+        del buf
     if cfg.n_fft != 7680:                                    # the geometry of the reference's own vocal models (Voc_FT, Kim_Vocal_*: n_fft 7680, dim_f 3072)
         from audiolab_amd.mdx import StftPlan
         fft_stage_lines(StftPlan(ctx, 7680, 1024, 3072, 256), "_7680")

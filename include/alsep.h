@@ -176,6 +176,13 @@ int64_t alsep_net_workspace_bytes(const alsep_net* net, int64_t B);
 int alsep_net_forward(alsep_ctx* ctx, const alsep_net* net, const void* spec_in, void* spec_out,
                       int64_t B, void* workspace, int64_t workspace_bytes, float in_scale,
                       float out_alpha, float out_beta);
+/* alsep_stft (channels-last, the network's storage type) + alsep_net_forward in one call for the half-precision networks: the STFT and
+ * the network's first 1x1 convolution run as ONE kernel (no spectrogram in HBM), bit-identical to the two calls.  pcm / ch_stride /
+ * chunk_stride as alsep_stft; zero_low_bins: bins below it enter the network as zeros (alsep_zero_low_bins of the overlap-add runner).
+ * Returns ALSEP_ERR_STATE when this (plan, network) pair has no fused kernel: call alsep_stft + alsep_net_forward then. */
+int alsep_net_forward_pcm(alsep_ctx* ctx, const alsep_net* net, const alsep_plan* plan, const float* pcm, int64_t ch_stride,
+                          int64_t chunk_stride, void* spec_out, int64_t B, void* workspace, int64_t workspace_bytes, float in_scale,
+                          float out_alpha, float out_beta, int zero_low_bins);
 
 /* Element-wise / reduction ops of the ensemble stage (stem_separator.py:241-262,173-239,
  * 415-456) and of the MDX runner (mdxnet.py:168-173 denoise average, :211 secondary stem). */

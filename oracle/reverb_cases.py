@@ -11,7 +11,7 @@ CASES = {
     "even_mono": (16000, 20000, 20000, 0, 160, 0.25, 2),        # 1-D arrays (mono files), 10 ms pre-delay
     "delay_stereo": (44100, 48000, 48000, 2, 1632, 0.30, 3),    # 37 ms pre-delay; the track is shorter than the 2 s impulse-response cap
     "ragged": (22050, 28000, 30000, 2, 50, 0.20, 4),            # wet longer than dry: the dry signal is zero-padded to the wet length
-    "long_stereo": (44100, 300001, 300001, 2, 441, 0.45, 5),    # impulse response cut at 2 s = 88 200 samples
+    "long_stereo": (44100, 120001, 120001, 2, 441, 0.2, 5),     # impulse response cut at 2 s = 88 200 samples
 }
 
 
