@@ -652,7 +652,8 @@ template <int N>
 static int launch_stft_first_conv(alsep_ctx* ctx, const alsep_plan* p, const float* pcm, int64_t ch_stride, int64_t chunk_stride, int64_t n_chunks,
                                   bf16_t* act, const r16::FirstConvArgs& fc) {
     typedef bf16_t OutT;
-    const size_t lds = r16::stft_lds_bytes<N / 256>() + r16::kFirstConvLdsFloats * sizeof(float);
+    const size_t lds = r16::stft_lds_bytes<N / 256>();                    // >= dim_f * 8 bytes of rounded bins (dim_f <= N / 2)
+    static_assert(sizeof(OutT) == 2, "stage geometry");
     ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)r16::stft_r16_kernel<N / 256, OutT, ALSEP_LAYOUT_NHWC, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope prof(ctx, ALSEP_PROF_STFT);
@@ -673,6 +674,7 @@ int ALSEP_TU_NAME(alsep_stft_first_conv)(alsep_ctx* ctx, const alsep_plan* plan,
                                          int zero_low) {
     if (!ctx || !plan || !pcm || !act || !w || !scale || !shift) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_stft_first_conv: null argument");
     if (g != r16::kFirstConvG || plan->dim_f > plan->n_fft / 2 || !stft_r16_enabled()) return ALSEP_ERR_STATE;
+    if (plan->n_fft != 4096 && plan->n_fft != 6144 && plan->n_fft != 7680) return ALSEP_ERR_STATE;
     if (n_chunks <= 0) return ALSEP_OK;
     const r16::FirstConvArgs fc{w, scale, shift, in_scale, zero_low};
     if (plan->n_fft == 4096) return launch_stft_first_conv<4096>(ctx, plan, pcm, ch_stride, chunk_stride, n_chunks, (bf16_t*)act, fc);

@@ -213,10 +213,15 @@ template <> __device__ __forceinline__ void store_bin<bf16_t>(bf16_t* spec, int6
 // Fused first layer (FUSE): the first 1x1 convolution of the TFC-TDF U-Net (4 spectrogram channels -> g = 48, folded BatchNorm, ReLU;
 // first_conv_kernel in tdfnet.hip) applied in the epilogue, so that the kernel writes the network's level-0 activation [B][T][F][48]
 // instead of the spectrogram: the spectrogram's HBM round trip (8 bytes per bin written, read back by first_conv_kernel) and that
-// kernel's launch disappear, and the FFT arithmetic hides under the 96-byte-per-bin store stream the network needs anyway.
+// kernel's launch disappear.
 // Bit-identical to stft + first_conv: the bin values are rounded to the storage type exactly where the spectrogram store rounded them,
-// and each output is the same chain w.x x0, fma(w.y, x1), fma(w.z, x2), fma(w.w, x3), fma(., scale in_scale, shift), max(., 0).
-// Weights arrive in LDS behind the frame buffer as [6 groups of 8 channels][4 channel pairs][10]: (wx wx' wy wy' wz wz' ww ww' | sc sc' sh sh').
+// each output is the same chain w.x x0, fma(w.y, x1), fma(w.z, x2), fma(w.w, x3), fma(., scale in_scale, shift), and the ReLU is taken on
+// the rounded value's 16-bit pattern (signed max with 0: rounding keeps the sign, and -0 becomes +0 as fmaxf(-0, 0) does).
+// Work split of the epilogue = first_conv_kernel's: once every thread holds its pass-C inputs the frame buffer is dead and receives the
+// frame's rounded bins ([dim_f] x 8 bytes); then thread tid < 126 owns ONE group of 8 output channels (tid % 6: its 32 weights, 8 scales
+// and 8 shifts stay in registers) and walks the bins 21 at a time (tid / 6 + 21 i), so that the workgroup's stores of one round are 126
+// consecutive 16-byte pieces of act.  (Two earlier forms -- every thread computing all 48 channels of its own bins, weights re-read per
+// bin pair from LDS or through scalar loads -- were bound by exactly those re-reads: 1.0-1.3 ms per launch of 52 chunks.)
 struct FirstConvArgs {
     const float* w;        // [48][4]
     const float* scale;    // [48]
@@ -225,11 +230,12 @@ struct FirstConvArgs {
     int zero_low;          // bins below this index enter the network as zeros (the overlap-add runner's zero_low_bins)
 };
 constexpr int kFirstConvG = 48;
-constexpr int kFirstConvLdsFloats = 6 * 4 * 12;              // 288 floats
+constexpr int kFirstConvGroups = kFirstConvG / 8;            // 16-byte pieces per bin
+constexpr int kFirstConvBinsPerRound = kThreads / kFirstConvGroups;   // 21 (threads 126, 127 idle in the epilogue)
 
 // grid (T, n_chunks), 128 threads.
 template <int R2, typename OutT, int LAYOUT, bool FUSE = false>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads) ALSEP_WAVES_PER_EU(2)
 stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_stride, int chunk, int hop, int dim_f,
                 int T, const float2* __restrict__ tw_, OutT* __restrict__ spec, FirstConvArgs fc) {
     constexpr int N = 256 * R2, NT = kThreads;
@@ -255,17 +261,6 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
     // first-order twiddles of passes B and C, fetched now: behind a barrier each would expose one memory latency
     const int ka = tid, kb = tid ? 256 - tid : 128;
     const v2f wB1 = tw[(tid & 15) * (N / 256)], wa1 = tw[ka], wb1 = tw[kb];
-    float* fcw = reinterpret_cast<float*>(alsep_smem + stft_lds_bytes<R2>());
-    if constexpr (FUSE) {
-        if (tid < kFirstConvG) {                             // channel tid -> group tid / 8, pair (tid % 8) / 2, half tid % 2
-            float* dst = fcw + ((tid >> 3) * 4 + ((tid & 7) >> 1)) * 12 + (tid & 1);
-            const float4 wv = *reinterpret_cast<const float4*>(fc.w + tid * 4);
-            dst[0] = wv.x; dst[2] = wv.y; dst[4] = wv.z; dst[6] = wv.w;
-            dst[8] = fc.scale[tid] * fc.in_scale;
-            dst[10] = fc.shift[tid];
-        }
-    }
-
     // ---- pass A: radix 16, P = 1.  Butterfly i takes x[i + M r] * w[i + M r]; writes row i (16 values).
     // Thread tid owns the NB consecutive butterflies i = NB tid + bb: its inputs for one r are NB consecutive samples
     // (one 8- / 12-byte load per channel; 32 loads in flight per thread instead of 96, all under the 63-deep vmcnt).
@@ -372,6 +367,7 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
         for (int r = 0; r < R2; ++r) za[r] = buf[ka + 256 * r];
 #pragma unroll
         for (int r = 0; r < R2; ++r) zb[r] = buf[kb + 256 * r];
+        if constexpr (FUSE) __syncthreads();                     // the frame buffer is reused for the rounded bins below
         {
             v2f w[R2];
             twiddle_powers<R2>(wa1, w);
@@ -404,9 +400,11 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
             }
         };
         if constexpr (FUSE) {
-            // (1) this thread's R2 bins, rounded to the storage type where the spectrogram store would round them: (L.x, L.y, R.x, R.y)
-            typedef OutT xin_t __attribute__((ext_vector_type(4)));
-            xin_t xv[R2];
+            typedef OutT x4_t __attribute__((ext_vector_type(4)));
+            typedef OutT out8_t __attribute__((ext_vector_type(8)));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            // (1) the frame's bins, rounded, into the dead frame buffer (the barrier after the za / zb loads made it free)
+            x4_t* xs = reinterpret_cast<x4_t*>(alsep_smem);
 #pragma unroll
             for (int q = 0; q < R2 / 2; ++q) {
                 const v2f a_q = za[LastDft<R2>::slot(q)], b_q = zb[LastDft<R2>::slot(q)];
@@ -414,44 +412,61 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
                 const v2f a_w = za[LastDft<R2>::slot((R2 - q) % R2)];
                 const v2f n1 = t0 ? a_w : b_m;
                 const v2f n2 = t0 ? b_m : a_m;
+                const int k1 = ka + 256 * q, k2 = kb + 256 * q;
                 const v2f l1 = cx_add_conj(a_q, n1), r1 = cx_sub_conj_divi(a_q, n1), l2 = cx_add_conj(b_q, n2), r2 = cx_sub_conj_divi(b_q, n2);
-                const bool z1 = ka + 256 * q < fc.zero_low, z2 = kb + 256 * q < fc.zero_low;
-                xv[2 * q][0] = (OutT)(z1 ? 0.f : l1.x); xv[2 * q][1] = (OutT)(z1 ? 0.f : l1.y);
-                xv[2 * q][2] = (OutT)(z1 ? 0.f : r1.x); xv[2 * q][3] = (OutT)(z1 ? 0.f : r1.y);
-                xv[2 * q + 1][0] = (OutT)(z2 ? 0.f : l2.x); xv[2 * q + 1][1] = (OutT)(z2 ? 0.f : l2.y);
-                xv[2 * q + 1][2] = (OutT)(z2 ? 0.f : r2.x); xv[2 * q + 1][3] = (OutT)(z2 ? 0.f : r2.y);
+                const bool z1 = k1 < fc.zero_low, z2 = k2 < fc.zero_low;
+                x4_t v1, v2;
+                v1[0] = (OutT)(z1 ? 0.f : l1.x); v1[1] = (OutT)(z1 ? 0.f : l1.y); v1[2] = (OutT)(z1 ? 0.f : r1.x); v1[3] = (OutT)(z1 ? 0.f : r1.y);
+                v2[0] = (OutT)(z2 ? 0.f : l2.x); v2[1] = (OutT)(z2 ? 0.f : l2.y); v2[2] = (OutT)(z2 ? 0.f : r2.x); v2[3] = (OutT)(z2 ? 0.f : r2.y);
+                if (k1 < dim_f) xs[k1] = v1;
+                if (k2 < dim_f) xs[k2] = v2;
             }
-            // (2) eight output channels at a time: their weights in registers, one 16-byte store per bin
-            typedef OutT out8_t __attribute__((ext_vector_type(8)));
-            OutT* act = spec + frame_off * kFirstConvG;
-#pragma unroll 1
-            for (int cg = 0; cg < kFirstConvG / 8; ++cg) {
-                v2f wx[4], wy[4], wz[4], ww[4], sc[4], sh[4];
+            // (2) this thread's channel group
+            const int cg = tid % kFirstConvGroups, bl = tid / kFirstConvGroups;
+            const bool active = bl < kFirstConvBinsPerRound;
+            v2f wx[4], wy[4], wz[4], ww[4], sc[4], sh[4];
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                const int c = 8 * cg + 2 * pr;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(fc.w + 4 * c), w1 = *reinterpret_cast<const f32x4*>(fc.w + 4 * c + 4);
+                wx[pr] = mk(w0[0], w1[0]); wy[pr] = mk(w0[1], w1[1]); wz[pr] = mk(w0[2], w1[2]); ww[pr] = mk(w0[3], w1[3]);
+                sc[pr] = mk(fc.scale[c] * fc.in_scale, fc.scale[c + 1] * fc.in_scale);
+                sh[pr] = mk(fc.shift[c], fc.shift[c + 1]);
+            }
+            __syncthreads();
+            // (3) rounds of 21 bins: piece index 126 i + tid of the frame's activation row, i.e. linear 16-byte stores
+            char* dst = reinterpret_cast<char*>(spec + frame_off * kFirstConvG) + 16 * tid;
+            const int rounds = (dim_f + kFirstConvBinsPerRound - 1) / kFirstConvBinsPerRound;
+            auto one = [&](x4_t x) {
+                const float x0 = (float)x[0], x1 = (float)x[1], x2 = (float)x[2], x3 = (float)x[3];
+                out8_t o;
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr) {
-                    const float* src = fcw + (cg * 4 + pr) * 12;
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
-                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + 8);
-                    wx[pr] = mk(v0[0], v0[1]); wy[pr] = mk(v0[2], v0[3]); wz[pr] = mk(v1[0], v1[1]); ww[pr] = mk(v1[2], v1[3]);
-                    sc[pr] = mk(v2[0], v2[1]); sh[pr] = mk(v2[2], v2[3]);
+                    v2f a = wx[pr] * x0;
+                    a = __builtin_elementwise_fma(wy[pr], mk(x1, x1), a);
+                    a = __builtin_elementwise_fma(wz[pr], mk(x2, x2), a);
+                    a = __builtin_elementwise_fma(ww[pr], mk(x3, x3), a);
+                    a = __builtin_elementwise_fma(a, sc[pr], sh[pr]);
+                    o[2 * pr] = (OutT)a.x;
+                    o[2 * pr + 1] = (OutT)a.y;
                 }
+                const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                return __builtin_elementwise_max(__builtin_bit_cast(s16x8, o), zero);
+            };
+            constexpr int U = 4;                                                     // rounds in flight
+            constexpr int kRoundBytes = kFirstConvBinsPerRound * kFirstConvG * (int)sizeof(OutT);
+            int i = 0;
+            if (active) {
+                for (; i + U <= rounds - 1; i += U) {                                // every bin of these rounds is below dim_f
+                    x4_t x[U];
 #pragma unroll
-                for (int i = 0; i < R2; ++i) {
-                    const int k = (i & 1 ? kb : ka) + 256 * (i >> 1);
-                    if (k >= dim_f) continue;
-                    const float x0 = (float)xv[i][0], x1 = (float)xv[i][1], x2 = (float)xv[i][2], x3 = (float)xv[i][3];
-                    out8_t o;
+                    for (int u = 0; u < U; ++u) x[u] = xs[bl + kFirstConvBinsPerRound * (i + u)];
 #pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) {
-                        v2f a = wx[pr] * x0;
-                        a = __builtin_elementwise_fma(wy[pr], mk(x1, x1), a);
-                        a = __builtin_elementwise_fma(wz[pr], mk(x2, x2), a);
-                        a = __builtin_elementwise_fma(ww[pr], mk(x3, x3), a);
-                        a = __builtin_elementwise_fma(a, sc[pr], sh[pr]);
-                        o[2 * pr] = (OutT)fmaxf(a.x, 0.f);
-                        o[2 * pr + 1] = (OutT)fmaxf(a.y, 0.f);
-                    }
-                    *reinterpret_cast<out8_t*>(act + (int64_t)k * kFirstConvG + 8 * cg) = o;
+                    for (int u = 0; u < U; ++u) *reinterpret_cast<s16x8*>(dst + (int64_t)kRoundBytes * (i + u)) = one(x[u]);
+                }
+                for (; i < rounds; ++i) {
+                    const int bin = bl + kFirstConvBinsPerRound * i;
+                    if (bin < dim_f) *reinterpret_cast<s16x8*>(dst + (int64_t)kRoundBytes * i) = one(xs[bin]);
                 }
             }
         } else {

@@ -33,10 +33,21 @@ _BANDS_4 = {
     3: dict(sr=14700, hl=160, n_fft=512, crop_start=17, crop_stop=216, hpf_start=48, hpf_stop=24, lpf_start=139, lpf_stop=210),
     4: dict(sr=44100, hl=480, n_fft=960, crop_start=78, crop_stop=383, hpf_start=130, hpf_stop=86),
 }
+# the "_sn" sets: the same bands with the top band's channels converted ("convert_channels": "stereo_n", modelparams/4band_v2_sn.json:48).
+# 4band_v3_sn (the BG-vocal model's set) is not in the reference tree: taken as 4band_v3 + the same line, as v2_sn is to v2 (inferred).
+_BANDS_4_SN = {**_BANDS_4, 4: dict(_BANDS_4[4], convert_channels="stereo_n")}
 MODEL_PARAMS: Dict[str, dict] = {
     "4band_v2": dict(bins=672, unstable_bins=8, reduction_bins=637, band=_BANDS_4, sr=44100, pre_filter_start=668, pre_filter_stop=672),
     "4band_v3": dict(bins=672, unstable_bins=8, reduction_bins=530, band=_BANDS_4, sr=44100, pre_filter_start=668, pre_filter_stop=672),
+    "4band_v2_sn": dict(bins=672, unstable_bins=8, reduction_bins=637, band=_BANDS_4_SN, sr=44100, pre_filter_start=668, pre_filter_stop=672),
+    "4band_v3_sn": dict(bins=672, unstable_bins=8, reduction_bins=530, band=_BANDS_4_SN, sr=44100, pre_filter_start=668, pre_filter_stop=672),
 }
+# "stereo_n": L' = (L + R / 4) / 0.9375, R' = (R + L / 4) / 0.9375 on the band's spectrogram; undone on the band's wave after the iSTFT by
+# L = L' - R' / 4, R = R' - L' / 4.  The reference tree's spec_utils has no such branch (its wave_to_spectrogram :30-56 knows mid_side,
+# mid_side_b2, reverse); the rule is the one of the engine the reference calls for this model (audio-separator's VR spec_utils
+# ``convert_channels`` / ``spectrogram_to_wave``: upstream, uncited, restated from memory -- parity for "_sn" sets is unpinned).
+_STEREO_N = 0.25
+_STEREO_N_NORM = 1.0 - _STEREO_N * _STEREO_N
 
 
 def _lp_gain(g: torch.Tensor, start: int, stop: int) -> None:
@@ -97,6 +108,9 @@ class VRFrontEnd:
             self._band_gain[d] = bg.float().to(dev)
         if off > self.bins:
             raise AlsepError("VRFrontEnd: the bands' crops exceed the stacked height")
+        for d, bp in mp["band"].items():
+            if bp.get("convert_channels") not in (None, "stereo_n"):
+                raise AlsepError(f"VRFrontEnd: band {d} of {params} asks for channel conversion {bp['convert_channels']!r}; only 'stereo_n' is built")
         self._plans: Dict[Tuple[int, int, int], StftPlan] = {}
 
     def _plan(self, n_fft: int, hop: int, dim_t: int) -> StftPlan:
@@ -125,6 +139,14 @@ class VRFrontEnd:
         spec = plan.stft_strided(buf, plan.chunk_size, 2 * plan.chunk_size, 1, torch.float32, _lib.LAYOUT_REF)
         return spec[0], off // hop, n_frames
 
+    def _cross_mix(self, pair: torch.Tensor, self_gain: float, other_gain: float) -> None:
+        """in place on a contiguous [2, ...] float32 pair: (a, b) <- (self_gain a + other_gain b, self_gain b + other_gain a)"""
+        ctx = self.ctx
+        a, b = pair[0], pair[1]
+        a0 = a.clone()
+        ctx.check(ctx.lib.alsep_axpby(ctx.handle, other_gain, _lib.ptr(b), self_gain, _lib.ptr(a), a.numel()), "alsep_axpby")
+        ctx.check(ctx.lib.alsep_axpby(ctx.handle, other_gain, _lib.ptr(a0), self_gain, _lib.ptr(b), b.numel()), "alsep_axpby")
+
     def analyse(self, wave: torch.Tensor):
         """vr.py:55-99: [2, n] at the set's rate -> (X [2, bins + 1, l] complex64, high end [2, hh, l] complex64)"""
         ctx, mp = self.ctx, self.mp
@@ -138,6 +160,9 @@ class VRFrontEnd:
             if d < self.bands_n:
                 x = self._resample(x, mp["band"][d + 1]["sr"], bp["sr"])
             specs[d] = self._band_stft(x, bp["n_fft"], bp["hl"])
+            if bp.get("convert_channels") == "stereo_n":                            # planes (L re, L im, R re, R im): a [2, 2 Fb Ty] pair
+                band = specs[d][0]
+                self._cross_mix(band.view(2, -1), 1.0 / _STEREO_N_NORM, _STEREO_N / _STEREO_N_NORM)
         l = min(s[2] for s in specs.values())
         X = torch.zeros(2, self.bins, l, 2, dtype=torch.float32, device=ctx.device)
         off = 0
@@ -196,6 +221,8 @@ class VRFrontEnd:
             plan = self._plan(bp["n_fft"], bp["hl"], l)
             w = ctx.empty((2, plan.chunk_size), torch.float32)                      # [2, hl * (l - 1)]
             plan.istft_strided(band, _lib.LAYOUT_REF, w, plan.chunk_size, 2 * plan.chunk_size, 0, plan.chunk_size, plan.chunk_size)
+            if bp.get("convert_channels") == "stereo_n":
+                self._cross_mix(w, 1.0, -_STEREO_N)
             if wave is not None:
                 if wave.shape[1] != w.shape[1]:
                     raise AlsepError(f"VRFrontEnd.synthesise: band {d} is {w.shape[1]} samples, the chain below it {wave.shape[1]}")

@@ -28,9 +28,16 @@ _BANDS_4 = {
     3: dict(sr=14700, hl=160, n_fft=512, crop_start=17, crop_stop=216, hpf_start=48, hpf_stop=24, lpf_start=139, lpf_stop=210),
     4: dict(sr=44100, hl=480, n_fft=960, crop_start=78, crop_stop=383, hpf_start=130, hpf_stop=86),
 }
+# "_sn": modelparams/4band_v2_sn.json differs from 4band_v2.json by ``"convert_channels": "stereo_n"`` on band 4 (:48); 4band_v3_sn (the
+# set of UVR-BVE-4B_SN-44100-1.pth, stem_separator.py:752) is not in the reference tree and is taken as 4band_v3 + the same line.  The
+# conversion itself is not in the tree's spec_utils either: it is the rule of audio-separator's VR spec_utils (``convert_channels``,
+# ``spectrogram_to_wave``), restated from memory -- upstream, uncited; PARITY UNPINNED for the "_sn" sets (no vector of the reference).
+_BANDS_4_SN = {**_BANDS_4, 4: dict(_BANDS_4[4], convert_channels="stereo_n")}
 MODEL_PARAMS = {
     "4band_v2": dict(bins=672, unstable_bins=8, reduction_bins=637, band=_BANDS_4, sr=44100, pre_filter_start=668, pre_filter_stop=672),
     "4band_v3": dict(bins=672, unstable_bins=8, reduction_bins=530, band=_BANDS_4, sr=44100, pre_filter_start=668, pre_filter_stop=672),
+    "4band_v2_sn": dict(bins=672, unstable_bins=8, reduction_bins=637, band=_BANDS_4_SN, sr=44100, pre_filter_start=668, pre_filter_stop=672),
+    "4band_v3_sn": dict(bins=672, unstable_bins=8, reduction_bins=530, band=_BANDS_4_SN, sr=44100, pre_filter_start=668, pre_filter_stop=672),
 }
 
 
@@ -64,9 +71,15 @@ def resample(x: np.ndarray, sr_in: int, sr_out: int) -> np.ndarray:
     return x if sr_in == sr_out else _resample(np.atleast_2d(x), sr_in, sr_out).reshape(x.shape[:-1] + (-1,))
 
 
-def wave_to_spectrogram(wave: np.ndarray, hop: int, n_fft: int) -> np.ndarray:
-    """spec_utils.py:30-56 (no mid-side / reverse: both False in the 4-band parameter sets): [2, n] -> complex [2, bins, frames]"""
-    return np.stack([stft(wave[0], n_fft, hop), stft(wave[1], n_fft, hop)])
+def wave_to_spectrogram(wave: np.ndarray, hop: int, n_fft: int, convert_channels=None) -> np.ndarray:
+    """spec_utils.py:30-56 (no mid-side / reverse: both False in the 4-band parameter sets): [2, n] -> complex [2, bins, frames];
+    ``convert_channels="stereo_n"``: upstream's L' = (L + R / 4) / 0.9375, R' = (R + L / 4) / 0.9375 (see MODEL_PARAMS)"""
+    spec = np.stack([stft(wave[0], n_fft, hop), stft(wave[1], n_fft, hop)])
+    if convert_channels == "stereo_n":
+        spec = np.stack([(spec[0] + spec[1] * 0.25) / 0.9375, (spec[1] + spec[0] * 0.25) / 0.9375])
+    elif convert_channels is not None:
+        raise ValueError(f"convert_channels {convert_channels!r}")
+    return spec
 
 
 def fft_lp_filter(spec, bin_start, bin_stop):
@@ -128,7 +141,11 @@ def cmb_spectrogram_to_wave(spec_m: np.ndarray, mp: dict, extra_bins_h=None, ext
         h = bp["crop_stop"] - bp["crop_start"]
         spec_s[:, bp["crop_start"]: bp["crop_stop"], :] = spec_m[:, offset: offset + h, :]
         offset += h
-        to_wave = lambda s: np.stack([istft(s[0], bp["hl"]), istft(s[1], bp["hl"])])
+        def to_wave(s, bp=bp):
+            w = np.stack([istft(s[0], bp["hl"]), istft(s[1], bp["hl"])])
+            if bp.get("convert_channels") == "stereo_n":                                  # upstream spectrogram_to_wave: undone on the wave
+                w = np.stack([w[0] - w[1] * 0.25, w[1] - w[0] * 0.25])
+            return w
         if d == bands_n:
             if extra_bins_h:
                 max_bin = bp["n_fft"] // 2
@@ -155,7 +172,7 @@ def front_end(wave: np.ndarray, mp: dict) -> Tuple[np.ndarray, np.ndarray, int]:
     for d in range(bands_n, 0, -1):
         bp = mp["band"][d]
         X_wave[d] = wave if d == bands_n else resample(X_wave[d + 1], mp["band"][d + 1]["sr"], bp["sr"])
-        X_spec_s[d] = wave_to_spectrogram(X_wave[d], bp["hl"], bp["n_fft"])
+        X_spec_s[d] = wave_to_spectrogram(X_wave[d], bp["hl"], bp["n_fft"], bp.get("convert_channels"))
         if d == bands_n:
             hh = (bp["n_fft"] // 2 - bp["crop_stop"]) + (mp["pre_filter_stop"] - mp["pre_filter_start"])
             high_end = X_spec_s[d][:, bp["n_fft"] // 2 - hh: bp["n_fft"] // 2, :]

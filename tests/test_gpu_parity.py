@@ -291,12 +291,13 @@ def test_full_size_mdx_bf16_vs_oracle(ctx):
     args = types.SimpleNamespace(margin=44100, chunks=0, denoise=False, dim_f=cfg.dim_f, dim_t=8, n_fft=cfg.n_fft)
     ctx.launch_counts_reset()
     got = Predictor(args, net, ctx=ctx).demix(torch.from_numpy(c["mix"]).cuda()).cpu().numpy()
-    counts = {k: ctx.launch_count(k) for k in ("stft_r16_kernel", "istft_r16_kernel", "conv3x3_bf16_m0_kernel",
+    counts = {k: ctx.launch_count(k) for k in ("stft_first_conv_kernel", "first_conv_kernel", "istft_r16_kernel", "conv3x3_bf16_m0_kernel",
                                                "conv3x3_bf16_mq_kernel", "conv3x3_bf16_big_kernel<3>", "conv3x3_bf16_kernel<64>",
                                                "tdf_bf16_wide_kernel<nores>", "tdf_bf16_wide_kernel<res>", "tdf_bf16_kernel",
                                                "ds_stream_kernel", "us_stream_kernel", "pix_gemm_kernel")}
     print("launches:", counts)
-    assert counts["stft_r16_kernel"] == 1 and counts["istft_r16_kernel"] == 1
+    # the front end is the fused STFT + first-layer kernel (bit-identical to stft_r16_kernel + first_conv_kernel: tests/test_fused_front.py)
+    assert counts["stft_first_conv_kernel"] == 1 and counts["first_conv_kernel"] == 0 and counts["istft_r16_kernel"] == 1
     assert counts["conv3x3_bf16_m0_kernel"] == 6 and counts["conv3x3_bf16_mq_kernel"] == 6      # levels 0 / 1: 2 blocks x 3
     assert counts["conv3x3_bf16_big_kernel<3>"] == 6 and counts["conv3x3_bf16_kernel<64>"] >= 6       # level 2; levels 3, 4
     assert counts["tdf_bf16_wide_kernel<nores>"] == 4 and counts["tdf_bf16_wide_kernel<res>"] == 4     # levels 0-1, both linears
