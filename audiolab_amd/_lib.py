@@ -69,6 +69,11 @@ _SIGNATURES = {
     "alsep_ola_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int64]),
     "alsep_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_float]),
+    "alsep_resample_poly": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_int]),
+    "alsep_resample_fft_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
+    "alsep_resample_fft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                     C.c_int64]),
     "alsep_zero_low_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int]),
     "alsep_net_create": (C.c_int, [C.c_void_p, C.POINTER(NetConfig), C.POINTER(TensorEntry), C.c_int64,
                                    C.POINTER(C.c_void_p)]),

@@ -430,6 +430,41 @@ extern "C" int alsep_resample(alsep_ctx* ctx, const float* x, float* y, int64_t 
     return ALSEP_OK;
 }
 
+// scipy.signal.resample_poly with its default window, i.e. what librosa.resample(res_type="polyphase") runs (the VR band chain going
+// down, vr.py:74-79 with the parameter sets' "res_type": "polyphase"): upfirdn(h, x, up, down) with h padded in front by n_pre_pad
+// zeros, entries [n_pre_remove, n_pre_remove + n_out) kept.  One thread per output sample:
+//   y[j] = sum_n x[n] h[(j + n_pre_remove) down - n up - n_pre_pad]      over the n whose tap index lies inside h
+// float32 accumulation as scipy's upfirdn on float32 data.
+__global__ void __launch_bounds__(kThreads)
+resample_poly_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int64_t n_in, int64_t n_out, int up, int down,
+                     const float* __restrict__ h, int n_taps, int n_pre_pad, int n_pre_remove) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= rows * n_out) return;
+    const int64_t r = i / n_out, j = i - r * n_out;
+    const int64_t top = (j + n_pre_remove) * (int64_t)down - n_pre_pad;     // tap index of x[0]
+    // tap = top - n up in [0, n_taps)  <=>  n in [ceil((top - n_taps + 1) / up), floor(top / up)]
+    int64_t n_hi = top >= 0 ? top / up : -1;
+    const int64_t lo_num = top - n_taps + 1;
+    int64_t n_lo = lo_num > 0 ? (lo_num + up - 1) / up : 0;
+    if (n_hi > n_in - 1) n_hi = n_in - 1;
+    const float* xr = x + r * n_in;
+    float acc = 0.f;
+    for (int64_t n = n_lo; n <= n_hi; ++n) acc = fmaf(xr[n], h[top - n * up], acc);
+    y[i] = acc;
+}
+
+extern "C" int alsep_resample_poly(alsep_ctx* ctx, const float* x, float* y, int64_t rows, int64_t n_in, int64_t n_out, int up, int down,
+                                   const float* taps, int n_taps, int n_pre_pad, int n_pre_remove) {
+    ALSEP_ENTER(ctx);
+    if (!ctx || !x || !y || !taps || rows <= 0 || n_in <= 0 || n_out <= 0 || up < 1 || down < 1 || n_taps < 1 || n_pre_pad < 0 ||
+        n_pre_remove < 0)
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_resample_poly: bad argument");
+    hipLaunchKernelGGL(resample_poly_kernel, dim3(grid_for(rows * n_out, 1)), dim3(kThreads), 0, ctx->stream, x, y, rows, n_in, n_out, up,
+                       down, taps, n_taps, n_pre_pad, n_pre_remove);
+    ALSEP_LAUNCH_CHECK(ctx, "resample_poly_kernel");
+    return ALSEP_OK;
+}
+
 extern "C" int alsep_zero_low_bins(alsep_ctx* ctx, void* spec, int dtype, int layout, int64_t B, int64_t dim_f, int64_t T,
                                    int nbins) {
     ALSEP_ENTER(ctx);

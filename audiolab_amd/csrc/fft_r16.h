@@ -437,9 +437,11 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
             // (3) rounds of 21 bins: piece index 126 i + tid of the frame's activation row, i.e. linear 16-byte stores
             char* dst = reinterpret_cast<char*>(spec + frame_off * kFirstConvG) + 16 * tid;
             const int rounds = (dim_f + kFirstConvBinsPerRound - 1) / kFirstConvBinsPerRound;
+            typedef OutT o2_t __attribute__((ext_vector_type(2)));
+            typedef short s16x2 __attribute__((ext_vector_type(2)));
             auto one = [&](x4_t x) {
                 const float x0 = (float)x[0], x1 = (float)x[1], x2 = (float)x[2], x3 = (float)x[3];
-                out8_t o;
+                s16x8 o;
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr) {
                     v2f a = wx[pr] * x0;
@@ -447,11 +449,12 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
                     a = __builtin_elementwise_fma(wz[pr], mk(x2, x2), a);
                     a = __builtin_elementwise_fma(ww[pr], mk(x3, x3), a);
                     a = __builtin_elementwise_fma(a, sc[pr], sh[pr]);
-                    o[2 * pr] = (OutT)a.x;
-                    o[2 * pr + 1] = (OutT)a.y;
+                    const s16x2 h = __builtin_bit_cast(s16x2, __builtin_convertvector(a, o2_t));    // one packed convert per pair
+                    o[2 * pr] = h[0];
+                    o[2 * pr + 1] = h[1];
                 }
                 const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-                return __builtin_elementwise_max(__builtin_bit_cast(s16x8, o), zero);
+                return __builtin_elementwise_max(o, zero);
             };
             constexpr int U = 4;                                                     // rounds in flight
             constexpr int kRoundBytes = kFirstConvBinsPerRound * kFirstConvG * (int)sizeof(OutT);

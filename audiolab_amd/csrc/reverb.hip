@@ -306,6 +306,45 @@ int dft_impl(alsep_ctx* ctx, const cplx* in, cplx* out, int64_t n, double sign, 
     return ALSEP_OK;
 }
 
+// ---- scipy.signal.resample (Fourier method), what librosa.resample(res_type="scipy") runs: the VR band chain going up (spec_utils.py
+// :427).  Two real rows travel as one complex signal (the operator is real and linear, so the complex-input branch of the scipy routine
+// applied to L + i R resamples both).
+__global__ void __launch_bounds__(kRvThreads)
+pack_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, cplx* __restrict__ z, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kRvThreads + threadIdx.x;
+    if (i < n) z[i] = cplx{(double)a[i], b ? (double)b[i] : 0.0};
+}
+
+// Y (length num) from X (length nx), the spectrum copy of scipy.signal.resample's complex branch: N = min(num, nx), the N/2 + 1 lowest
+// non-negative frequencies, the N - (N/2 + 1) negative ones at the end, and the Nyquist rule for even N (upsampling: halved and mirrored
+// to -N/2; downsampling: X[-N/2] added to the bin at -N/2).
+__global__ void __launch_bounds__(kRvThreads)
+resample_spectrum_kernel(const cplx* __restrict__ X, cplx* __restrict__ Y, int64_t nx, int64_t num) {
+    const int64_t k = (int64_t)blockIdx.x * kRvThreads + threadIdx.x;
+    if (k >= num) return;
+    const int64_t N = num < nx ? num : nx, nyq = N / 2 + 1, neg = N - nyq;   // Y[num - neg ..] = X[nx - neg ..]
+    cplx v{0.0, 0.0};
+    if (k < nyq) v = X[k];
+    else if (N > 2 && k >= num - neg) v = X[nx - (num - k)];
+    if (N % 2 == 0) {
+        if (num < nx) {                                                      // index -N/2 of Y is num - N/2 = N/2 here (num == N)
+            if (k == num - N / 2) { const cplx e = X[nx - N / 2]; v.x += e.x; v.y += e.y; }
+        } else if (nx < num) {
+            if (k == N / 2) { v.x *= 0.5; v.y *= 0.5; }
+            if (k == num - N / 2) { v = X[N / 2]; v.x *= 0.5; v.y *= 0.5; }
+        }
+    }
+    Y[k] = v;
+}
+
+__global__ void __launch_bounds__(kRvThreads)
+unpack_rows_kernel(const cplx* __restrict__ z, float* __restrict__ a, float* __restrict__ b, int64_t n, double scale) {
+    const int64_t i = (int64_t)blockIdx.x * kRvThreads + threadIdx.x;
+    if (i >= n) return;
+    a[i] = (float)(z[i].x * scale);
+    if (b) b[i] = (float)(z[i].y * scale);
+}
+
 int64_t dft_ws_points(int64_t n) {
     const int l2 = log2_ceil(n);
     if (((int64_t)1 << l2) == n) return n;
@@ -434,6 +473,45 @@ extern "C" int alsep_rfft_mag_f64(alsep_ctx* ctx, const double* x, int64_t n, vo
     if (int rc = dft_impl(ctx, z, s, n, -1.0, s + n)) return rc;
     hipLaunchKernelGGL(magnitude_kernel, dim3(rv_grid(n / 2 + 1)), dim3(kRvThreads), 0, ctx->stream, s, mag_out, n / 2 + 1);
     ALSEP_LAUNCH_CHECK(ctx, "rfft_mag_kernel");
+    return ALSEP_OK;
+}
+
+static int64_t resample_fft_points(int64_t n_in, int64_t n_out) {
+    const int64_t a = dft_ws_points(n_in), b = dft_ws_points(n_out);
+    return 2 * n_in + 2 * n_out + (a > b ? a : b);
+}
+
+extern "C" int64_t alsep_resample_fft_workspace_bytes(int64_t n_in, int64_t n_out) {
+    if (n_in <= 0 || n_out <= 0 || n_in > kMaxPoints || n_out > kMaxPoints) return -1;
+    return resample_fft_points(n_in, n_out) * (int64_t)sizeof(cplx);
+}
+
+// x [rows, n_in] (row stride ldx) -> y [rows, n_out] (row stride ldy), float32; rows in pairs through one complex transform each
+extern "C" int alsep_resample_fft(alsep_ctx* ctx, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t n_in, int64_t n_out,
+                                  void* ws, int64_t ws_bytes) {
+    ALSEP_ENTER(ctx);
+    if (!ctx || !x || !y || !ws || rows <= 0 || n_in <= 0 || n_out <= 0 || n_in > kMaxPoints || n_out > kMaxPoints || ldx < n_in || ldy < n_out)
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_resample_fft: bad argument");
+    if (ws_bytes < resample_fft_points(n_in, n_out) * (int64_t)sizeof(cplx)) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_resample_fft: workspace too small");
+    cplx* z = (cplx*)ws;                 // n_in: packed input
+    cplx* X = z + n_in;                  // n_in: its spectrum
+    cplx* Y = X + n_in;                  // n_out: resampled spectrum
+    cplx* o = Y + n_out;                 // n_out: inverse transform
+    cplx* dws = o + n_out;
+    for (int64_t r = 0; r < rows; r += 2) {
+        const float* a = x + r * ldx;
+        const float* b = r + 1 < rows ? x + (r + 1) * ldx : nullptr;
+        hipLaunchKernelGGL(pack_rows_kernel, dim3(rv_grid(n_in)), dim3(kRvThreads), 0, ctx->stream, a, b, z, n_in);
+        ALSEP_LAUNCH_CHECK(ctx, "pack_rows_kernel");
+        if (int rc = dft_impl(ctx, z, X, n_in, -1.0, dws)) return rc;
+        hipLaunchKernelGGL(resample_spectrum_kernel, dim3(rv_grid(n_out)), dim3(kRvThreads), 0, ctx->stream, X, Y, n_in, n_out);
+        ALSEP_LAUNCH_CHECK(ctx, "resample_spectrum_kernel");
+        if (int rc = dft_impl(ctx, Y, o, n_out, +1.0, dws)) return rc;
+        // ifft (1 / n_out) times n_out / n_in
+        hipLaunchKernelGGL(unpack_rows_kernel, dim3(rv_grid(n_out)), dim3(kRvThreads), 0, ctx->stream, o, y + r * ldy,
+                           r + 1 < rows ? y + (r + 1) * ldy : nullptr, n_out, 1.0 / (double)n_in);
+        ALSEP_LAUNCH_CHECK(ctx, "unpack_rows_kernel");
+    }
     return ALSEP_OK;
 }
 

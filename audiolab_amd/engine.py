@@ -92,9 +92,11 @@ MODEL_ROSTER: Dict[str, tuple] = {
     # VR-architecture models: woodwinds split (stem_separator.py:596), noise removal (:148, wrappers/separate.py:114-117), the standalone
     # de-echo / de-reverb list (:1048-1050).  (architecture, parameter set, nout, nout_lstm) and which stem the network predicts are the
     # values published with the models (upstream, uncited); labels as the orchestrator matches them ("(woodwinds)" :615, "No Noise" :800).
-    # Not here: UVR-BVE-4B_SN-44100-1.pth (:752) -- its parameter set asks for the "stereo_n" channel conversion (modelparams/
-    # 4band_v2_sn.json:48), which the reference tree's own spec_utils does not implement either; the BG-vocal stage stays skipped.
+    # UVR-BVE-4B_SN-44100-1.pth (:752, the BG-vocal split): its parameter set converts the top band's channels ("stereo_n", as modelparams/
+    # 4band_v2_sn.json:48 does for the v2 bands); the set itself (4band_v3_sn) and the conversion rule are upstream's, not in the reference
+    # tree (vr_frontend.MODEL_PARAMS note) -- this entry is unpinned.  Labels as :763-766 matches them: "(Vocals)" = background.
     "17_HP-Wind_Inst-UVR.pth": ("vr", dict(arch="nets_123821KB", params="4band_v2"), {"labels": ("No Woodwinds", "Woodwinds")}),
+    "UVR-BVE-4B_SN-44100-1.pth": ("vr", dict(arch="new", params="4band_v3_sn", nout=64, nout_lstm=128), {"labels": ("Vocals", "Instrumental")}),
     "UVR-DeNoise.pth": ("vr", dict(arch="new", params="4band_v3", nout=48, nout_lstm=128), {"labels": ("Noise", "No Noise")}),
     "UVR-DeNoise-Lite.pth": ("vr", dict(arch="new", params="4band_v3", nout=16, nout_lstm=128), {"labels": ("Noise", "No Noise")}),
     "UVR-DeEcho-DeReverb.pth": ("vr", dict(arch="new", params="4band_v3", nout=64, nout_lstm=128), {"labels": ("No Reverb", "Reverb")}),

@@ -9,6 +9,7 @@ values) cross to the host to take the reference's branches.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -160,6 +161,63 @@ def resample(ctx: Context, x: torch.Tensor, sr_in: int, sr_out: int, zeros: int 
     y = ctx.empty((rows, n_out))
     ctx.check(ctx.lib.alsep_resample(ctx.handle, _lib.ptr(x), _lib.ptr(y), rows, n_in, n_out, sr_in, sr_out, zeros, rolloff, beta),
               "alsep_resample")
+    return y
+
+
+_POLY_TAPS: dict = {}
+
+
+def _poly_filter(up: int, down: int) -> torch.Tensor:
+    """scipy.signal.resample_poly's default filter: firwin(2 half_len + 1, 1 / max_rate, window=("kaiser", 5.0)) with half_len =
+    10 max_rate -- cutoff sinc(cutoff m) under a symmetric Kaiser window, scaled to unit gain at DC -- cast to float32 (the data's type)
+    and multiplied by ``up`` there.  Built in float64 on the host."""
+    key = (up, down)
+    if key not in _POLY_TAPS:
+        max_rate = max(up, down)
+        half_len = 10 * max_rate
+        m = torch.arange(-half_len, half_len + 1, dtype=torch.float64)
+        cutoff = 1.0 / max_rate
+        h = cutoff * torch.special.sinc(cutoff * m)
+        h = h * torch.kaiser_window(2 * half_len + 1, periodic=False, beta=5.0, dtype=torch.float64)
+        h = h / h.sum()
+        _POLY_TAPS[key] = (h.to(torch.float32) * float(up)), half_len
+    return _POLY_TAPS[key]
+
+
+def resample_poly(ctx: Context, x: torch.Tensor, sr_in: int, sr_out: int) -> torch.Tensor:
+    """librosa.resample(res_type="polyphase") = scipy.signal.resample_poly(x, sr_out // g, sr_in // g) on the device
+    (``alsep_resample_poly``): [C, N] -> [C, ceil(N up / down)]."""
+    if sr_in == sr_out:
+        return x
+    g = math.gcd(int(sr_in), int(sr_out))
+    up, down = int(sr_out) // g, int(sr_in) // g
+    taps, half_len = _poly_filter(up, down)
+    x = _flat(x)
+    rows, n_in = x.shape
+    n_out = -(-n_in * up // down)
+    n_pre_pad = down - half_len % down
+    n_pre_remove = (half_len + n_pre_pad) // down
+    y = ctx.empty((rows, n_out))
+    t = taps.to(ctx.device)
+    ctx.check(ctx.lib.alsep_resample_poly(ctx.handle, _lib.ptr(x), _lib.ptr(y), rows, n_in, n_out, up, down, _lib.ptr(t), t.numel(),
+                                          n_pre_pad, n_pre_remove), "alsep_resample_poly")
+    return y
+
+
+def resample_fft(ctx: Context, x: torch.Tensor, sr_in: int, sr_out: int) -> torch.Tensor:
+    """librosa.resample(res_type="scipy") = scipy.signal.resample(x, ceil(N sr_out / sr_in)) on the device (``alsep_resample_fft``)."""
+    if sr_in == sr_out:
+        return x
+    x = _flat(x)
+    rows, n_in = x.shape
+    n_out = -(-n_in * int(sr_out) // int(sr_in))
+    nbytes = ctx.lib.alsep_resample_fft_workspace_bytes(n_in, n_out)
+    if nbytes < 0:
+        raise AlsepError(f"resample_fft: {n_in} -> {n_out} samples is beyond the transform limit (2^27 points)")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=ctx.device)
+    y = ctx.empty((rows, n_out))
+    ctx.check(ctx.lib.alsep_resample_fft(ctx.handle, _lib.ptr(x), n_in, _lib.ptr(y), n_out, rows, n_in, n_out, _lib.ptr(ws), nbytes),
+              "alsep_resample_fft")
     return y
 
 

@@ -10,8 +10,9 @@ its helpers modules/rvc/infer/lib/uvr5_pack/lib_v5/spec_utils.py (``wave_to_spec
   -> per output: mirrored high end, per band: crop back, low-pass / high-pass ramps, iSTFT, add, resample up the chain.
 
 Everything between the input wave and the two output waves stays in HBM; the STFT / iSTFT are the library's FFT kernels (plans 320, 512,
-640, 960), the resampler is ``alsep_resample`` (the reference asks librosa for four different resamplers; this build has one Kaiser-
-windowed sinc -- DESIGN section 6).  The librosa zero-padded framing is obtained from ``alsep_stft`` (which reflect-pads its chunk) by
+640, 960); the band chain's resamplers are the two scipy routines librosa runs for the kinds the reference asks for ("polyphase" going
+down, "scipy" going up: ``alsep_resample_poly`` / ``alsep_resample_fft``; the other two kinds in the reference's text, "sinc_fastest"
+and the top band's "kaiser_fast", only ever see equal rates in the 4-band sets -- DESIGN section 6).  The librosa zero-padded framing is obtained from ``alsep_stft`` (which reflect-pads its chunk) by
 placing the wave at an offset inside a zero buffer and reading the frames whose windows stay inside the zeros.
 """
 from __future__ import annotations
@@ -28,10 +29,11 @@ from .vrnet import VRNet, vr_inference
 
 # lib_v5/modelparams/4band_v2.json, 4band_v3.json (hyper-parameters of the published models; both False: mid_side, reverse)
 _BANDS_4 = {
-    1: dict(sr=7350, hl=80, n_fft=640, crop_start=0, crop_stop=85, lpf_start=25, lpf_stop=53),
-    2: dict(sr=7350, hl=80, n_fft=320, crop_start=4, crop_stop=87, hpf_start=25, hpf_stop=12, lpf_start=31, lpf_stop=62),
-    3: dict(sr=14700, hl=160, n_fft=512, crop_start=17, crop_stop=216, hpf_start=48, hpf_stop=24, lpf_start=139, lpf_stop=210),
-    4: dict(sr=44100, hl=480, n_fft=960, crop_start=78, crop_stop=383, hpf_start=130, hpf_stop=86),
+    1: dict(sr=7350, hl=80, n_fft=640, crop_start=0, crop_stop=85, lpf_start=25, lpf_stop=53, res_type="polyphase"),
+    2: dict(sr=7350, hl=80, n_fft=320, crop_start=4, crop_stop=87, hpf_start=25, hpf_stop=12, lpf_start=31, lpf_stop=62, res_type="polyphase"),
+    3: dict(sr=14700, hl=160, n_fft=512, crop_start=17, crop_stop=216, hpf_start=48, hpf_stop=24, lpf_start=139, lpf_stop=210,
+            res_type="polyphase"),
+    4: dict(sr=44100, hl=480, n_fft=960, crop_start=78, crop_stop=383, hpf_start=130, hpf_stop=86, res_type="kaiser_fast"),
 }
 # the "_sn" sets: the same bands with the top band's channels converted ("convert_channels": "stereo_n", modelparams/4band_v2_sn.json:48).
 # 4band_v3_sn (the BG-vocal model's set) is not in the reference tree: taken as 4band_v3 + the same line, as v2_sn is to v2 (inferred).
@@ -121,11 +123,19 @@ class VRFrontEnd:
             self._plans[key] = StftPlan(self.ctx, n_fft, hop, n_fft // 2 + 1, dim_t)
         return self._plans[key]
 
-    def _resample(self, x: torch.Tensor, sr_in: int, sr_out: int) -> torch.Tensor:
+    def _resample(self, x: torch.Tensor, sr_in: int, sr_out: int, res_type: str) -> torch.Tensor:
+        """librosa.resample as the reference calls it in the band chain: ``res_type`` "polyphase" on the way down (the parameter
+        sets' value, vr.py:74-79) is scipy.signal.resample_poly, "scipy" on the way up (spec_utils.py:427) scipy.signal.resample; equal
+        rates return the input (which is why the "sinc_fastest" of the lowest band, :404-414, never runs in the 4-band sets: bands 1 and 2
+        share 7350 Hz).  Any other kind is refused: libsamplerate's and resampy's filters are not restated here."""
         if sr_in == sr_out:
             return x
-        from .ensemble import resample
-        return resample(self.ctx, x, sr_in, sr_out)
+        from . import ensemble
+        if res_type == "polyphase":
+            return ensemble.resample_poly(self.ctx, x, sr_in, sr_out)
+        if res_type == "scipy":
+            return ensemble.resample_fft(self.ctx, x, sr_in, sr_out)
+        raise AlsepError(f"VRFrontEnd: resampler kind {res_type!r} ({sr_in} -> {sr_out} Hz) is not built (polyphase, scipy)")
 
     def _band_stft(self, wave: torch.Tensor, n_fft: int, hop: int) -> Tuple[torch.Tensor, int, int]:
         """librosa.stft(center=True, pad_mode="constant") of [2, n]: ([4, Fb, Ty] band spectrogram, first frame, frames)"""
@@ -140,12 +150,15 @@ class VRFrontEnd:
         return spec[0], off // hop, n_frames
 
     def _cross_mix(self, pair: torch.Tensor, self_gain: float, other_gain: float) -> None:
-        """in place on a contiguous [2, ...] float32 pair: (a, b) <- (self_gain a + other_gain b, self_gain b + other_gain a)"""
+        """in place on a [2, ...] float32 pair: (a, b) <- (self_gain a + other_gain b, self_gain b + other_gain a).  The halves of a view
+        need not sit on the 16-byte boundary ``alsep_axpby`` asks for: the arithmetic runs on fresh copies, the results are copied back."""
         ctx = self.ctx
-        a, b = pair[0], pair[1]
-        a0 = a.clone()
-        ctx.check(ctx.lib.alsep_axpby(ctx.handle, other_gain, _lib.ptr(b), self_gain, _lib.ptr(a), a.numel()), "alsep_axpby")
-        ctx.check(ctx.lib.alsep_axpby(ctx.handle, other_gain, _lib.ptr(a0), self_gain, _lib.ptr(b), b.numel()), "alsep_axpby")
+        a, b = pair[0].clone(), pair[1].clone()
+        ra, rb = a.clone(), b.clone()
+        ctx.check(ctx.lib.alsep_axpby(ctx.handle, other_gain, _lib.ptr(b), self_gain, _lib.ptr(ra), ra.numel()), "alsep_axpby")
+        ctx.check(ctx.lib.alsep_axpby(ctx.handle, other_gain, _lib.ptr(a), self_gain, _lib.ptr(rb), rb.numel()), "alsep_axpby")
+        pair[0].copy_(ra)
+        pair[1].copy_(rb)
 
     def analyse(self, wave: torch.Tensor):
         """vr.py:55-99: [2, n] at the set's rate -> (X [2, bins + 1, l] complex64, high end [2, hh, l] complex64)"""
@@ -158,7 +171,7 @@ class VRFrontEnd:
         for d in range(self.bands_n, 0, -1):
             bp = mp["band"][d]
             if d < self.bands_n:
-                x = self._resample(x, mp["band"][d + 1]["sr"], bp["sr"])
+                x = self._resample(x, mp["band"][d + 1]["sr"], bp["sr"], bp.get("res_type", "polyphase"))
             specs[d] = self._band_stft(x, bp["n_fft"], bp["hl"])
             if bp.get("convert_channels") == "stereo_n":                            # planes (L re, L im, R re, R im): a [2, 2 Fb Ty] pair
                 band = specs[d][0]
@@ -227,7 +240,8 @@ class VRFrontEnd:
                 if wave.shape[1] != w.shape[1]:
                     raise AlsepError(f"VRFrontEnd.synthesise: band {d} is {w.shape[1]} samples, the chain below it {wave.shape[1]}")
                 w = w + wave
-            wave = w if d == self.bands_n else self._resample(w, bp["sr"], mp["band"][d + 1]["sr"])
+            # spec_utils.py:402-427: the lowest band goes up with "sinc_fastest", the middle ones with "scipy"
+            wave = w if d == self.bands_n else self._resample(w, bp["sr"], mp["band"][d + 1]["sr"], "sinc_fastest" if d == 1 else "scipy")
         return wave
 
 

@@ -133,6 +133,19 @@ int alsep_ola_finish(alsep_ctx* ctx, const float* part, float gain, float* out, 
  * rolloff * min(sr_in, sr_out) / 2, Kaiser beta) -- PARITY UNPINNED; restated in oracle/mdx_oracle.py resample(). */
 int alsep_resample(alsep_ctx* ctx, const float* x, float* y, int64_t rows, int64_t n_in, int64_t n_out, int sr_in, int sr_out,
                    int zeros, float rolloff, float beta);
+/* scipy.signal.resample_poly(x, up, down) with a caller-made filter (its default: firwin(20 max(up, down) + 1, 1 / max(up, down),
+ * window=("kaiser", 5.0)) * up in float32) -- what librosa.resample(res_type="polyphase") runs in the VR band chain going down
+ * (modules/rvc/infer/modules/uvr5/vr.py:74-79, modelparams/4band_v*.json "res_type").  up / down already divided by their gcd;
+ * n_pre_pad = down - half_len % down, n_pre_remove = (half_len + n_pre_pad) / down, n_out = ceil(n_in up / down) as scipy computes
+ * them (audiolab_amd/vr_frontend.py).  x [rows, n_in] -> y [rows, n_out], taps on the device. */
+int alsep_resample_poly(alsep_ctx* ctx, const float* x, float* y, int64_t rows, int64_t n_in, int64_t n_out, int up, int down,
+                        const float* taps, int n_taps, int n_pre_pad, int n_pre_remove);
+/* scipy.signal.resample(x, n_out) (Fourier method) -- librosa.resample(res_type="scipy"), the VR band chain going up
+ * (modules/rvc/infer/lib/uvr5_pack/lib_v5/spec_utils.py:427): spectrum truncated / zero-padded with scipy's Nyquist rule, inverse
+ * transform times n_out / n_in.  Any lengths <= 2^27 (float64 Bluestein transforms); rows go two per complex transform. */
+int64_t alsep_resample_fft_workspace_bytes(int64_t n_in, int64_t n_out);
+int alsep_resample_fft(alsep_ctx* ctx, const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t n_in, int64_t n_out,
+                       void* ws, int64_t ws_bytes);
 /* zero the lowest nbins bins of a spectrogram in place (MDXSeparator.run_model zeroes bins 0..2). */
 int alsep_zero_low_bins(alsep_ctx* ctx, void* spec, int dtype, int layout, int64_t B, int64_t dim_f, int64_t T,
                         int nbins);

@@ -2,7 +2,9 @@
 """Golden vectors for the VR multi-band front / back end (TEST INFRASTRUCTURE).
 
 Imports the REFERENCE module modules/rvc/infer/lib/uvr5_pack/lib_v5/spec_utils.py in this container with ``librosa`` replaced by a stub
-whose ``stft`` / ``istft`` / ``resample`` are the primitives of oracle/vr_oracle.py (librosa, resampy, samplerate are not in the image),
+(librosa, resampy, samplerate are not in the image): ``stft`` / ``istft`` are the primitives of oracle/vr_oracle.py; ``resample`` does
+what librosa.resample does for the kinds that run -- equal rates: the input; "polyphase": scipy.signal.resample_poly; "scipy":
+scipy.signal.resample -- with SCIPY ITSELF (a dependency of the reference, importable here), and raises for any other kind;
 runs the reference's own ``wave_to_spectrogram``, ``combine_spectrograms``, ``mirroring`` and ``cmb_spectrogram_to_wave`` on a seeded
 signal with the reference's 4band_v2 parameter file, and records the results: tests/golden/vr_frontend.npz.  What these vectors pin is
 everything the reference does AROUND those primitives (cropping, stacking, pre-filter gains, filter ramps, mirroring, band recombination
@@ -32,7 +34,24 @@ def load_ref():
     lib = types.ModuleType("librosa")
     lib.stft = lambda y, n_fft=2048, hop_length=None, **kw: vo.stft(np.asarray(y), n_fft, hop_length)
     lib.istft = lambda stft_matrix, hop_length=None, **kw: vo.istft(np.asarray(stft_matrix), hop_length)
-    lib.resample = lambda y, orig_sr, target_sr, res_type=None, **kw: vo.resample(np.asarray(y, dtype=np.float32), orig_sr, target_sr)
+
+    def resample(y, orig_sr, target_sr, res_type="soxr_hq", **kw):               # librosa/core/audio.py resample, the reachable branches
+        import math
+        import scipy.signal
+        y = np.asarray(y)
+        if orig_sr == target_sr:
+            return y
+        ratio = float(target_sr) / orig_sr
+        n_samples = int(np.ceil(y.shape[-1] * ratio))
+        if res_type in ("scipy", "fft"):
+            y_hat = scipy.signal.resample(y, n_samples, axis=-1)
+        elif res_type == "polyphase":
+            g = math.gcd(int(orig_sr), int(target_sr))
+            y_hat = scipy.signal.resample_poly(y, int(target_sr) // g, int(orig_sr) // g, axis=-1)
+        else:
+            raise RuntimeError(f"librosa stub: resampler kind {res_type!r} needs a package that is not in the image")
+        return np.asarray(y_hat, dtype=y.dtype)
+    lib.resample = resample
     sys.modules["librosa"] = lib
     sys.modules.setdefault("soundfile", types.ModuleType("soundfile"))
     pkg_dir = os.path.join(REF, "modules/rvc/infer/lib/uvr5_pack/lib_v5")
@@ -60,7 +79,8 @@ def main():
     X_wave, X_spec_s = {}, {}
     for d in range(bands_n, 0, -1):                             # vr.py:55-96 with the reference's own functions
         bp = P["band"][d]
-        X_wave[d] = wave if d == bands_n else su.librosa.resample(X_wave[d + 1], orig_sr=P["band"][d + 1]["sr"], target_sr=bp["sr"])
+        X_wave[d] = wave if d == bands_n else su.librosa.resample(X_wave[d + 1], orig_sr=P["band"][d + 1]["sr"], target_sr=bp["sr"],
+                                                                  res_type=bp["res_type"])
         X_spec_s[d] = su.wave_to_spectrogram(X_wave[d], bp["hl"], bp["n_fft"], P["mid_side"], P["mid_side_b2"], P["reverse"])
         if d == bands_n:
             hh = (bp["n_fft"] // 2 - bp["crop_stop"]) + (P["pre_filter_stop"] - P["pre_filter_start"])

@@ -37,6 +37,49 @@ def test_oracle_matches_reference_vectors():
     assert np.max(np.abs(voc[::7] - g["voc_wave"])) < 1e-5
 
 
+def test_resampler_restatements_vs_scipy():
+    """oracle/vr_oracle.py resample_poly / resample_fft against the scipy routines librosa calls for "polyphase" and "scipy" (scipy is a
+    dependency of the reference and importable here): the pin of the band chain's resamplers"""
+    import scipy.signal as ss
+    rng = np.random.default_rng(0)
+    for n in (1000, 4411, 44100 + 7):
+        x = rng.standard_normal((2, n)).astype(np.float32)
+        for up, down in ((1, 3), (1, 2), (2, 1), (3, 1), (160, 147)):
+            want = ss.resample_poly(x, up, down, axis=-1)
+            got = vo.resample_poly(x, up, down)
+            assert got.shape == want.shape and got.dtype == want.dtype and np.max(np.abs(got - want)) < 2e-6
+        for num in (2 * n, 3 * n, n // 2, n // 3 + 1, n + 1):
+            want = ss.resample(x, num, axis=-1)                                          # float32 pocketfft; the restatement runs in float64
+            assert np.max(np.abs(vo.resample_fft(x, num) - want)) < 5e-6
+    with pytest.raises(ValueError, match="kaiser_fast"):
+        vo.resample(x, 48000, 44100, "kaiser_fast")
+    assert vo.resample(x, 7350, 7350, "sinc_fastest") is x
+
+
+@pytest.mark.parametrize("n", [999, 480 * 40 + 3])
+def test_device_resamplers_vs_oracle(dev, n):
+    """alsep_resample_poly / alsep_resample_fft through ensemble.resample_poly / resample_fft: the chain's ratios, a ragged general
+    ratio, an odd row count, down- and upsampling with even and odd lengths (scipy's Nyquist rule)"""
+    from audiolab_amd import ensemble
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((3, n)).astype(np.float32)
+    xd = on(dev, x)
+    for sr_in, sr_out in ((44100, 14700), (14700, 7350), (7350, 14700), (48000, 44100)):
+        got = host(ensemble.resample_poly(dev, xd, sr_in, sr_out))
+        want = vo.resample(x, sr_in, sr_out, "polyphase")
+        assert got.shape == want.shape and np.max(np.abs(got - want)) < 3e-6
+    for sr_in, sr_out in ((7350, 14700), (14700, 44100), (44100, 14700), (14700, 7350), (44100, 48000)):
+        for rows in (3, 2):
+            got = host(ensemble.resample_fft(dev, xd[:rows], sr_in, sr_out))
+            want = vo.resample(x[:rows], sr_in, sr_out, "scipy")
+            assert got.shape == want.shape and np.max(np.abs(got - want)) < 3e-6
+    even = on(dev, x[:1, : n - n % 2])                                                   # even length both ways
+    for sr_in, sr_out in ((2, 1), (1, 2)):
+        want = vo.resample(host(even), sr_in, sr_out, "scipy")
+        assert np.max(np.abs(host(ensemble.resample_fft(dev, even, sr_in, sr_out)) - want)) < 3e-6
+    assert ensemble.resample_poly(dev, xd, 7350, 7350) is xd
+
+
 def test_front_and_back_end_vs_reference_vectors(dev):
     from audiolab_amd.vr_frontend import VRFrontEnd
     g = np.load(GOLD)
@@ -86,6 +129,45 @@ def test_stages_vs_oracle(dev, n):
     assert np.max(np.abs(host(f.synthesise(X_in)) - w_o)) < 2e-5 * max(1.0, np.max(np.abs(w_o)))
 
 
+@pytest.mark.parametrize("params", ["4band_v2_sn", "4band_v3_sn"])
+def test_stereo_n_sets_vs_oracle(dev, params):
+    """the "_sn" parameter sets (top band converted with "stereo_n", modelparams/4band_v2_sn.json:48; the BG-vocal model's set): front
+    end and back end against the oracle, the conversion's exact inverse (analyse -> synthesise without mirroring returns what the plain
+    set returns), and that the conversion really happened (the top band's rows differ from the plain set's, the lower bands' do not).
+    The rule is upstream's, restated from memory -- no vector of the reference pins it (oracle/vr_oracle.py MODEL_PARAMS note)."""
+    from audiolab_amd.vr_frontend import VRFrontEnd
+    n = 480 * 30 + 5
+    wave = synth_mix(n, seed=17)
+    wave[1] = 0.6 * wave[1] + 0.2 * np.roll(wave[0], 37)                                 # channels that differ: the conversion is visible
+    mp, plain = vo.MODEL_PARAMS[params], params[:-3]
+    f, f_plain = VRFrontEnd(params, dev), VRFrontEnd(plain, dev)
+    X_o, he_o, hh = vo.front_end(wave, mp)
+    X_d, he_d = f.analyse(on(dev, wave))
+    peak = np.max(np.abs(X_o))
+    assert np.max(np.abs(host(X_d) - X_o)) < 2e-5 * peak and np.max(np.abs(host(he_d) - he_o)) < 2e-5 * peak
+    X_p = host(f_plain.analyse(on(dev, wave))[0])
+    lo = sum(mp["band"][d]["crop_stop"] - mp["band"][d]["crop_start"] for d in (1, 2, 3))
+    assert np.max(np.abs(host(X_d)[:, :lo] - X_p[:, :lo])) == 0.0
+    assert np.max(np.abs(host(X_d)[:, lo:] - X_p[:, lo:])) > 1e-2 * peak
+    want = (X_p[:, lo:] + 0.25 * X_p[::-1, lo:]) / 0.9375
+    assert np.max(np.abs(host(X_d)[:, lo:] - want)) < 1e-6 * peak
+    for spec in (X_o.astype(np.complex64), (0.5 * X_o).astype(np.complex64)):
+        w_o = vo.cmb_spectrogram_to_wave(spec, mp, hh, vo.mirroring(spec, he_o, mp)).T
+        w_d = host(f.synthesise(on(dev, np.ascontiguousarray(spec)), on(dev, np.ascontiguousarray(he_o))))
+        assert w_d.shape == w_o.shape and np.max(np.abs(w_d - w_o)) < 2e-5 * max(1.0, np.max(np.abs(w_o)))
+    back, back_plain = host(f.synthesise(X_d)), host(f_plain.synthesise(f_plain.analyse(on(dev, wave))[0]))
+    assert np.max(np.abs(back - back_plain)) < 2e-5 * max(1.0, np.max(np.abs(back_plain)))
+
+
+def test_unknown_channel_conversion_is_refused(dev, monkeypatch):
+    from audiolab_amd import vr_frontend
+    from audiolab_amd._lib import AlsepError
+    bad = {**vr_frontend._BANDS_4, 4: dict(vr_frontend._BANDS_4[4], convert_channels="mid_side_c")}
+    monkeypatch.setitem(vr_frontend.MODEL_PARAMS, "bad", dict(vr_frontend.MODEL_PARAMS["4band_v3"], band=bad))
+    with pytest.raises(AlsepError, match="mid_side_c"):
+        vr_frontend.VRFrontEnd("bad", dev)
+
+
 class _TiltNet:
     """stands in for a VRNet in the runner: [B, bins, frames, 2] -> the input times a frequency tilt"""
     offset, output_bin = 8, 673
@@ -123,7 +205,7 @@ def test_separator_end_to_end(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["17_HP-Wind_Inst-UVR.pth", "UVR-DeNoise-Lite.pth"])
+@pytest.mark.parametrize("name", ["17_HP-Wind_Inst-UVR.pth", "UVR-DeNoise-Lite.pth", "UVR-BVE-4B_SN-44100-1.pth"])
 def test_engine_runs_vr_models_full_size(gpu_ctx, tmp_path, name):
     """the roster's VR entries at their real size (673 bins, window 512; seeded random-init weights): labels, lengths, and the
     size-independent property of the split -- the two output spectrograms sum to the mix's, and the back end without mirroring is
