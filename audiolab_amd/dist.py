@@ -97,6 +97,33 @@ def all_gather_ranges(local: torch.Tensor, ranges: List[Tuple[int, int]], total:
     return out
 
 
+def all_gather_multi_ranges(locals_: List[torch.Tensor], ranges: List[List[Tuple[int, int]]], totals: List[int],
+                            group: Optional[dist.ProcessGroup] = None) -> List[torch.Tensor]:
+    """Several ``all_gather_ranges`` in ONE collective (the shift passes of the Demucs runner: a rank's range differs per pass):
+    locals_[p] is this rank's [..., hi - lo] piece of ranges[p][rank]; every piece is padded to its pass's longest range, the padded
+    pieces travel side by side in one buffer.  -> [[..., totals[p]] for p]."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    widths = [max(max(h - l for l, h in rg), 1) for rg in ranges]
+    lead = locals_[0].shape[:-1]
+    send = torch.zeros(lead + (sum(widths),), dtype=locals_[0].dtype, device=locals_[0].device)
+    at = 0
+    for loc, rg, w in zip(locals_, ranges, widths):
+        lo, hi = rg[rank]
+        if loc.shape[-1] != hi - lo or loc.shape[:-1] != lead:
+            raise ValueError(f"rank {rank}: a local piece is {tuple(loc.shape)}, expected {tuple(lead) + (hi - lo,)}")
+        send[..., at: at + hi - lo] = loc
+        at += w
+    recv = all_gather_fixed(send, group)
+    outs, at = [], 0
+    for rg, w, total in zip(ranges, widths, totals):
+        out = torch.empty(lead + (total,), dtype=send.dtype, device=send.device)
+        for r, (l, h) in enumerate(rg):
+            out[..., l:h] = recv[r][..., at: at + h - l]
+        outs.append(out)
+        at += w
+    return outs
+
+
 def all_gather_fixed(local: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """[...] of the same shape on every rank -> [world, ...] (the seam sums of neighbouring shards: a few MB per rank)"""
     world = dist.get_world_size(group)

@@ -621,21 +621,70 @@ class DemucsRunner:
             main.wait_stream(st)
             for p in range(n_pass):
                 ctx.check(lib.alsep_axpby(h, 1.0, _lib.ptr(accs[k][p]), 1.0, _lib.ptr(acc[p]), acc[p].numel()), "alsep_axpby")
-        if self.sharded and world > 1:
-            acc = [adist.all_reduce_partial(a, self.group) for a in acc]
         # per pass: divide by the summed weights of that pass, cut the view back to the track, average the passes
-        out = ctx.zeros((S * 2, L))
         stride = int((1 - self.overlap) * seg)
         passes = shift_offsets(self.shifts, max_shift, self.seed) if self.shifts else [0]
+        width = L + max_shift
+        sws = []
         for p, offset in enumerate(passes):
             view_len = L + max_shift - offset if self.shifts else L
-            sw = torch.zeros(view_len)
+            sw = torch.zeros(width)
             for off in range(0, view_len, stride):
                 cl = min(view_len - off, seg)
                 sw[off:off + cl] += _tri(seg)[:cl]
-            sw = sw.to(ctx.device)
+            sws.append(sw.to(ctx.device))
+        if self.sharded and world > 1:
+            # a rank's units are a contiguous run, so in every pass it owns the span from its first unit's offset to the next
+            # rank's (the last one: to the end).  Its units reach at most seg - stride samples beyond that span: those seam sums travel in
+            # one small all-gather and are added by the span's owner; every rank divides ITS spans by the summed weights, and ONE
+            # all-gather of the finished spans (both passes side by side) gives every rank the whole passes -- no full-length all-reduce.
+            seam = max(seg - stride, 1)
+            bounds = [adist.window_range(len(units), world, q) for q in range(world)]
+            ranges, tails = [], []
+            for p in range(n_pass):
+                firsts = []                                                     # first offset of rank q's units in pass p (None: none there)
+                for q_lo, q_hi in bounds:
+                    offs = [u[3] for u in units[q_lo:q_hi] if u[0] == p]
+                    firsts.append(offs[0] if offs else None)
+                owners = [q for q in range(world) if firsts[q] is not None]
+                rg = [None] * world
+                for i, q in enumerate(owners):
+                    rg[q] = (0 if i == 0 else firsts[q], firsts[owners[i + 1]] if i + 1 < len(owners) else width)
+                for q in range(world):                                          # a rank without units in this pass: an empty span, placed
+                    if rg[q] is None:                                           # so that the spans stay ascending and cover [0, width)
+                        at = next((rg[r][0] for r in range(q + 1, world) if rg[r] is not None and firsts[r] is not None), width)
+                        rg[q] = (at, at)
+                ranges.append(rg)
+                own_lo, own_hi = rg[rank]
+                tail = ctx.zeros((S * 2, seam))
+                n_tail = max(0, min(seam, width - own_hi)) if own_hi > own_lo else 0
+                if n_tail:
+                    tail[:, :n_tail] = acc[p][:, own_hi: own_hi + n_tail]
+                tails.append(tail)
+            got = adist.all_gather_fixed(torch.stack(tails), self.group)        # [world, n_pass, 2 S, seam]
+            pieces = []
+            for p in range(n_pass):
+                own_lo, own_hi = ranges[p][rank]
+                own = acc[p][:, own_lo:own_hi].contiguous()
+                for q in range(rank):                                           # earlier owners whose units reach into this span
+                    q_lo, q_hi = ranges[p][q]
+                    if q_hi <= q_lo:
+                        continue
+                    lo_, hi_ = max(q_hi, own_lo), min(q_hi + seam, own_hi)
+                    if hi_ > lo_:
+                        own[:, lo_ - own_lo: hi_ - own_lo] += got[q, p][:, lo_ - q_hi: hi_ - q_hi]
+                if own_hi > own_lo:
+                    swp = sws[p][own_lo:own_hi].contiguous()
+                    ctx.check(lib.alsep_nn_vec_div(h, _lib.ptr(own), _lib.ptr(swp), S * 2, own_hi - own_lo), "alsep_nn_vec_div")
+                pieces.append(own)
+            acc = adist.all_gather_multi_ranges(pieces, ranges, [width] * n_pass, self.group)
+        out = ctx.zeros((S * 2, L))
+        for p, offset in enumerate(passes):
+            view_len = L + max_shift - offset if self.shifts else L
             a = acc[p][:, :view_len].contiguous()
-            ctx.check(lib.alsep_nn_vec_div(h, _lib.ptr(a), _lib.ptr(sw), S * 2, view_len), "alsep_nn_vec_div")
+            if not (self.sharded and world > 1):
+                sw = sws[p][:view_len].contiguous()
+                ctx.check(lib.alsep_nn_vec_div(h, _lib.ptr(a), _lib.ptr(sw), S * 2, view_len), "alsep_nn_vec_div")
             cut = a[:, max_shift - offset: max_shift - offset + L].contiguous()
             ctx.check(lib.alsep_axpby(h, 1.0 / n_pass, _lib.ptr(cut), 1.0, _lib.ptr(out), S * 2 * L), "alsep_axpby")
         # sources * ref.std() + ref.mean()

@@ -131,6 +131,10 @@ def _worker_ola_demucs(rank, world, port, emul_so, out_path):
     out = DemucsRunner(hnet, shifts=1, overlap=0.25, seed=0, sharded=True).separate(hm)
     hw = ho.separate(ocfg, hsd, hm, shifts=1, overlap=0.25, seed=0).numpy()
     errs.append(float(max(np.max(np.abs(out[k].numpy() - hw[i])) for i, k in enumerate(ocfg.sources))))
+    # two shift passes: a rank's run of units crosses the pass boundary (its span differs per pass, the other rank has none in one of them)
+    out = DemucsRunner(hnet, shifts=2, overlap=0.25, seed=3, sharded=True).separate(hm[:, :3100])
+    hw = ho.separate(ocfg, hsd, hm[:, :3100], shifts=2, overlap=0.25, seed=3).numpy()
+    errs[-1] = max(errs[-1], float(max(np.max(np.abs(out[k].numpy() - hw[i])) for i, k in enumerate(ocfg.sources))))
     res = torch.tensor(errs)
     dist.all_reduce(res, op=dist.ReduceOp.MAX)
     if rank == 0:
