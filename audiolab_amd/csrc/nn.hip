@@ -643,6 +643,75 @@ nn_chan_stats_partial_small_kernel(const float* __restrict__ x, int64_t P, int C
         part[((int64_t)blockIdx.y * C + c) * 2 + 1] = q;
     }
 }
+// The same statistics for C % 4 == 0, C <= 1024 (every layer of MDX23C): thread = (pixel lane g, channel quad c4), one float4 per
+// pixel and thread, four pixels in flight; a workgroup takes a slab of pixels, the pixel lanes' fp64 partials meet in LDS in a fixed
+// order.  Against nn_chan_stats_partial_small_kernel (scalar loads, one dependent chain per thread, <= 256 workgroups: 160 GB/s on
+// the 65 536 x 128 level-0 tensors, a quarter of MDX23C's time) this is a streaming read.
+__global__ void __launch_bounds__(kNnThreads)
+nn_chan_stats4_kernel(const float* __restrict__ x, int64_t P, int C, int nb, double* __restrict__ part) {
+    double* red = reinterpret_cast<double*>(alsep_smem);      // [threads][8]
+    const int Q = C / 4, G = kNnThreads / Q;                   // G >= 1 pixel lanes; threads beyond G * Q idle
+    const int c4 = threadIdx.x % Q, g = threadIdx.x / Q;
+    const int64_t chunk = (P + nb - 1) / nb;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < P ? lo + chunk : P;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    if (g < G) {
+        const float* xp = x + 4 * c4;
+        int64_t p = lo + g;
+        for (; p + 3 * (int64_t)G < hi; p += 4 * (int64_t)G) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(xp + (p + (int64_t)u * G) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double d = (double)v[u][e]; s[e] += d; q[e] = fma(d, d, q[e]); }
+        }
+        for (; p < hi; p += G) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xp + p * C);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double d = (double)v[e]; s[e] += d; q[e] = fma(d, d, q[e]); }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[8 * threadIdx.x + e] = s[e]; red[8 * threadIdx.x + 4 + e] = q[e]; }
+    __syncthreads();
+    if (g == 0) {
+        for (int k = 1; k < G; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[e] += red[8 * (k * Q + c4) + e]; q[e] += red[8 * (k * Q + c4) + 4 + e]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            part[((int64_t)blockIdx.x * C + 4 * c4 + e) * 2] = s[e];
+            part[((int64_t)blockIdx.x * C + 4 * c4 + e) * 2 + 1] = q[e];
+        }
+    }
+}
+// reduction of the slabs' partials: 64 channels per workgroup, four strands per channel (slab b = strand, strand + 4, ...), combined in
+// a fixed order
+__global__ void __launch_bounds__(kNnThreads)
+nn_chan_stats_final4_kernel(const double* __restrict__ part, int nb, int64_t P, int C, float eps, float* __restrict__ stats) {
+    __shared__ double red[kNnThreads][2];
+    const int cl = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int b = j; b < nb; b += kNnThreads / 64) {
+            s += part[((int64_t)b * C + c) * 2];
+            q += part[((int64_t)b * C + c) * 2 + 1];
+        }
+    red[threadIdx.x][0] = s;
+    red[threadIdx.x][1] = q;
+    __syncthreads();
+    if (j == 0 && c < C) {
+        for (int k = 1; k < kNnThreads / 64; ++k) { s += red[k * 64 + cl][0]; q += red[k * 64 + cl][1]; }
+        const double mean = s / (double)P;
+        double var = q / (double)P - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[2 * c] = (float)mean;
+        stats[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
 __global__ void nn_chan_stats_final_kernel(const double* __restrict__ part, int nb, int64_t P, int C, float eps, float* __restrict__ stats) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -665,6 +734,24 @@ nn_chan_norm_apply_kernel(const float* __restrict__ x, float* __restrict__ y, co
         float v = (x[i] - stats[2 * c]) * stats[2 * c + 1];
         if (gamma) v = fmaf(v, gamma[c], beta[c]);
         y[i] = act == 3 ? gelu_erf(v) : v;
+    }
+}
+// the same with the result stored as IEEE half (the A operand of the half-precision convolution that follows; C % 4 == 0)
+__global__ void __launch_bounds__(kNnThreads)
+nn_chan_norm_apply_h_kernel(const float* __restrict__ x, _Float16* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                            const float* __restrict__ stats, int64_t n4, int C, int act) {
+    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kNnThreads) {
+        const int c = (int)((4 * i) % C);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + 4 * i);
+        h16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = (xv[e] - stats[2 * (c + e)]) * stats[2 * (c + e) + 1];
+            if (gamma) v = fmaf(v, gamma[c + e], beta[c + e]);
+            o[e] = (_Float16)(act == 3 ? gelu_erf(v) : v);
+        }
+        *reinterpret_cast<h16x4*>(y + 4 * i) = o;
     }
 }
 __global__ void __launch_bounds__(kNnThreads)
@@ -1084,22 +1171,30 @@ extern "C" int alsep_roformer_mask(alsep_ctx* ctx, const float* spec, const floa
     return ALSEP_OK;
 }
 
+static int64_t instnorm_slabs(int64_t P, int C) {
+    if (C % 4 == 0 && C <= 4 * kNnThreads) {                 // nn_chan_stats4_kernel: slabs of >= 64 pixels, at most 1024 of them
+        const int64_t nb = ceil_div64(P, 64);
+        return nb > 1024 ? 1024 : nb;
+    }
+    const int64_t nb = ceil_div64(P, 512);
+    return nb > 256 ? 256 : nb;
+}
 extern "C" int64_t alsep_nn_instnorm_workspace_bytes(int64_t P, int C) {
     if (P <= 0 || C <= 0) return -1;
-    int64_t nb = ceil_div64(P, 512);
-    if (nb > 256) nb = 256;
-    return (int64_t)sizeof(double) * 2 * C * nb + (int64_t)sizeof(float) * 2 * C + 64;
+    return (int64_t)sizeof(double) * 2 * C * instnorm_slabs(P, C) + (int64_t)sizeof(float) * 2 * C + 64;
 }
-extern "C" int alsep_nn_instnorm(alsep_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta, int64_t P, int C, float eps,
-                                 int act, void* workspace) {
-    ALSEP_ENTER(ctx);
-    NN_ARG(ctx && x && y && workspace && P > 0 && C > 0 && (act == 0 || act == 3) && ((gamma == nullptr) == (beta == nullptr)) &&
-               ((uintptr_t)workspace & 7) == 0,
-           "alsep_nn_instnorm");
-    int64_t nb = ceil_div64(P, 512);
-    if (nb > 256) nb = 256;
+// statistics of x [P, C] per channel -> stats [C][2] = (mean, 1 / sqrt(var + eps)) behind the partials in the workspace
+static float* instnorm_stats(alsep_ctx* ctx, const float* x, int64_t P, int C, float eps, void* workspace) {
+    const int64_t nb = instnorm_slabs(P, C);
     double* part = reinterpret_cast<double*>(workspace);
     float* stats = reinterpret_cast<float*>(part + 2 * (int64_t)C * nb);
+    if (C % 4 == 0 && C <= 4 * kNnThreads && ((uintptr_t)x & 15) == 0) {
+        hipLaunchKernelGGL(nn_chan_stats4_kernel, dim3((unsigned)nb), dim3(kNnThreads), 8 * kNnThreads * sizeof(double), ctx->stream, x, P, C, (int)nb,
+                           part);
+        hipLaunchKernelGGL(nn_chan_stats_final4_kernel, dim3((unsigned)ceil_div64(C, 64)), dim3(kNnThreads), 0, ctx->stream, (const double*)part,
+                           (int)nb, P, C, eps, stats);
+        return stats;
+    }
     if (C < kNnThreads && kNnThreads % C == 0)
         hipLaunchKernelGGL(nn_chan_stats_partial_small_kernel, dim3(1, (unsigned)nb), dim3(kNnThreads), 2 * kNnThreads * sizeof(double), ctx->stream,
                            x, P, C, (int)nb, part);
@@ -1108,9 +1203,30 @@ extern "C" int alsep_nn_instnorm(alsep_ctx* ctx, const float* x, float* y, const
                            P, C, (int)nb, part);
     hipLaunchKernelGGL(nn_chan_stats_final_kernel, dim3((unsigned)ceil_div64(C, 64)), dim3(64), 0, ctx->stream, (const double*)part, (int)nb, P, C,
                        eps, stats);
-    hipLaunchKernelGGL(nn_chan_norm_apply_kernel, dim3(ew_grid(P * C)), dim3(kNnThreads), 0, ctx->stream, x, y, gamma, beta, (const float*)stats,
-                       P * C, C, act);
+    return stats;
+}
+extern "C" int alsep_nn_instnorm(alsep_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta, int64_t P, int C, float eps,
+                                 int act, void* workspace) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && x && y && workspace && P > 0 && C > 0 && (act == 0 || act == 3) && ((gamma == nullptr) == (beta == nullptr)) &&
+               ((uintptr_t)workspace & 7) == 0,
+           "alsep_nn_instnorm");
+    const float* stats = instnorm_stats(ctx, x, P, C, eps, workspace);
+    hipLaunchKernelGGL(nn_chan_norm_apply_kernel, dim3(ew_grid(P * C)), dim3(kNnThreads), 0, ctx->stream, x, y, gamma, beta, stats, P * C, C, act);
     ALSEP_LAUNCH_CHECK(ctx, "nn_instnorm kernels");
+    return ALSEP_OK;
+}
+// the same with y stored as IEEE half (C % 4 == 0, 16-byte aligned x, 8-byte aligned y): the input of alsep_nn_conv2d_f16
+extern "C" int alsep_nn_instnorm_f16(alsep_ctx* ctx, const float* x, void* y, const float* gamma, const float* beta, int64_t P, int C, float eps,
+                                     int act, void* workspace) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && x && y && workspace && P > 0 && C > 0 && C % 4 == 0 && (act == 0 || act == 3) && ((gamma == nullptr) == (beta == nullptr)) &&
+               ((uintptr_t)workspace & 7) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0,
+           "alsep_nn_instnorm_f16");
+    const float* stats = instnorm_stats(ctx, x, P, C, eps, workspace);
+    hipLaunchKernelGGL(nn_chan_norm_apply_h_kernel, dim3(ew_grid(P * C / 4)), dim3(kNnThreads), 0, ctx->stream, x, (_Float16*)y, gamma, beta, stats,
+                       P * C / 4, C, act);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_instnorm_f16 kernels");
     return ALSEP_OK;
 }
 

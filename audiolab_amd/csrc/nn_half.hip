@@ -219,6 +219,155 @@ nn_gemm_hh_kernel(GemmHArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Convolution as the same GEMM (MDX23C's TFC convolutions in half-precision mode): M = output pixels, N = output channels,
+// K = (tap, ci) with Cin % 64 == 0, so a 64-wide K slice is 64 consecutive input channels of ONE tap -- one 128-byte line of the pixel the
+// tap lands on (channels-last activations stored as IEEE half by the InstanceNorm kernel that produced them).  Only the A operand's
+// addressing differs from nn_gemm_hh_kernel: a thread's four staging rows keep their output pixel's (image base, iy0, ix0), and per
+// slice the tap's offset is added; a tap outside the image reads a clamped address and is zeroed when it is stored to LDS (the
+// validity travels with the register set it belongs to).  Weights [Cout][KH KW Cin] in IEEE half.  Epilogue: float32 into a channel
+// slice of y (the residual stream), optional float32 residual (the block's shortcut branch) -- four consecutive channels per lane.
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct ConvHArgs {
+    const _Float16* x; const _Float16* w;
+    float* y; const float* R;
+    int64_t npix, ldr;
+    int H, W, Cin, Cout, Ho, Wo, KH, KW, sh, sw, ph, pw, y_ct, y_c0;
+};
+
+struct HcStage {
+    h16x8 a[4], b[4];
+    unsigned ok;                                                              // bit h: row h's tap is inside the image
+};
+
+__global__ void __launch_bounds__(kHThreads, 2)
+nn_conv_hh_kernel(ConvHArgs p) {
+    _Float16* As = reinterpret_cast<_Float16*>(alsep_smem);
+    _Float16* Bs = As + 2 * kHgBM * kHgBK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.Cout + kHgBN - 1) / kHgBN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t tm = wg / tiles_n;
+    const int tn = wg % tiles_n;
+    const int64_t m0 = tm * kHgBM;
+    const int n0 = tn * kHgBN;
+    const int K = p.KH * p.KW * p.Cin;
+    const int sr = tid >> 3, sg = tid & 7;
+    const _Float16* xb[4];
+    const _Float16* gb[4];
+    int iy0[4], ix0[4];
+    bool va[4], vb[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int64_t pix = m0 + sr + 32 * h;
+        va[h] = pix < p.npix;
+        const int64_t pc = va[h] ? pix : 0;
+        const int64_t img = pc / ((int64_t)p.Ho * p.Wo);
+        const int rem = (int)(pc - img * p.Ho * p.Wo);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        iy0[h] = oy * p.sh - p.ph;
+        ix0[h] = ox * p.sw - p.pw;
+        xb[h] = p.x + img * (int64_t)p.H * p.W * p.Cin + 8 * sg;
+        const int rb = n0 + sr + 32 * h;
+        vb[h] = rb < p.Cout;
+        gb[h] = p.w + (int64_t)(vb[h] ? rb : 0) * K + 8 * sg;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    h16x8 zh;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zh[e] = (_Float16)0.f;
+    const int nk = K / kHgBK;
+    auto gload = [&](HcStage& r, int kt) {
+        const int kc = kt < nk ? kt : 0;                                     // beyond K: any valid slice (zeroed in lstore)
+        const int k0 = kc * kHgBK;
+        const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
+        const int dy = tap / p.KW, dx = tap - dy * p.KW;
+        r.ok = 0;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int iy = iy0[h] + dy, ix = ix0[h] + dx;
+            const bool in = va[h] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            r.ok |= (in ? 1u : 0u) << h;
+            const int64_t off = in ? ((int64_t)iy * p.W + ix) * p.Cin + ci0 : 0;
+            r.a[h] = *reinterpret_cast<const h16x8*>(xb[h] + off);
+            r.b[h] = *reinterpret_cast<const h16x8*>(gb[h] + k0);
+        }
+    };
+    auto lstore = [&](const HcStage& r, int buf, int kt) {
+        const bool in = kt < nk;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int row = sr + 32 * h;
+            *reinterpret_cast<h16x8*>(As + (size_t)buf * kHgBM * kHgBK + hg_slot(row, sg)) = (in && ((r.ok >> h) & 1u)) ? r.a[h] : zh;
+            *reinterpret_cast<h16x8*>(Bs + (size_t)buf * kHgBN * kHgBK + hg_slot(row, sg)) = (vb[h] && in) ? r.b[h] : zh;
+        }
+    };
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            h16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const h16x8*>(As + (size_t)buf * kHgBM * kHgBK + hg_slot(wm * 64 + i * 16 + l15, 4 * st + lq));
+                bf[i] = *reinterpret_cast<const h16x8*>(Bs + (size_t)buf * kHgBN * kHgBK + hg_slot(wn * 64 + i * 16 + l15, 4 * st + lq));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+    HcStage r0, r1;
+    gload(r0, 0);
+    gload(r1, 1);
+    lstore(r0, 0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        gload(r0, kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(r1, 1, kt + 1);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 >= nk) break;
+        gload(r1, kt + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(r0, 0, kt + 2);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t pix = m0 + wm * 64 + i * 16 + l15;
+        if (pix >= p.npix) continue;
+        f32x4 rv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn * 64 + j * 16 + 4 * lq;
+            rv[j] = (p.R && col < p.Cout) ? *reinterpret_cast<const f32x4*>(p.R + pix * p.ldr + col) : z4;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn * 64 + j * 16 + 4 * lq;
+            if (col >= p.Cout) continue;
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + rv[j][r];
+            *reinterpret_cast<f32x4*>(p.y + pix * p.y_ct + p.y_c0 + col) = v;
+        }
+    }
+}
+
 // lucidrains RMSNorm (y = x / max(||x||_2, 1e-12) sqrt(C) gamma, sum of squares in double as nn_rmsnorm_kernel) with the result stored
 // as IEEE half: the A operand of the Linear that follows.  One wave per row.
 __global__ void __launch_bounds__(kHThreads)
@@ -513,6 +662,34 @@ extern "C" int alsep_nn_gemm_f16(alsep_ctx* ctx, const void* A, int64_t lda, int
     }
 #undef ALSEP_HG_GO
     ALSEP_LAUNCH_CHECK(ctx, "nn_gemm_hh_kernel");
+    return ALSEP_OK;
+}
+
+// y[pixel][y_coff + co] = sum_{tap, ci} x[pixel's tap][ci] w[co][tap][ci] (+ R[pixel][co]): x, w IEEE half (x channels-last [B, H, W, Cin],
+// w [Cout][KH][KW][Cin]), y / R float32.  Needs Cin % 64 == 0, Cout % 4 == 0, y_ctotal % 4 == 0, y_coff % 4 == 0, ldr % 4 == 0, 16-byte
+// aligned bases (ALSEP_ERR_ARG otherwise).
+extern "C" int alsep_nn_conv2d_f16(alsep_ctx* ctx, const void* x, const void* w, float* y, const float* R, int64_t ldr, int64_t B, int H, int W,
+                                   int Cin, int Cout, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, int y_ctotal, int y_coff) {
+    ALSEP_ENTER(ctx);
+    if (!ctx || !x || !w || !y || B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 || stride_h < 1 || stride_w < 1 ||
+        pad_h < 0 || pad_w < 0 || y_coff < 0 || y_coff + Cout > y_ctotal)
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d_f16: bad argument");
+    const int Ho = (H + 2 * pad_h - KH) / stride_h + 1, Wo = (W + 2 * pad_w - KW) / stride_w + 1;
+    if (Ho < 1 || Wo < 1) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d_f16: empty output");
+    if (Cin % 64 || Cout % 4 || y_ctotal % 4 || y_coff % 4 || (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) ||
+        (R && (ldr % 4 || ldr < Cout || ((uintptr_t)R & 15))))
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d_f16: operands do not meet the alignment this kernel needs (Cin %% 64, Cout %% 4)");
+    const int64_t npix = B * Ho * Wo;
+    const int64_t n_wg = ceil_div64(Cout, kHgBN) * ceil_div64(npix, kHgBM);
+    if (n_wg > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d_f16: too many tiles");
+    ConvHArgs p{(const _Float16*)x, (const _Float16*)w, y, R, npix, ldr, H, W, Cin, Cout, Ho, Wo, KH, KW, stride_h, stride_w, pad_h, pad_w, y_ctotal,
+                y_coff};
+    ProfScope prof(ctx, ALSEP_PROF_NN_CONV);
+    const double K = (double)KH * KW * Cin;
+    prof.work(2.0 * (double)npix * Cout * K, 2.0 * (double)B * H * W * Cin + 2.0 * Cout * K + (R ? 8.0 : 4.0) * (double)npix * Cout);
+    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)nn_conv_hh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHgLds));
+    hipLaunchKernelGGL(nn_conv_hh_kernel, dim3((unsigned)n_wg), dim3(kHThreads), kHgLds, ctx->stream, p);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_conv_hh_kernel");
     return ALSEP_OK;
 }
 

@@ -428,7 +428,7 @@ class Separator:
             seed = int.from_bytes(hashlib.sha256(model_filename.encode()).digest()[:4], "little")
             sd, weights = mdx23c_synth(cfg, seed=seed), "synthetic"
             logger.warning("%s: no weight file under %s -- SYNTHETIC random-init weights (allow_synthetic=True)", model_filename, self.model_file_dir)
-        net = MDX23C(cfg, sd, ctx=self.ctx)
+        net = MDX23C(cfg, sd, ctx=self.ctx, precision="f32" if self.dtype == torch.float32 else "f16")   # use_autocast: half-precision mode
         inst = _ModelInstance(model_filename, net, None, labels[0], None)
         inst.roformer = RoformerRunner(net, labels)             # the same chunked runner (training project's demix_track)
         inst.output_dir = self.output_dir

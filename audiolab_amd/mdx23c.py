@@ -97,15 +97,29 @@ def expected_shapes(cfg: MDX23CConfig) -> Dict[str, Tuple[Tuple[int, ...], str]]
 class _W:
     """[KH][KW][Cin][Cout] convolution weights (no bias anywhere in this network)"""
 
-    def __init__(self, ctx: Context, w4: torch.Tensor):
+    def __init__(self, ctx: Context, w4: torch.Tensor, half: bool = False, what: str = ""):
         self.kh, self.kw, self.cin, self.cout = (int(v) for v in w4.shape)
         self.w = w4.detach().float().contiguous().to(ctx.device)
         self.scale = torch.ones(self.cout, device=ctx.device)
         self.shift = torch.zeros(self.cout, device=ctx.device)
+        self.wh = None
+        if half:                                            # [Cout][KH][KW][Cin] IEEE half: the image alsep_nn_conv2d_f16 reads
+            if self.cin % 64 or self.cout % 4:
+                raise AlsepError(f"MDX23C precision='f16': {what} has {self.cin} -> {self.cout} channels; the half-precision convolution needs "
+                                 f"input channels in multiples of 64 (num_channels / growth of the .yaml)")
+            self.wh = self.w.permute(3, 0, 1, 2).contiguous().to(torch.float16)
 
 
 class MDX23C:
-    def __init__(self, cfg: MDX23CConfig, state_dict: Dict[str, torch.Tensor], ctx: Optional[Context] = None):
+    def __init__(self, cfg: MDX23CConfig, state_dict: Dict[str, torch.Tensor], ctx: Optional[Context] = None, precision: str = "f32"):
+        """``precision="f16"``: the half-precision mode (the reference runs this network under torch autocast, stem_separator.py:106
+        ``use_autocast=True``).  The convolutions of the TFC-TDF blocks and of the down- / up-scaling layers -- 85 % of the arithmetic --
+        read IEEE-half activations (written in that type by the InstanceNorm + GELU kernel in front of them; the shortcut branch's raw
+        input by a conversion pass) and IEEE-half weights on v_mfma_f32_16x16x32_f16; their results, the residual stream, the statistics,
+        the TDF linears and the first / final 1x1 convolutions stay float32.  Storage-mode oracle: oracle/mdx23c_oracle.forward(half=True)."""
+        if precision not in ("f32", "f16"):
+            raise AlsepError(f"MDX23C: precision {precision!r} (f32, f16)")
+        self.half = precision == "f16"
         if tuple(cfg.scale) != (2, 2):
             raise AlsepError("MDX23C: only scale (2, 2) is implemented")
         if cfg.dim_f % cfg.num_subbands or (cfg.dim_f // cfg.num_subbands) % (2 ** cfg.num_scales * cfg.bottleneck_factor):
@@ -121,13 +135,13 @@ class MDX23C:
                       ("encoder_blocks.0.tfc_tdf.blocks.%d." % cfg.num_blocks_per_scale, f"num_blocks_per_scale={cfg.num_blocks_per_scale}")))
         v = lambda k: sd[k].detach().float().contiguous().to(dev)
 
-        def conv(k):                      # Conv2d [Cout, Cin, KH, KW] over (T, F) -> H = T, W = F
-            return _W(self.ctx, sd[k].permute(2, 3, 1, 0))
+        def conv(k, half=None):           # Conv2d [Cout, Cin, KH, KW] over (T, F) -> H = T, W = F
+            return _W(self.ctx, sd[k].permute(2, 3, 1, 0), self.half if half is None else half, k)
 
         def tconv(k):                     # ConvTranspose2d [Cin, Cout, 2, 2] -> 1x1 conv to (dy*2+dx)*Cout + co
             w = sd[k]
             cin, cout = w.shape[:2]
-            return _W(self.ctx, w.permute(0, 2, 3, 1).reshape(cin, 4 * cout)[None, None]), int(cout)
+            return _W(self.ctx, w.permute(0, 2, 3, 1).reshape(cin, 4 * cout)[None, None], self.half, k), int(cout)
 
         def block(p):
             out = []
@@ -139,7 +153,7 @@ class MDX23C:
                                 n2=(v(q + ".tfc2.0.weight"), v(q + ".tfc2.0.bias")), c2=conv(q + ".tfc2.2.weight")))
             return out
         try:
-            self.first = conv("first_conv.weight")
+            self.first = conv("first_conv.weight", False)
             self.enc = [dict(blk=block(f"encoder_blocks.{i}.tfc_tdf"),
                              dn=(v(f"encoder_blocks.{i}.downscale.conv.0.weight"), v(f"encoder_blocks.{i}.downscale.conv.0.bias")),
                              dconv=conv(f"encoder_blocks.{i}.downscale.conv.2.weight")) for i in range(cfg.num_scales)]
@@ -149,7 +163,7 @@ class MDX23C:
                 tw, cout = tconv(f"decoder_blocks.{i}.upscale.conv.2.weight")
                 self.dec.append(dict(un=(v(f"decoder_blocks.{i}.upscale.conv.0.weight"), v(f"decoder_blocks.{i}.upscale.conv.0.bias")), up=tw,
                                      cout=cout, blk=block(f"decoder_blocks.{i}.tfc_tdf")))
-            self.final0, self.final2 = conv("final_conv.0.weight"), conv("final_conv.2.weight")
+            self.final0, self.final2 = conv("final_conv.0.weight", False), conv("final_conv.2.weight", False)
         except KeyError as e:
             raise AlsepError(f"state_dict is missing {e} for this MDX23CConfig") from e
         self._plans: Dict[int, object] = {}
@@ -166,14 +180,37 @@ class MDX23C:
                                           cv.cin, cv.cout, cv.kh, cv.kw, stride[0], stride[1], pad[0], pad[1], 1, 1, act, ct, coff), "alsep_nn_conv2d")
         return y, Ho, Wo
 
-    def _norm_act(self, x, P, Cn, gb):
+    def _norm_act(self, x, P, Cn, gb, half=False):
+        """InstanceNorm2d(affine) + GELU; ``half``: the result as IEEE half (what a half-precision convolution reads)"""
         ctx = self.ctx
         need = int(ctx.lib.alsep_nn_instnorm_workspace_bytes(P, Cn))
         if self._ws is None or self._ws.numel() < need:
             self._ws = ctx.empty((max(need, 1 << 16),), torch.uint8)
+        if half:
+            y = ctx.empty((P, Cn), torch.float16)
+            ctx.check(ctx.lib.alsep_nn_instnorm_f16(ctx.handle, _lib.ptr(x), _lib.ptr(y), _lib.ptr(gb[0]), _lib.ptr(gb[1]), P, Cn, 1e-5, ACT_GELU,
+                                                    _lib.ptr(self._ws)), "alsep_nn_instnorm_f16")
+            return y
         y = ctx.empty((P, Cn))
         ctx.check(ctx.lib.alsep_nn_instnorm(ctx.handle, _lib.ptr(x), _lib.ptr(y), _lib.ptr(gb[0]), _lib.ptr(gb[1]), P, Cn, 1e-5, ACT_GELU,
                                             _lib.ptr(self._ws)), "alsep_nn_instnorm")
+        return y
+
+    def _conv_h(self, xh, H, W, cv: _W, stride=(1, 1), pad=(0, 0), res=None):
+        """half-precision convolution of an IEEE-half activation; float32 result (+ ``res``, float32 [pixels, Cout])"""
+        ctx = self.ctx
+        Ho = (H + 2 * pad[0] - cv.kh) // stride[0] + 1
+        Wo = (W + 2 * pad[1] - cv.kw) // stride[1] + 1
+        y = ctx.empty((Ho * Wo, cv.cout))
+        ctx.check(ctx.lib.alsep_nn_conv2d_f16(ctx.handle, _lib.ptr(xh), _lib.ptr(cv.wh), _lib.ptr(y), _lib.ptr(res) if res is not None else None,
+                                              cv.cout, 1, H, W, cv.cin, cv.cout, cv.kh, cv.kw, stride[0], stride[1], pad[0], pad[1], cv.cout, 0),
+                  "alsep_nn_conv2d_f16")
+        return y, Ho, Wo
+
+    def _to_half(self, x):
+        ctx = self.ctx
+        y = ctx.empty(tuple(x.shape), torch.float16)
+        ctx.check(ctx.lib.alsep_nn_to_f16(ctx.handle, _lib.ptr(x), _lib.ptr(y), x.numel()), "alsep_nn_to_f16")
         return y
 
     def _linear_f(self, x, T, Fin, Cn, w):
@@ -196,6 +233,14 @@ class MDX23C:
         P = T * Fw
         for L in blk:
             cin, c = L["c1"].cin, L["c1"].cout
+            if self.half:
+                s, _, _ = self._conv_h(self._to_half(x), T, Fw, L["short"])
+                x, _, _ = self._conv_h(self._norm_act(x, P, cin, L["n1"], True), T, Fw, L["c1"], pad=(1, 1))
+                t, Fh = self._linear_f(self._norm_act(x, P, c, L["nt1"]), T, Fw, c, L["l1"])
+                t, _ = self._linear_f(self._norm_act(t, T * Fh, c, L["nt2"]), T, Fh, c, L["l2"])
+                x = self._add(x, t, P * c)
+                x, _, _ = self._conv_h(self._norm_act(x, P, c, L["n2"], True), T, Fw, L["c2"], pad=(1, 1), res=s)      # + shortcut, fused
+                continue
             s, _, _ = self._conv(x, T, Fw, L["short"])
             x, _, _ = self._conv(self._norm_act(x, P, cin, L["n1"]), T, Fw, L["c1"], pad=(1, 1))
             t, Fh = self._linear_f(self._norm_act(x, P, c, L["nt1"]), T, Fw, c, L["l1"])
@@ -235,11 +280,17 @@ class MDX23C:
         for E in self.enc:
             x = self._block(x, Tc, Fc, E["blk"])
             skips.append((x, Tc, Fc, c))
-            x, Tc, Fc = self._conv(self._norm_act(x, Tc * Fc, c, E["dn"]), Tc, Fc, E["dconv"], stride=(2, 2))
+            if self.half:
+                x, Tc, Fc = self._conv_h(self._norm_act(x, Tc * Fc, c, E["dn"], True), Tc, Fc, E["dconv"], stride=(2, 2))
+            else:
+                x, Tc, Fc = self._conv(self._norm_act(x, Tc * Fc, c, E["dn"]), Tc, Fc, E["dconv"], stride=(2, 2))
             c = E["dconv"].cout
         x = self._block(x, Tc, Fc, self.bott)
         for D in self.dec:
-            g, _, _ = self._conv(self._norm_act(x, Tc * Fc, c, D["un"]), Tc, Fc, D["up"])
+            if self.half:
+                g, _, _ = self._conv_h(self._norm_act(x, Tc * Fc, c, D["un"], True), Tc, Fc, D["up"])
+            else:
+                g, _, _ = self._conv(self._norm_act(x, Tc * Fc, c, D["un"]), Tc, Fc, D["up"])
             skip, Ts, Fs, cs = skips.pop()
             c = D["cout"]
             cat = ctx.empty((Ts * Fs, c + cs))

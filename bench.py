@@ -375,9 +375,9 @@ def other_workload(args) -> None:
         fam = MODEL_ROSTER[name][0] if isinstance(MODEL_ROSTER[name][0], str) and MODEL_ROSTER[name][0] in ("roformer", "mdx23c", "vr", "demucs") else "mdx"
         probe = eng.separate_array(mix[:, : min(n, 10 * SR)])
         stems, audio_s = len(probe), n / SR
-        mode = "IEEE-half MFMA operands (the reference's use_autocast=True)" if (half and fam in ("roformer", "mdx")) else "fp32"
+        mode = "IEEE-half MFMA operands (the reference's use_autocast=True)" if (half and fam in ("roformer", "mdx", "mdx23c")) else "fp32"
         desc = f"{name} ({fam}), {seconds} s 44.1 kHz stereo, {mode}, {stems} stems out, world {world}: replicas"
-        dtype_name, sharding = ("f16" if (half and fam in ("roformer", "mdx")) else "f32"), f"replicas x{world}"
+        dtype_name, sharding = ("f16" if (half and fam in ("roformer", "mdx", "mdx23c")) else "f32"), f"replicas x{world}"
 
         def step():
             return eng.separate_array(mix)

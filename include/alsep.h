@@ -330,6 +330,15 @@ int alsep_roformer_mask(alsep_ctx* ctx, const float* spec, const float* h, const
 int64_t alsep_nn_instnorm_workspace_bytes(int64_t P, int C);
 int alsep_nn_instnorm(alsep_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta, int64_t P, int C, float eps, int act,
                       void* workspace);
+/* the same with y stored as IEEE half (C % 4 == 0): the activation a half-precision convolution reads (MDX23C's half-precision mode --
+ * stem_separator.py:106 use_autocast=True: convolutions in half, normalisation in float32) */
+int alsep_nn_instnorm_f16(alsep_ctx* ctx, const float* x, void* y, const float* gamma, const float* beta, int64_t P, int C, float eps, int act,
+                          void* workspace);
+/* Conv2d on v_mfma_f32_16x16x32_f16: x IEEE half channels-last [B, H, W, Cin], w IEEE half [Cout][KH][KW][Cin], float32 result into the
+ * channel slice [y_coff, y_coff + Cout) of y [B, Ho, Wo, y_ctotal], optionally + R (float32 [pixels][ldr]: a block's shortcut branch).
+ * Cin % 64 == 0, Cout % 4 == 0; no bias, no activation (this network has neither after a convolution). */
+int alsep_nn_conv2d_f16(alsep_ctx* ctx, const void* x, const void* w, float* y, const float* R, int64_t ldr, int64_t B, int H, int W, int Cin,
+                        int Cout, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, int y_ctotal, int y_coff);
 /* y = a * b element-wise */
 int alsep_nn_mul(alsep_ctx* ctx, const float* a, const float* b, float* y, int64_t n);
 /* second half of ConvTranspose2d(kernel = stride = 2): g [H, W, 4*Cout] (1x1 conv, columns (dy*2+dx)*Cout + co) -> channel slice

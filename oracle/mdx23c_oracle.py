@@ -57,22 +57,31 @@ def _norm_act(w, p: str, x: torch.Tensor) -> torch.Tensor:
     return F.gelu(F.instance_norm(x, weight=w[p + ".weight"], bias=w[p + ".bias"], eps=1e-5))
 
 
-def _tfc_tdf(w, p: str, x: torch.Tensor, l: int) -> torch.Tensor:
+def _h(x: torch.Tensor, half: bool) -> torch.Tensor:
+    """storage rounding of the build's half-precision mode: what a half-precision convolution reads is IEEE half (float32 arithmetic on
+    the rounded values: the MFMA accumulates in float32)"""
+    return x.half().float() if half else x
+
+
+def _tfc_tdf(w, p: str, x: torch.Tensor, l: int, half: bool = False) -> torch.Tensor:
     for i in range(l):
         q = f"{p}.blocks.{i}"
-        s = F.conv2d(x, w[q + ".shortcut.weight"])
-        x = F.conv2d(_norm_act(w, q + ".tfc1.0", x), w[q + ".tfc1.2.weight"], padding=1)
+        s = F.conv2d(_h(x, half), _h(w[q + ".shortcut.weight"], half))
+        x = F.conv2d(_h(_norm_act(w, q + ".tfc1.0", x), half), _h(w[q + ".tfc1.2.weight"], half), padding=1)
         t = F.linear(_norm_act(w, q + ".tdf.0", x), w[q + ".tdf.2.weight"])
         t = F.linear(_norm_act(w, q + ".tdf.3", t), w[q + ".tdf.5.weight"])
         x = x + t
-        x = F.conv2d(_norm_act(w, q + ".tfc2.0", x), w[q + ".tfc2.2.weight"], padding=1)
+        x = F.conv2d(_h(_norm_act(w, q + ".tfc2.0", x), half), _h(w[q + ".tfc2.2.weight"], half), padding=1)
         x = x + s
     return x
 
 
 @torch.no_grad()
-def forward(cfg: MDX23CConfig, w: Dict[str, torch.Tensor], audio: torch.Tensor) -> torch.Tensor:
-    """audio [B, 2, L] (L = hop * (T - 1)) -> [B, num_stems, 2, L]"""
+def forward(cfg: MDX23CConfig, w: Dict[str, torch.Tensor], audio: torch.Tensor, half: bool = False) -> torch.Tensor:
+    """audio [B, 2, L] (L = hop * (T - 1)) -> [B, num_stems, 2, L].  ``half``: the storage-mode oracle of the build's half-precision mode
+    (audiolab_amd/mdx23c.py ``precision="f16"``): the inputs and weights of the TFC-TDF blocks' convolutions and of the down- / up-scaling
+    convolutions rounded to IEEE half, everything else float32 -- NOT torch autocast (which would also round those layers' outputs and
+    run the TDF linears in half); the reference's own autocast run is a third thing this oracle does not claim to reproduce."""
     B, C, L = audio.shape
     win = torch.hann_window(cfg.n_fft)
     z = torch.stft(audio.reshape(B * C, L), cfg.n_fft, cfg.hop, window=win, center=True, return_complex=True)
@@ -86,16 +95,16 @@ def forward(cfg: MDX23CConfig, w: Dict[str, torch.Tensor], audio: torch.Tensor) 
     x = x.transpose(-1, -2)
     enc = []
     for i in range(cfg.num_scales):
-        x = _tfc_tdf(w, f"encoder_blocks.{i}.tfc_tdf", x, cfg.num_blocks_per_scale)
+        x = _tfc_tdf(w, f"encoder_blocks.{i}.tfc_tdf", x, cfg.num_blocks_per_scale, half)
         enc.append(x)
-        x = F.conv2d(_norm_act(w, f"encoder_blocks.{i}.downscale.conv.0", x), w[f"encoder_blocks.{i}.downscale.conv.2.weight"],
+        x = F.conv2d(_h(_norm_act(w, f"encoder_blocks.{i}.downscale.conv.0", x), half), _h(w[f"encoder_blocks.{i}.downscale.conv.2.weight"], half),
                      stride=cfg.scale)
-    x = _tfc_tdf(w, "bottleneck_block", x, cfg.num_blocks_per_scale)
+    x = _tfc_tdf(w, "bottleneck_block", x, cfg.num_blocks_per_scale, half)
     for i in range(cfg.num_scales):
-        x = F.conv_transpose2d(_norm_act(w, f"decoder_blocks.{i}.upscale.conv.0", x), w[f"decoder_blocks.{i}.upscale.conv.2.weight"],
-                               stride=cfg.scale)
+        x = F.conv_transpose2d(_h(_norm_act(w, f"decoder_blocks.{i}.upscale.conv.0", x), half),
+                               _h(w[f"decoder_blocks.{i}.upscale.conv.2.weight"], half), stride=cfg.scale)
         x = torch.cat([x, enc.pop()], 1)
-        x = _tfc_tdf(w, f"decoder_blocks.{i}.tfc_tdf", x, cfg.num_blocks_per_scale)
+        x = _tfc_tdf(w, f"decoder_blocks.{i}.tfc_tdf", x, cfg.num_blocks_per_scale, half)
     x = x.transpose(-1, -2)
     x = x * first
     x = F.conv2d(F.gelu(F.conv2d(torch.cat([mix, x], 1), w["final_conv.0.weight"])), w["final_conv.2.weight"])

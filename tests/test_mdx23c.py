@@ -36,6 +36,79 @@ def test_forward_one_chunk_vs_oracle(dev):
     assert np.max(np.abs(want)) > 1e-3 and err < 1e-4 * max(1.0, float(np.max(np.abs(want))))
 
 
+@pytest.mark.parametrize("case", [
+    # (H, W, Cin, Cout, KH, KW, stride, pad, residual)
+    (9, 13, 64, 72, 3, 3, 1, 1, True),          # ragged pixel / channel tiles, every border tap
+    (8, 12, 128, 64, 1, 1, 1, 0, False),        # the shortcut branch
+    (10, 6, 64, 128, 2, 2, 2, 0, False),        # the down-scaling convolution
+    (130, 3, 64, 4, 3, 3, 1, 1, True),          # more than one pixel tile, the narrowest channel slice
+])
+def test_half_conv_vs_torch(dev, case):
+    """alsep_nn_conv2d_f16 against torch.conv2d on the same rounded operands: only the float32 summation order differs"""
+    import torch.nn.functional as F
+    from audiolab_amd import _lib
+    H, W, Cin, Cout, KH, KW, st, pad, with_res = case
+    g = torch.Generator().manual_seed(H * 100 + Cout)
+    x = (torch.randn(H, W, Cin, generator=g) * 0.7).half()
+    w = (torch.randn(Cout, KH, KW, Cin, generator=g) / (KH * KW * Cin) ** 0.5).half()
+    Ho, Wo = (H + 2 * pad - KH) // st + 1, (W + 2 * pad - KW) // st + 1
+    res = torch.randn(Ho * Wo, Cout, generator=g) if with_res else None
+    want = F.conv2d(x.float().permute(2, 0, 1)[None], w.float().permute(0, 3, 1, 2), stride=st, padding=pad)[0].permute(1, 2, 0).reshape(Ho * Wo, Cout)
+    if with_res:
+        want = want + res
+    xd, wd = on(dev, x), on(dev, w)
+    y = dev.empty((Ho * Wo, Cout + 8))
+    y.fill_(-7.0)
+    rd = on(dev, res) if with_res else None
+    dev.check(dev.lib.alsep_nn_conv2d_f16(dev.handle, _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), _lib.ptr(rd) if with_res else None, Cout, 1, H, W, Cin,
+                                          Cout, KH, KW, st, st, pad, pad, Cout + 8, 4), "alsep_nn_conv2d_f16")
+    got = host(y)
+    assert np.all(got[:, :4] == -7.0) and np.all(got[:, 4 + Cout:] == -7.0)             # only its channel slice is written
+    assert np.max(np.abs(got[:, 4: 4 + Cout] - want.numpy())) < 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_instnorm_half_and_wide_statistics(dev):
+    """the float4 statistics kernel (C % 4 == 0) and the half-precision output against torch.instance_norm, ragged slab sizes"""
+    import torch.nn.functional as F
+    from audiolab_amd import _lib
+    for P, Cn in ((1000, 64), (4099, 192), (77, 768), (300, 12)):
+        g = torch.Generator().manual_seed(P)
+        x = torch.randn(P, Cn, generator=g) * 2 + torch.linspace(-3, 3, Cn)
+        gamma, beta = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g) * 0.1
+        want = F.gelu(F.instance_norm(x.t()[None, :, :, None], weight=gamma, bias=beta, eps=1e-5))[0, :, :, 0].t()
+        ws = dev.empty((int(dev.lib.alsep_nn_instnorm_workspace_bytes(P, Cn)),), torch.uint8)
+        xd, gd, bd = on(dev, x), on(dev, gamma), on(dev, beta)
+        y32 = dev.empty((P, Cn))
+        dev.check(dev.lib.alsep_nn_instnorm(dev.handle, _lib.ptr(xd), _lib.ptr(y32), _lib.ptr(gd), _lib.ptr(bd), P, Cn, 1e-5, 3, _lib.ptr(ws)), "instnorm")
+        assert np.max(np.abs(host(y32) - want.numpy())) < 2e-5
+        y16 = dev.empty((P, Cn), torch.float16)
+        dev.check(dev.lib.alsep_nn_instnorm_f16(dev.handle, _lib.ptr(xd), _lib.ptr(y16), _lib.ptr(gd), _lib.ptr(bd), P, Cn, 1e-5, 3, _lib.ptr(ws)),
+                  "instnorm_f16")
+        # the float32 result rounded once: equal to rounding the float32 kernel's own output
+        assert np.array_equal(host(y16), host(y32).astype(np.float16))
+
+
+def test_half_mode_vs_storage_oracle(dev):
+    """precision="f16" (half-precision convolutions on IEEE-half activations, everything else float32) against the storage-mode
+    oracle: the same roundings, float32 arithmetic -- and, as the yardstick, against the float32 oracle (what the mode costs)"""
+    from audiolab_amd.mdx23c import MDX23C, MDX23CConfig
+    from audiolab_amd._lib import AlsepError
+    ocfg = small_cfg(num_channels=64, growth=64, dim_f=64, num_subbands=2, num_scales=1, num_blocks_per_scale=1, chunk_size=64 * 7)
+    sd = mo.synthetic_state_dict(ocfg, 2)
+    net = MDX23C(MDX23CConfig(**dataclasses.asdict(ocfg)), sd, ctx=dev, precision="f16")
+    x = torch.randn(2, ocfg.chunk_size, generator=torch.Generator().manual_seed(5)) * 0.3
+    want_h = mo.forward(ocfg, sd, x[None], half=True)[0].numpy()
+    want_f = mo.forward(ocfg, sd, x[None])[0].numpy()
+    got = host(net.forward(on(dev, x)))
+    peak = float(np.max(np.abs(want_f)))
+    e_h, cost = float(np.max(np.abs(got - want_h))), float(np.max(np.abs(want_h - want_f)))
+    print(f"mdx23c half mode: vs storage oracle {e_h:.3e}, the mode's own cost {cost:.3e}, peak {peak:.3f}")
+    assert peak > 1e-3 and cost > 0
+    assert e_h < 0.9 * cost + 1e-5 * max(1.0, peak)                     # rounding flips of re-ordered sums stay a fraction of the mode's cost
+    with pytest.raises(AlsepError, match="multiples of 64"):
+        MDX23C(MDX23CConfig(**dataclasses.asdict(small_cfg())), mo.synthetic_state_dict(small_cfg(), 1), ctx=dev, precision="f16")
+
+
 def test_six_way_drum_split_through_the_runner(dev):
     """the drum-kit splitter's shape (six instruments) through the chunked runner and the engine's roster entry"""
     from audiolab_amd.roformer import RoformerRunner
@@ -71,6 +144,34 @@ def test_full_size_chunk_vs_oracle(gpu_ctx):
     err = float(np.max(np.abs(got.cpu().numpy() - want)))
     print(f"mdx23c full-size chunk: max|delta| = {err:.3e}, peak = {np.max(np.abs(want)):.3f}, {dt * 1e3:.0f} ms (first call)")
     assert np.max(np.abs(want)) > 1e-3 and err < 1e-4 * max(1.0, float(np.max(np.abs(want))))
+
+
+@pytest.mark.gpu
+def test_full_size_chunk_half_precision(gpu_ctx):
+    """the same full-size chunk in the half-precision mode against the storage-mode oracle, with the float32 oracle as yardstick"""
+    import time
+    from audiolab_amd.mdx23c import MDX23C, MDX23CConfig
+    from audiolab_amd.synth import synth_mix
+    ocfg = mo.MDX23CConfig()
+    sd = mo.synthetic_state_dict(ocfg, 0)
+    net = MDX23C(MDX23CConfig(), sd, ctx=gpu_ctx, precision="f16")
+    x = torch.from_numpy(synth_mix(ocfg.chunk_size))
+    want_h = mo.forward(ocfg, sd, x[None], half=True)[0].numpy()
+    want_f = mo.forward(ocfg, sd, x[None])[0].numpy()
+    got = net.forward(x.cuda())
+    gpu_ctx.synchronize()
+    t0 = time.perf_counter()
+    got = net.forward(x.cuda())
+    gpu_ctx.synchronize()
+    dt = time.perf_counter() - t0
+    got = got.cpu().numpy()
+    peak = float(np.max(np.abs(want_f)))
+    e_h, cost = float(np.max(np.abs(got - want_h))), float(np.max(np.abs(want_h - want_f)))
+    rel = float(np.linalg.norm(got - want_f) / np.linalg.norm(want_f))
+    print(f"mdx23c full-size half mode: vs storage oracle {e_h:.3e}, the mode's own cost {cost:.3e} (rel L2 vs fp32 {rel:.3e}), peak {peak:.3f}, "
+          f"{dt * 1e3:.0f} ms (second call)")
+    assert gpu_ctx.launch_count("nn_conv_hh_kernel") > 0
+    assert e_h < 0.9 * cost + 1e-5 * max(1.0, peak)
 
 
 def test_engine_roster_entries(dev):
