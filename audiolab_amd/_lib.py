@@ -131,7 +131,9 @@ _SIGNATURES = {
     "alsep_nn_instnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "alsep_nn_instnorm_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_int,
                                         C.c_void_p]),
-    "alsep_nn_conv2d_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64] + [C.c_int] * 12),
+    "alsep_nn_conv2d_f16_workspace_bytes": (C.c_int64, [C.c_int64] + [C.c_int] * 10),
+    "alsep_nn_conv2d_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64] + [C.c_int] * 12 +
+                            [C.c_void_p, C.c_int64]),
     "alsep_nn_mul": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "alsep_nn_depth_to_space2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5),
     "alsep_mdx23c_spec_in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),

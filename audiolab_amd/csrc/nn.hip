@@ -687,24 +687,36 @@ nn_chan_stats4_kernel(const float* __restrict__ x, int64_t P, int C, int nb, dou
         }
     }
 }
-// reduction of the slabs' partials: 64 channels per workgroup, four strands per channel (slab b = strand, strand + 4, ...), combined in
-// a fixed order
+// reduction of the slabs' partials: 16 channels per workgroup, sixteen strands per channel (slab b = strand, strand + 16, ...; four
+// loads in flight per strand), combined in a fixed order.  (64 channels x 4 strands on <= 12 workgroups was a 256-deep chain of
+// dependent-latency loads: 33 us per call, 11 % of MDX23C's half-precision chunk.)
 __global__ void __launch_bounds__(kNnThreads)
 nn_chan_stats_final4_kernel(const double* __restrict__ part, int nb, int64_t P, int C, float eps, float* __restrict__ stats) {
     __shared__ double red[kNnThreads][2];
-    const int cl = threadIdx.x & 63, j = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    constexpr int ST = kNnThreads / 16;
+    const int cl = threadIdx.x & 15, j = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int b = j; b < nb; b += kNnThreads / 64) {
-            s += part[((int64_t)b * C + c) * 2];
-            q += part[((int64_t)b * C + c) * 2 + 1];
+    if (c < C) {
+        const double* pc = part + 2 * (int64_t)c;
+        int b = j;
+        for (; b + 3 * ST < nb; b += 4 * ST) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[2 * u] = pc[(int64_t)(b + u * ST) * C * 2];
+                v[2 * u + 1] = pc[(int64_t)(b + u * ST) * C * 2 + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s += v[2 * u]; q += v[2 * u + 1]; }
         }
+        for (; b < nb; b += ST) { s += pc[(int64_t)b * C * 2]; q += pc[(int64_t)b * C * 2 + 1]; }
+    }
     red[threadIdx.x][0] = s;
     red[threadIdx.x][1] = q;
     __syncthreads();
     if (j == 0 && c < C) {
-        for (int k = 1; k < kNnThreads / 64; ++k) { s += red[k * 64 + cl][0]; q += red[k * 64 + cl][1]; }
+        for (int k = 1; k < ST; ++k) { s += red[k * 16 + cl][0]; q += red[k * 16 + cl][1]; }
         const double mean = s / (double)P;
         double var = q / (double)P - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -1191,7 +1203,7 @@ static float* instnorm_stats(alsep_ctx* ctx, const float* x, int64_t P, int C, f
     if (C % 4 == 0 && C <= 4 * kNnThreads && ((uintptr_t)x & 15) == 0) {
         hipLaunchKernelGGL(nn_chan_stats4_kernel, dim3((unsigned)nb), dim3(kNnThreads), 8 * kNnThreads * sizeof(double), ctx->stream, x, P, C, (int)nb,
                            part);
-        hipLaunchKernelGGL(nn_chan_stats_final4_kernel, dim3((unsigned)ceil_div64(C, 64)), dim3(kNnThreads), 0, ctx->stream, (const double*)part,
+        hipLaunchKernelGGL(nn_chan_stats_final4_kernel, dim3((unsigned)ceil_div64(C, 16)), dim3(kNnThreads), 0, ctx->stream, (const double*)part,
                            (int)nb, P, C, eps, stats);
         return stats;
     }

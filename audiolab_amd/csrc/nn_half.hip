@@ -233,6 +233,8 @@ struct ConvHArgs {
     float* y; const float* R;
     int64_t npix, ldr;
     int H, W, Cin, Cout, Ho, Wo, KH, KW, sh, sw, ph, pw, y_ct, y_c0;
+    int splits, nk_per;                            // split K: workgroup (tile, s) sums slices [s nk_per, (s + 1) nk_per) into part[s]
+    float* part;                                   // [splits][npix][Cout] float32 (splits > 1)
 };
 
 struct HcStage {
@@ -249,8 +251,9 @@ nn_conv_hh_kernel(ConvHArgs p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.Cout + kHgBN - 1) / kHgBN;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int64_t tm = wg / tiles_n;
-    const int tn = wg % tiles_n;
+    const int sp = wg % p.splits, tile = wg / p.splits;
+    const int64_t tm = tile / tiles_n;
+    const int tn = tile % tiles_n;
     const int64_t m0 = tm * kHgBM;
     const int n0 = tn * kHgBN;
     const int K = p.KH * p.KW * p.Cin;
@@ -282,9 +285,10 @@ nn_conv_hh_kernel(ConvHArgs p) {
     h16x8 zh;
 #pragma unroll
     for (int e = 0; e < 8; ++e) zh[e] = (_Float16)0.f;
-    const int nk = K / kHgBK;
+    const int kt_lo = sp * p.nk_per;
+    const int nk = min(K / kHgBK - kt_lo, p.nk_per);                         // this workgroup's slices: kt_lo + [0, nk)
     auto gload = [&](HcStage& r, int kt) {
-        const int kc = kt < nk ? kt : 0;                                     // beyond K: any valid slice (zeroed in lstore)
+        const int kc = kt_lo + (kt < nk ? kt : 0);                           // beyond the range: any valid slice (zeroed in lstore)
         const int k0 = kc * kHgBK;
         const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
         const int dy = tap / p.KW, dx = tap - dy * p.KW;
@@ -346,6 +350,20 @@ nn_conv_hh_kernel(ConvHArgs p) {
         __builtin_amdgcn_sched_barrier(0);
     }
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.splits > 1) {                                                      // partial sums; conv_splitk_reduce_kernel finishes
+        float* part = p.part + (int64_t)sp * p.npix * p.Cout;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t pix = m0 + wm * 64 + i * 16 + l15;
+            if (pix >= p.npix) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + wn * 64 + j * 16 + 4 * lq;
+                if (col < p.Cout) *reinterpret_cast<f32x4*>(part + pix * p.Cout + col) = acc[i][j];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t pix = m0 + wm * 64 + i * 16 + l15;
@@ -365,6 +383,21 @@ nn_conv_hh_kernel(ConvHArgs p) {
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + rv[j][r];
             *reinterpret_cast<f32x4*>(p.y + pix * p.y_ct + p.y_c0 + col) = v;
         }
+    }
+}
+
+// y slice = part[0] + part[1] + ... (in that order) (+ R): four channels per thread
+__global__ void __launch_bounds__(kHThreads)
+conv_splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t npix, int Cout, const float* __restrict__ R, int64_t ldr,
+                          float* __restrict__ y, int y_ct, int y_c0) {
+    const int64_t n4 = npix * (Cout / 4);
+    for (int64_t i = (int64_t)blockIdx.x * kHThreads + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kHThreads) {
+        const int64_t pix = i / (Cout / 4);
+        const int col = (int)(i - pix * (Cout / 4)) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(part + pix * Cout + col);
+        for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(part + ((int64_t)s * npix + pix) * Cout + col);
+        if (R) v += *reinterpret_cast<const f32x4*>(R + pix * ldr + col);
+        *reinterpret_cast<f32x4*>(y + pix * y_ct + y_c0 + col) = v;
     }
 }
 
@@ -665,31 +698,73 @@ extern "C" int alsep_nn_gemm_f16(alsep_ctx* ctx, const void* A, int64_t lda, int
     return ALSEP_OK;
 }
 
+// Split K: a layer whose 128 x 128 tiles do not fill the chip (the deep levels of the U-Net: 8 x 32 pixels x 768 channels are 12 tiles
+// with 108 K slices each -- 225 us at 12 TFLOP/s) is cut along K into `splits` ranges of >= 8 slices, each workgroup writes its partial
+// tile, conv_splitk_reduce_kernel adds them in a fixed order (deterministic, unlike atomics).
+static void conv_h_split(int64_t npix, int Cout, int K, int* splits, int* nk_per) {
+    const int64_t tiles = ceil_div64(Cout, kHgBN) * ceil_div64(npix, kHgBM);
+    const int nk = K / kHgBK;
+    int s = 1;
+    if (tiles < 256) {
+        const int64_t want = ceil_div64(384, tiles);
+        const int cap = nk / 8 > 1 ? nk / 8 : 1;
+        s = (int)(want < cap ? want : cap);
+    }
+    *nk_per = (nk + s - 1) / s;
+    *splits = (nk + *nk_per - 1) / *nk_per;
+}
+static int conv_h_geometry(int H, int W, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, int* Ho, int* Wo) {
+    *Ho = (H + 2 * pad_h - KH) / stride_h + 1;
+    *Wo = (W + 2 * pad_w - KW) / stride_w + 1;
+    return *Ho >= 1 && *Wo >= 1;
+}
+// bytes of workspace alsep_nn_conv2d_f16 needs for this layer (0: none)
+extern "C" int64_t alsep_nn_conv2d_f16_workspace_bytes(int64_t B, int H, int W, int Cin, int Cout, int KH, int KW, int stride_h, int stride_w,
+                                                       int pad_h, int pad_w) {
+    int Ho, Wo, splits, nk_per;
+    if (B < 1 || H < 1 || W < 1 || Cin < 64 || Cin % 64 || Cout < 1 || KH < 1 || KW < 1 || stride_h < 1 || stride_w < 1 || pad_h < 0 || pad_w < 0 ||
+        !conv_h_geometry(H, W, KH, KW, stride_h, stride_w, pad_h, pad_w, &Ho, &Wo))
+        return -1;
+    conv_h_split(B * Ho * Wo, Cout, KH * KW * Cin, &splits, &nk_per);
+    return splits > 1 ? (int64_t)splits * B * Ho * Wo * Cout * (int64_t)sizeof(float) : 0;
+}
+
 // y[pixel][y_coff + co] = sum_{tap, ci} x[pixel's tap][ci] w[co][tap][ci] (+ R[pixel][co]): x, w IEEE half (x channels-last [B, H, W, Cin],
 // w [Cout][KH][KW][Cin]), y / R float32.  Needs Cin % 64 == 0, Cout % 4 == 0, y_ctotal % 4 == 0, y_coff % 4 == 0, ldr % 4 == 0, 16-byte
-// aligned bases (ALSEP_ERR_ARG otherwise).
+// aligned bases, and alsep_nn_conv2d_f16_workspace_bytes(...) bytes of workspace (ALSEP_ERR_ARG otherwise).
 extern "C" int alsep_nn_conv2d_f16(alsep_ctx* ctx, const void* x, const void* w, float* y, const float* R, int64_t ldr, int64_t B, int H, int W,
-                                   int Cin, int Cout, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, int y_ctotal, int y_coff) {
+                                   int Cin, int Cout, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, int y_ctotal, int y_coff,
+                                   void* workspace, int64_t workspace_bytes) {
     ALSEP_ENTER(ctx);
     if (!ctx || !x || !w || !y || B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 || stride_h < 1 || stride_w < 1 ||
         pad_h < 0 || pad_w < 0 || y_coff < 0 || y_coff + Cout > y_ctotal)
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d_f16: bad argument");
-    const int Ho = (H + 2 * pad_h - KH) / stride_h + 1, Wo = (W + 2 * pad_w - KW) / stride_w + 1;
-    if (Ho < 1 || Wo < 1) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d_f16: empty output");
+    int Ho, Wo;
+    if (!conv_h_geometry(H, W, KH, KW, stride_h, stride_w, pad_h, pad_w, &Ho, &Wo)) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d_f16: empty output");
     if (Cin % 64 || Cout % 4 || y_ctotal % 4 || y_coff % 4 || (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) ||
         (R && (ldr % 4 || ldr < Cout || ((uintptr_t)R & 15))))
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d_f16: operands do not meet the alignment this kernel needs (Cin %% 64, Cout %% 4)");
     const int64_t npix = B * Ho * Wo;
-    const int64_t n_wg = ceil_div64(Cout, kHgBN) * ceil_div64(npix, kHgBM);
+    int splits, nk_per;
+    conv_h_split(npix, Cout, KH * KW * Cin, &splits, &nk_per);
+    if (splits > 1 && (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < (int64_t)splits * npix * Cout * (int64_t)sizeof(float)))
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d_f16: workspace missing or too small (alsep_nn_conv2d_f16_workspace_bytes)");
+    const int64_t n_wg = ceil_div64(Cout, kHgBN) * ceil_div64(npix, kHgBM) * splits;
     if (n_wg > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d_f16: too many tiles");
     ConvHArgs p{(const _Float16*)x, (const _Float16*)w, y, R, npix, ldr, H, W, Cin, Cout, Ho, Wo, KH, KW, stride_h, stride_w, pad_h, pad_w, y_ctotal,
-                y_coff};
+                y_coff, splits, nk_per, (float*)workspace};
     ProfScope prof(ctx, ALSEP_PROF_NN_CONV);
     const double K = (double)KH * KW * Cin;
     prof.work(2.0 * (double)npix * Cout * K, 2.0 * (double)B * H * W * Cin + 2.0 * Cout * K + (R ? 8.0 : 4.0) * (double)npix * Cout);
     ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)nn_conv_hh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHgLds));
     hipLaunchKernelGGL(nn_conv_hh_kernel, dim3((unsigned)n_wg), dim3(kHThreads), kHgLds, ctx->stream, p);
     ALSEP_LAUNCH_CHECK(ctx, "nn_conv_hh_kernel");
+    if (splits > 1) {
+        const int64_t n4 = npix * (Cout / 4);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(n4, kHThreads), 4096)), dim3(kHThreads), 0, ctx->stream,
+                           (const float*)workspace, splits, npix, Cout, R, ldr, y, y_ctotal, y_coff);
+        ALSEP_LAUNCH_CHECK(ctx, "conv_splitk_reduce_kernel");
+    }
     return ALSEP_OK;
 }
 

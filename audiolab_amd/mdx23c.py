@@ -168,6 +168,7 @@ class MDX23C:
             raise AlsepError(f"state_dict is missing {e} for this MDX23CConfig") from e
         self._plans: Dict[int, object] = {}
         self._ws: Optional[torch.Tensor] = None
+        self._cws: Optional[torch.Tensor] = None
 
     # -- wrappers ---------------------------------------------------------------------------------------------
     def _conv(self, x, H, W, cv: _W, stride=(1, 1), pad=(0, 0), act=ACT_NONE, out=None, ctotal=None, coff=0):
@@ -202,9 +203,14 @@ class MDX23C:
         Ho = (H + 2 * pad[0] - cv.kh) // stride[0] + 1
         Wo = (W + 2 * pad[1] - cv.kw) // stride[1] + 1
         y = ctx.empty((Ho * Wo, cv.cout))
+        need = int(ctx.lib.alsep_nn_conv2d_f16_workspace_bytes(1, H, W, cv.cin, cv.cout, cv.kh, cv.kw, stride[0], stride[1], pad[0], pad[1]))
+        if need < 0:
+            raise AlsepError("MDX23C: alsep_nn_conv2d_f16_workspace_bytes rejected the layer's geometry")
+        if need and (self._cws is None or self._cws.numel() < need):     # split-K partials of the deep levels' layers
+            self._cws = ctx.empty((need,), torch.uint8)
         ctx.check(ctx.lib.alsep_nn_conv2d_f16(ctx.handle, _lib.ptr(xh), _lib.ptr(cv.wh), _lib.ptr(y), _lib.ptr(res) if res is not None else None,
-                                              cv.cout, 1, H, W, cv.cin, cv.cout, cv.kh, cv.kw, stride[0], stride[1], pad[0], pad[1], cv.cout, 0),
-                  "alsep_nn_conv2d_f16")
+                                              cv.cout, 1, H, W, cv.cin, cv.cout, cv.kh, cv.kw, stride[0], stride[1], pad[0], pad[1], cv.cout, 0,
+                                              _lib.ptr(self._cws) if need else None, need), "alsep_nn_conv2d_f16")
         return y, Ho, Wo
 
     def _to_half(self, x):

@@ -336,9 +336,13 @@ int alsep_nn_instnorm_f16(alsep_ctx* ctx, const float* x, void* y, const float* 
                           void* workspace);
 /* Conv2d on v_mfma_f32_16x16x32_f16: x IEEE half channels-last [B, H, W, Cin], w IEEE half [Cout][KH][KW][Cin], float32 result into the
  * channel slice [y_coff, y_coff + Cout) of y [B, Ho, Wo, y_ctotal], optionally + R (float32 [pixels][ldr]: a block's shortcut branch).
- * Cin % 64 == 0, Cout % 4 == 0; no bias, no activation (this network has neither after a convolution). */
+ * Cin % 64 == 0, Cout % 4 == 0; no bias, no activation (this network has neither after a convolution).  Layers with few output tiles are
+ * split along K (partial tiles in `workspace`, summed in a fixed order): alsep_nn_conv2d_f16_workspace_bytes says how much they need. */
+int64_t alsep_nn_conv2d_f16_workspace_bytes(int64_t B, int H, int W, int Cin, int Cout, int KH, int KW, int stride_h, int stride_w, int pad_h,
+                                            int pad_w);
 int alsep_nn_conv2d_f16(alsep_ctx* ctx, const void* x, const void* w, float* y, const float* R, int64_t ldr, int64_t B, int H, int W, int Cin,
-                        int Cout, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, int y_ctotal, int y_coff);
+                        int Cout, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, int y_ctotal, int y_coff, void* workspace,
+                        int64_t workspace_bytes);
 /* y = a * b element-wise */
 int alsep_nn_mul(alsep_ctx* ctx, const float* a, const float* b, float* y, int64_t n);
 /* second half of ConvTranspose2d(kernel = stride = 2): g [H, W, 4*Cout] (1x1 conv, columns (dy*2+dx)*Cout + co) -> channel slice

@@ -42,6 +42,8 @@ def test_forward_one_chunk_vs_oracle(dev):
     (8, 12, 128, 64, 1, 1, 1, 0, False),        # the shortcut branch
     (10, 6, 64, 128, 2, 2, 2, 0, False),        # the down-scaling convolution
     (130, 3, 64, 4, 3, 3, 1, 1, True),          # more than one pixel tile, the narrowest channel slice
+    (8, 32, 768, 136, 3, 3, 1, 1, True),        # the bottleneck's shape class: few tiles, 108 K slices -> split along K, ragged last range
+    (4, 8, 1280, 64, 3, 3, 1, 1, False),        # 180 K slices on one tile
 ])
 def test_half_conv_vs_torch(dev, case):
     """alsep_nn_conv2d_f16 against torch.conv2d on the same rounded operands: only the float32 summation order differs"""
@@ -60,8 +62,11 @@ def test_half_conv_vs_torch(dev, case):
     y = dev.empty((Ho * Wo, Cout + 8))
     y.fill_(-7.0)
     rd = on(dev, res) if with_res else None
+    need = int(dev.lib.alsep_nn_conv2d_f16_workspace_bytes(1, H, W, Cin, Cout, KH, KW, st, st, pad, pad))
+    assert (need > 0) == (Cin >= 768)                                                    # only the long-K, few-tile layers are split
+    ws = dev.empty((max(need, 16),), torch.uint8)
     dev.check(dev.lib.alsep_nn_conv2d_f16(dev.handle, _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(y), _lib.ptr(rd) if with_res else None, Cout, 1, H, W, Cin,
-                                          Cout, KH, KW, st, st, pad, pad, Cout + 8, 4), "alsep_nn_conv2d_f16")
+                                          Cout, KH, KW, st, st, pad, pad, Cout + 8, 4, _lib.ptr(ws) if need else None, need), "alsep_nn_conv2d_f16")
     got = host(y)
     assert np.all(got[:, :4] == -7.0) and np.all(got[:, 4 + Cout:] == -7.0)             # only its channel slice is written
     assert np.max(np.abs(got[:, 4: 4 + Cout] - want.numpy())) < 2e-5 * max(1.0, float(want.abs().max()))
