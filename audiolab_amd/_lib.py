@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libalsep.so")
 F32, BF16, F16 = 0, 1, 2
 PROF_CONV3X3, PROF_CONV3X3_SMALL, PROF_TDF, PROF_PIX, PROF_POINTWISE, PROF_STFT, PROF_ISTFT = 1, 2, 3, 4, 5, 6, 7
 PROF_CONV3X3_REGW, PROF_CONV3X3_PIPE, PROF_CONV3X3_BIG, PROF_CONV3X3_BIG3 = 8, 9, 10, 11
-PROF_NN_GEMM, PROF_NN_CONV, PROF_NN_GEMM_H, PROF_NN_ATTN_H = 12, 13, 14, 15
+PROF_NN_GEMM, PROF_NN_CONV, PROF_NN_GEMM_H, PROF_NN_ATTN_H, PROF_NN_CONV_H = 12, 13, 14, 15, 16
 LAYOUT_REF, LAYOUT_NHWC = 0, 1
 ABI_VERSION = 1
 

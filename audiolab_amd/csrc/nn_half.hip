@@ -753,7 +753,7 @@ extern "C" int alsep_nn_conv2d_f16(alsep_ctx* ctx, const void* x, const void* w,
     if (n_wg > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d_f16: too many tiles");
     ConvHArgs p{(const _Float16*)x, (const _Float16*)w, y, R, npix, ldr, H, W, Cin, Cout, Ho, Wo, KH, KW, stride_h, stride_w, pad_h, pad_w, y_ctotal,
                 y_coff, splits, nk_per, (float*)workspace};
-    ProfScope prof(ctx, ALSEP_PROF_NN_CONV);
+    ProfScope prof(ctx, ALSEP_PROF_NN_CONV_H);
     const double K = (double)KH * KW * Cin;
     prof.work(2.0 * (double)npix * Cout * K, 2.0 * (double)B * H * W * Cin + 2.0 * Cout * K + (R ? 8.0 : 4.0) * (double)npix * Cout);
     ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)nn_conv_hh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHgLds));

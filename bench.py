@@ -162,6 +162,7 @@ def cpu_baseline(cfg, sd, mix_np, n_windows: int):
 def _kernel_classes(lib_mod):
     return [
         ("nn_gemm_h_kernel", lib_mod.PROF_NN_GEMM_H, PEAK_BF16_TFLOPS), ("nn_attn_h_kernel", lib_mod.PROF_NN_ATTN_H, PEAK_BF16_TFLOPS),
+        ("nn_conv_hh_kernel (f16 MFMA convolution)", lib_mod.PROF_NN_CONV_H, PEAK_BF16_TFLOPS),
         ("nn_gemm_tn_kernel / nn_bgemm_kernel (f32 MFMA)", lib_mod.PROF_NN_GEMM, PEAK_F32_TFLOPS),
         ("nn_conv2d_tiled_kernel / nn_conv2d_kernel (f32 MFMA)", lib_mod.PROF_NN_CONV, PEAK_F32_TFLOPS),
         ("conv3x3_bf16_m0_kernel / regw (level 0)", lib_mod.PROF_CONV3X3_REGW, PEAK_BF16_TFLOPS),
@@ -243,8 +244,9 @@ def other_workload(args) -> None:
     cpu_fn = None                                              # () -> cpu_baseline object, rank 0 at N = 1 only
 
     def one_lane_engine(**kw):                                 # the engine of the roofline passes: one unit at a time
-        saved = {k: os.environ.get(k) for k in ("ALSEP_RUNNER_LANES", "ALSEP_DEMUCS_LANES")}
+        saved = {k: os.environ.get(k) for k in ("ALSEP_RUNNER_LANES", "ALSEP_DEMUCS_LANES", "ALSEP_RUNNER_GRAPH")}
         os.environ["ALSEP_RUNNER_LANES"] = os.environ["ALSEP_DEMUCS_LANES"] = "1"
+        os.environ["ALSEP_RUNNER_GRAPH"] = "0"               # launches replayed from a HIP graph do not pass through the profiling brackets
         try:
             return Separator(ctx=ctx, allow_synthetic=True, **kw)
         finally:

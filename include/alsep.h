@@ -76,7 +76,8 @@ enum {
     ALSEP_PROF_NN_GEMM = 12,     /* nn_gemm_tn_kernel / nn_bgemm_kernel (float32 MFMA products of the transformer / Demucs / MDX23C families) */
     ALSEP_PROF_NN_CONV = 13,     /* nn_conv2d_tiled_kernel / vr_conv2d_kernel through alsep_nn_conv2d */
     ALSEP_PROF_NN_GEMM_H = 14,   /* nn_gemm_h_kernel (f16 MFMA Linear) */
-    ALSEP_PROF_NN_ATTN_H = 15    /* nn_attn_h_kernel (one-pass f16 attention) */
+    ALSEP_PROF_NN_ATTN_H = 15,   /* nn_attn_h_kernel (one-pass f16 attention) */
+    ALSEP_PROF_NN_CONV_H = 16    /* nn_conv_hh_kernel (f16 MFMA convolution) + its split-K reduction */
 };
 int alsep_profile_begin(alsep_ctx* ctx, int category);
 int alsep_profile_end(alsep_ctx* ctx, double* total_ms, int64_t* launches);
