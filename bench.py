@@ -243,18 +243,12 @@ def other_workload(args) -> None:
     seed_of = lambda name: int.from_bytes(hashlib.sha256(name.encode()).digest()[:4], "little")
     cpu_fn = None                                              # () -> cpu_baseline object, rank 0 at N = 1 only
 
-    def one_lane_engine(**kw):                                 # the engine of the roofline passes: one unit at a time
-        saved = {k: os.environ.get(k) for k in ("ALSEP_RUNNER_LANES", "ALSEP_DEMUCS_LANES", "ALSEP_RUNNER_GRAPH")}
+    def one_lane_engine(**kw):                                 # the engine of the roofline passes: one unit at a time, plain launches
+        # The runners read these when a model is LOADED (which may be after this returns), so they stay set: the timed region is over,
+        # and the engine it used has its runners already.  Launches replayed from a HIP graph would not pass through the profiling brackets.
         os.environ["ALSEP_RUNNER_LANES"] = os.environ["ALSEP_DEMUCS_LANES"] = "1"
-        os.environ["ALSEP_RUNNER_GRAPH"] = "0"               # launches replayed from a HIP graph do not pass through the profiling brackets
-        try:
-            return Separator(ctx=ctx, allow_synthetic=True, **kw)
-        finally:
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+        os.environ["ALSEP_RUNNER_GRAPH"] = "0"
+        return Separator(ctx=ctx, allow_synthetic=True, **kw)
 
     if wl == "demucs6":                                       # configs[2]: htdemucs 6-stem, 10 min, overlap 0.25, segments sharded
         seconds = args.seconds if args.seconds != TRACK_SECONDS else 600
@@ -703,8 +697,7 @@ def main() -> None:
             else:
                 p_preds[0].demix(mix[:, :2 * gen - 1])
             p_steps = 1 if name == "f32" else max(1, min(args.steps, 3))
-            if name != "f32":
-                [p.demix(mix) for p in p_preds]
+            [p.demix(mix) for p in p_preds]                  # untimed: workspaces of every model allocated, every kernel of this type loaded
             fence()
             t0 = time.perf_counter()
             for _ in range(p_steps):

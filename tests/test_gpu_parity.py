@@ -387,7 +387,7 @@ def test_half_storage_error_per_depth(ctx, storage):
         d = (a - b).astype(np.float64)
         return float(np.sqrt((d ** 2).sum() / (b.astype(np.float64) ** 2).sum()))
     rows = []
-    for depth in (1, 3, 5, 7, 9, 11):
+    for depth in (1, 3, 7, 11):                                # (5 and 9 keep their rows in HALF_BOUNDS: profiles/r03_half_storage_per_depth.txt)
         cfg = TDFNetConfig(num_blocks=depth)
         sd = synthetic_state_dict(cfg, seed=depth)
         g = mdx_oracle.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)

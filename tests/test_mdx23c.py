@@ -130,6 +130,17 @@ def test_six_way_drum_split_through_the_runner(dev):
     assert float(np.max(np.abs(got - want))) < 1e-4 * max(1.0, float(np.max(np.abs(want))))
 
 
+_FULL_FP32: dict = {}
+
+
+def _full_size_fp32_oracle():
+    from audiolab_amd.synth import synth_mix
+    if "w" not in _FULL_FP32:
+        ocfg = mo.MDX23CConfig()
+        _FULL_FP32["w"] = mo.forward(ocfg, mo.synthetic_state_dict(ocfg, 0), torch.from_numpy(synth_mix(ocfg.chunk_size))[None])[0].numpy()
+    return _FULL_FP32["w"]
+
+
 @pytest.mark.gpu
 def test_full_size_chunk_vs_oracle(gpu_ctx):
     """MDX23C-8KFFT-InstVoc_HQ's shape (n_fft 8192, dim_f 4096, 4 sub-bands, 5 scales, 128..768 channels) on one 5.9 s chunk"""
@@ -140,7 +151,7 @@ def test_full_size_chunk_vs_oracle(gpu_ctx):
     sd = mo.synthetic_state_dict(ocfg, 0)
     net = MDX23C(MDX23CConfig(), sd, ctx=gpu_ctx)
     x = torch.from_numpy(synth_mix(ocfg.chunk_size))
-    want = mo.forward(ocfg, sd, x[None])[0].numpy()
+    want = _full_size_fp32_oracle()
     gpu_ctx.synchronize()
     t0 = time.perf_counter()
     got = net.forward(x.cuda())
@@ -162,7 +173,7 @@ def test_full_size_chunk_half_precision(gpu_ctx):
     net = MDX23C(MDX23CConfig(), sd, ctx=gpu_ctx, precision="f16")
     x = torch.from_numpy(synth_mix(ocfg.chunk_size))
     want_h = mo.forward(ocfg, sd, x[None], half=True)[0].numpy()
-    want_f = mo.forward(ocfg, sd, x[None])[0].numpy()
+    want_f = _full_size_fp32_oracle()
     got = net.forward(x.cuda())
     gpu_ctx.synchronize()
     t0 = time.perf_counter()

@@ -65,6 +65,20 @@ def test_runner_vs_oracle(dev, kind, n):
     assert float(np.max(np.abs(got - want))) < 1e-4
 
 
+_FULL_FP32: dict = {}
+
+
+def _full_size_fp32_oracle(kind):
+    """the float32 oracle on the full-size chunk, computed once per kind for the two tests that need it (30-45 s of CPU each)"""
+    from audiolab_amd.synth import synth_mix
+    if kind not in _FULL_FP32:
+        ocfg = ro.RoformerConfig(kind=kind, depth=6 if kind == "mel" else 4)
+        sd = ro.synthetic_state_dict(ocfg, 0)
+        x = torch.from_numpy(synth_mix(ocfg.chunk_size))
+        _FULL_FP32[kind] = ro.forward(ocfg, sd, x[None])[0].numpy()
+    return _FULL_FP32[kind]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["mel", "bs"])
 def test_full_size_chunk_vs_oracle(gpu_ctx, kind):
@@ -77,7 +91,7 @@ def test_full_size_chunk_vs_oracle(gpu_ctx, kind):
     sd = ro.synthetic_state_dict(ocfg, 0)
     net = Roformer(RoformerConfig(**dataclasses.asdict(ocfg)), sd, ctx=gpu_ctx)
     x = torch.from_numpy(synth_mix(ocfg.chunk_size))
-    want = ro.forward(ocfg, sd, x[None])[0].numpy()
+    want = _full_size_fp32_oracle(kind)
     gpu_ctx.synchronize()
     t0 = time.perf_counter()
     got = net.forward(x.cuda())
@@ -274,7 +288,7 @@ def test_full_size_chunk_half_precision(gpu_ctx, kind):
     net = Roformer(RoformerConfig(**dataclasses.asdict(ocfg)), sd, ctx=gpu_ctx, precision="f16")
     x = torch.from_numpy(synth_mix(ocfg.chunk_size))
     want_h = ro.forward(ocfg, sd, x[None], half=True)[0].numpy()
-    want_32 = ro.forward(ocfg, sd, x[None])[0].numpy()
+    want_32 = _full_size_fp32_oracle(kind)
     net.forward(x.cuda())
     gpu_ctx.synchronize()
     t0 = time.perf_counter()
