@@ -394,6 +394,16 @@ def other_workload(args) -> None:
                 return _timed_cpu(lambda: ro.forward(ocfg, sd, x[None]), stems, ocfg.chunk_size / SR * (ocfg.chunk_size // ocfg.num_overlap) / ocfg.chunk_size,
                                   f"oracle/roformer_oracle.forward on one {ocfg.chunk_size / SR:.0f} s chunk (the runner advances "
                                   f"{ocfg.chunk_size // ocfg.num_overlap / SR:.0f} s per chunk: the rate counts that), torch-CPU fp32")
+        elif fam == "mdx23c":
+            def cpu_fn():
+                import dataclasses
+                from oracle import mdx23c_oracle as m3
+                ocfg = m3.MDX23CConfig(**dataclasses.asdict(MODEL_ROSTER[name][1]))
+                sd = m3.synthetic_state_dict(ocfg, seed_of(name))
+                x = torch.from_numpy(synth_mix(ocfg.chunk_size))
+                return _timed_cpu(lambda: m3.forward(ocfg, sd, x[None]), stems, (ocfg.chunk_size // ocfg.num_overlap) / SR,
+                                  f"oracle/mdx23c_oracle.forward on one {ocfg.chunk_size / SR:.1f} s chunk (the runner advances "
+                                  f"{ocfg.chunk_size // ocfg.num_overlap / SR:.2f} s per chunk: the rate counts that), torch-CPU fp32")
 
     def fence():
         if world > 1:
