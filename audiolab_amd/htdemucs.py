@@ -527,7 +527,7 @@ class DemucsRunner:
     (audio_separator defaults: shifts 2, overlap 0.25, segments of the model's training length), on the device."""
 
     def __init__(self, net: HTDemucs, shifts: int = 2, overlap: float = 0.25, seed: int = 0, sharded: bool = False, group=None,
-                 lanes: Optional[int] = None):
+                 lanes: Optional[int] = None, graphs: Optional[bool] = None):
         """``lanes``: (shift, segment) units in flight at once, each on a HIP stream of its own (default: 4 on a GPU, 1 elsewhere).  One
         segment of htdemucs_6s is ~450 launches of mostly small kernels (grids of 42-170 workgroups on 256 CUs): units are independent,
         so running a few side by side fills the chip; the weighted sums are kept per lane and added at the end."""
@@ -537,15 +537,42 @@ class DemucsRunner:
         if lanes is None:
             lanes = int(os.environ.get("ALSEP_DEMUCS_LANES", "4")) if self.ctx.device.type == "cuda" else 1
         self.lanes = max(1, int(lanes)) if self.ctx.device.type == "cuda" else 1
+        # ``graphs`` (default off; ``ALSEP_DEMUCS_GRAPH=1``): every lane captures ONE segment forward into a HIP graph on its own stream and
+        # replays it per unit, as the Roformer / MDX23C runner does.  Measured here it LOSES: htdemucs_6s, 10 min, 4 lanes: 1.70 s with plain
+        # launches, 2.05 s with graph replays (a segment is ~450 small kernels; the replay's per-node cost exceeds what the host saves).
+        if graphs is None:
+            graphs = os.environ.get("ALSEP_DEMUCS_GRAPH", "0") != "0"
+        self.graphs = bool(graphs) and self.ctx.device.type == "cuda"
         self._lane_nets: List[tuple] = []                      # [(HTDemucs view, torch stream)], built on first use
+        self._graphs: Dict[int, tuple] = {}                    # lane index -> (graph, static input, static output)
 
     def _lanes(self):
         if not self._lane_nets:
-            self._lane_nets = [(self.net, None)]
-            for _ in range(1, self.lanes):
+            first = 0 if self.graphs else 1                    # a capture needs a non-default stream: with graphs lane 0 gets its own too
+            if not self.graphs:
+                self._lane_nets = [(self.net, None)]
+            for _ in range(first, self.lanes):
                 st = torch.cuda.Stream(device=self.ctx.device)
                 self._lane_nets.append((self.net.on_stream(Context(self.ctx.device, stream=st.cuda_stream)), st))
         return self._lane_nets
+
+    def _forward_unit(self, k: int, lane_net, st, chunk: torch.Tensor) -> torch.Tensor:
+        """the network on one [2, seg] segment on lane k's stream: eagerly, or -- from the lane's second unit on -- as a graph replay"""
+        if not self.graphs:
+            return lane_net.forward(chunk)
+        if k not in self._graphs:
+            y = lane_net.forward(chunk)                         # eager first: plans, tables, workspaces outside a capture
+            st.synchronize()
+            static_in = chunk.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                static_out = lane_net.forward(static_in)
+            self._graphs[k] = (g, static_in, static_out)
+            return y
+        g, static_in, static_out = self._graphs[k]
+        static_in.copy_(chunk)
+        g.replay()
+        return static_out
 
     def units(self, length: int):
         """[(root offset of the view, view length, chunk offset in the view, chunk length, out offset)] over all shifts"""
@@ -591,11 +618,12 @@ class DemucsRunner:
         lanes = self._lanes()[: max(1, min(self.lanes, hi - lo))]
         # one weighted sum per (lane, shift pass), view coordinates; lane 0 runs on this context's stream, the others on their own
         accs = [[ctx.zeros((S * 2, L + max_shift)) for _ in range(n_pass)] for _ in lanes]
-        main = torch.cuda.current_stream(ctx.device) if len(lanes) > 1 else None
-        for _, st in lanes[1:]:
-            st.wait_stream(main)                                 # root, weight and the zeroed sums are ready
+        main = torch.cuda.current_stream(ctx.device) if (len(lanes) > 1 or self.graphs) else None
+        for _, st in lanes:
+            if st is not None:
+                st.wait_stream(main)                             # root, weight and the zeroed sums are ready
 
-        def run_unit(lane_net, lane_acc, unit):
+        def run_unit(k, lane_net, st, lane_acc, unit):
             p, offset, view_len, off, cl = unit
             lctx = lane_net.ctx
             delta = seg - cl
@@ -604,21 +632,26 @@ class DemucsRunner:
             cs, ce = max(0, start), min(total, end)
             chunk = lctx.zeros((2, seg))
             chunk[:, cs - start: cs - start + (ce - cs)] = root[:, cs:ce]
-            y = lane_net.forward(chunk)                                              # [S, 2, seg]
+            y = self._forward_unit(k, lane_net, st, chunk)                           # [S, 2, seg]
             src = C.c_void_p(y.data_ptr() + 4 * (delta // 2))
             dst = C.c_void_p(lane_acc[p].data_ptr() + 4 * off)
             lctx.check(lctx.lib.alsep_nn_vec_fma(lctx.handle, dst, src, _lib.ptr(weight), S * 2, cl, L + max_shift, seg), "alsep_nn_vec_fma")
 
         for i, unit in enumerate(units[lo:hi]):
-            lane_net, st = lanes[i % len(lanes)]
+            k = i % len(lanes)
+            lane_net, st = lanes[k]
             if st is None:
-                run_unit(lane_net, accs[0], unit)
+                run_unit(k, lane_net, st, accs[0], unit)
             else:
                 with torch.cuda.stream(st):                      # torch's allocator ties the lane's temporaries to its stream
-                    run_unit(lane_net, accs[i % len(lanes)], unit)
+                    run_unit(k, lane_net, st, accs[k], unit)
         acc = accs[0]
-        for k, (_, st) in enumerate(lanes[1:], start=1):
+        for k, (_, st) in enumerate(lanes):
+            if st is None:
+                continue
             main.wait_stream(st)
+            if k == 0:
+                continue
             for p in range(n_pass):
                 ctx.check(lib.alsep_axpby(h, 1.0, _lib.ptr(accs[k][p]), 1.0, _lib.ptr(acc[p]), acc[p].numel()), "alsep_axpby")
         # per pass: divide by the summed weights of that pass, cut the view back to the track, average the passes
