@@ -105,6 +105,14 @@ __device__ __forceinline__ unsigned long long clock_cycles() { return __builtin_
 __device__ __forceinline__ unsigned long long clock_100mhz() { return __builtin_amdgcn_s_memrealtime(); }
 
 // Extends the live range of a register value to this point (no code).
+// A per-lane integer the optimiser must treat as a NEW value from here on: values derived from it are recomputed after this point
+// instead of being kept alive (or spilled) across the code in between -- e.g. the lane / wave coordinates an epilogue needs again
+// after a main loop that has no register to spare.
+__device__ __forceinline__ int opaque_vgpr(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 template <typename T>
 __device__ __forceinline__ void keep_vgprs_live(const T& v) {
     asm volatile("" ::"v"(v));
@@ -190,6 +198,8 @@ __device__ __forceinline__ v2f cx_conj_add_pi(v2f a, v2f b) {
 
 // register budget of a kernel: exactly n waves per SIMD (512 / n VGPRs + AGPRs per lane)
 #define ALSEP_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+// the same with a template-dependent choice (the attribute accepts value-dependent constant expressions)
+#define ALSEP_WAVES_PER_EU_IF(cond, a, b) __attribute__((amdgpu_waves_per_eu((cond) ? (a) : (b), (cond) ? (a) : (b))))
 
 // A literal the optimiser must materialise HERE, in an SGPR (s_mov, scalar unit): loop-invariant literals of an
 // unrolled body are otherwise hoisted into one VGPR each and spill.

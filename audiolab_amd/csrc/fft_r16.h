@@ -518,8 +518,13 @@ template <> __device__ __forceinline__ void load_bin_g<bf16_t>(const ALSEP_GLOBA
 template <int R2> constexpr int istft_lds_bytes() { return 256 * (R2 + 1) * 8; }
 
 // grid (n_groups, n_chunks); each workgroup finishes `run` consecutive hop-blocks (as istft_regring_kernel).
+// Occupancy: two waves per SIMD (256 VGPRs) where that needs no scratch -- the channels-last, full-band variant of the bench.  The
+// variants with per-bin predicates or plane-strided loads (reference layout: HTDemucs, the model_run seam; dim_f < N/2) spill 47-195
+// registers at 256 and get 512 instead: a kernel that uses scratch must not run from several HIP streams at once on this stack (the
+// runners' lanes do exactly that; see nn_half.hip), and one wave per SIMD is the lesser cost for these off-bench geometries.
 template <int R2, int NBH, typename InT, int LAYOUT, bool FULL>   // FULL: dim_f >= N/2 (no zero-filled bins below Nyquist)
-__global__ void __launch_bounds__(kThreads) ALSEP_WAVES_PER_EU(2)
+__global__ void __launch_bounds__(kThreads)
+ALSEP_WAVES_PER_EU_IF(LAYOUT == ALSEP_LAYOUT_NHWC && FULL, 2, 1)
 istft_r16_kernel(const InT* __restrict__ spec, int dim_f, int T, const float2* __restrict__ tw_,
                  const float* __restrict__ env, int j_lo, int j_hi, int run,
                  float* __restrict__ out, int64_t out_ch_stride, int64_t out_chunk_stride, int64_t keep_lo,

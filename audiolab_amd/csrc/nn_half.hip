@@ -16,6 +16,7 @@
 //                        load, head gates in the epilogue, f16 out
 //   roformer_bandsplit_in_kernel   gather + RMSNorm of every band of a frame -> zero-padded f16 rows of one batched Linear
 #include "alsep_common.h"
+#include <alsep_gfx950_asm.h>
 
 namespace {
 
@@ -103,16 +104,20 @@ nn_gemm_hh_kernel(GemmHArgs p) {
     if (n0 >= Nb) return;                                                    // whole workgroups leave together
     // staging duty per slice: 1024 granules per operand, four per thread: rows sr + 32 h, k-group sg (8 lanes = one 128-byte line)
     const int sr = tid >> 3, sg = tid & 7;
-    const _Float16* ga[4];
-    const _Float16* gb[4];
+    // row addresses as one base per operand + 32-bit element offsets (the launcher checks rows * ld < 2^31): four 64-bit pointers per
+    // operand were the registers that pushed the kernel into scratch at 256 VGPRs -- and kernels that use scratch corrupt each
+    // other's spilled registers when they run concurrently from several HIP streams on this stack (the runner's lanes; measured:
+    // 3e-3 ... 6e-2 run-to-run differences in the stems, gone with one hardware queue or without scratch), so none of the kernels a
+    // lane launches may spill
+    unsigned oa[4], ob[4];
     bool va[4], vb[4];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const int ra = m0 + sr + 32 * h, rb = n0 + sr + 32 * h;
         va[h] = ra < p.M;
         vb[h] = rb < Nb;
-        ga[h] = a + (int64_t)(va[h] ? ra : 0) * p.lda;
-        gb[h] = b + (int64_t)(vb[h] ? rb : 0) * p.ldb;
+        oa[h] = (unsigned)((va[h] ? ra : 0) * (int)p.lda);
+        ob[h] = (unsigned)((vb[h] ? rb : 0) * (int)p.ldb);
     }
     f32x4 acc[4][4];
 #pragma unroll
@@ -128,8 +133,8 @@ nn_gemm_hh_kernel(GemmHArgs p) {
         const int ks = kq < p.K ? kq : 0;                                    // clamped: always a valid address (zeroed in lstore)
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            r.a[h] = *reinterpret_cast<const h16x8*>(ga[h] + ks);
-            r.b[h] = *reinterpret_cast<const h16x8*>(gb[h] + ks);
+            r.a[h] = *reinterpret_cast<const h16x8*>(a + (oa[h] + (unsigned)ks));
+            r.b[h] = *reinterpret_cast<const h16x8*>(b + (ob[h] + (unsigned)ks));
         }
     };
     // the registers are first TOUCHED here, an iteration after their loads were issued
@@ -258,25 +263,25 @@ nn_conv_hh_kernel(ConvHArgs p) {
     const int n0 = tn * kHgBN;
     const int K = p.KH * p.KW * p.Cin;
     const int sr = tid >> 3, sg = tid & 7;
-    const _Float16* xb[4];
-    const _Float16* gb[4];
-    int iy0[4], ix0[4];
-    bool va[4], vb[4];
+    // per staging row: image base as a 32-bit element offset, (iy0, ix0) packed into one register, weight row offset (the launcher
+    // checks that x and w have fewer than 2^31 elements): no 64-bit pointers per row -- the kernel must not spill (see the GEMM)
+    unsigned xo[4];
+    int yx0[4];                                                               // iy0 in the high half, ix0 in the low (both in [-32768, 32767])
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-        const int64_t pix = m0 + sr + 32 * h;
-        va[h] = pix < p.npix;
-        const int64_t pc = va[h] ? pix : 0;
-        const int64_t img = pc / ((int64_t)p.Ho * p.Wo);
-        const int rem = (int)(pc - img * p.Ho * p.Wo);
+        const int pix = (int)m0 + sr + 32 * h;                               // fewer than 2^31 pixels (launcher)
+        const bool va = pix < (int)p.npix;                                   // a row beyond the last pixel: iy0 far above the image, every tap "outside"
+        const int pc = va ? pix : 0;
+        const int img = pc / (p.Ho * p.Wo);
+        const int rem = pc - img * (p.Ho * p.Wo);
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        iy0[h] = oy * p.sh - p.ph;
-        ix0[h] = ox * p.sw - p.pw;
-        xb[h] = p.x + img * (int64_t)p.H * p.W * p.Cin + 8 * sg;
-        const int rb = n0 + sr + 32 * h;
-        vb[h] = rb < p.Cout;
-        gb[h] = p.w + (int64_t)(vb[h] ? rb : 0) * K + 8 * sg;
+        yx0[h] = ((va ? oy * p.sh - p.ph : -32000) << 16) | ((ox * p.sw - p.pw) & 0xffff);
+        xo[h] = (unsigned)img * (unsigned)(p.H * p.W * p.Cin) + 8u * (unsigned)sg;
     }
+    // weight rows beyond Cout read the last row: their products land in output columns that are never stored, so nothing needs zeroing
+    // there (nor in pixel rows beyond npix, nor in a slice beyond this workgroup's range, which is staged but never multiplied); only a
+    // tap outside the image must contribute zeros
+    const int wrow = n0 + sr;
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -295,21 +300,20 @@ nn_conv_hh_kernel(ConvHArgs p) {
         r.ok = 0;
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const int iy = iy0[h] + dy, ix = ix0[h] + dx;
-            const bool in = va[h] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const int iy = (yx0[h] >> 16) + dy, ix = (int)(short)(yx0[h] & 0xffff) + dx;
+            const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             r.ok |= (in ? 1u : 0u) << h;
-            const int64_t off = in ? ((int64_t)iy * p.W + ix) * p.Cin + ci0 : 0;
-            r.a[h] = *reinterpret_cast<const h16x8*>(xb[h] + off);
-            r.b[h] = *reinterpret_cast<const h16x8*>(gb[h] + k0);
+            const unsigned off = in ? (unsigned)((iy * p.W + ix) * p.Cin + ci0) : 0u;
+            r.a[h] = *reinterpret_cast<const h16x8*>(p.x + (xo[h] + off));
+            r.b[h] = *reinterpret_cast<const h16x8*>(p.w + ((unsigned)(min(wrow + 32 * h, p.Cout - 1) * K) + 8u * (unsigned)sg + (unsigned)k0));
         }
     };
-    auto lstore = [&](const HcStage& r, int buf, int kt) {
-        const bool in = kt < nk;
+    auto lstore = [&](const HcStage& r, int buf) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const int row = sr + 32 * h;
-            *reinterpret_cast<h16x8*>(As + (size_t)buf * kHgBM * kHgBK + hg_slot(row, sg)) = (in && ((r.ok >> h) & 1u)) ? r.a[h] : zh;
-            *reinterpret_cast<h16x8*>(Bs + (size_t)buf * kHgBN * kHgBK + hg_slot(row, sg)) = (vb[h] && in) ? r.b[h] : zh;
+            *reinterpret_cast<h16x8*>(As + (size_t)buf * kHgBM * kHgBK + hg_slot(row, sg)) = ((r.ok >> h) & 1u) ? r.a[h] : zh;
+            *reinterpret_cast<h16x8*>(Bs + (size_t)buf * kHgBN * kHgBK + hg_slot(row, sg)) = r.b[h];
         }
     };
     auto compute = [&](int buf) {
@@ -330,14 +334,14 @@ nn_conv_hh_kernel(ConvHArgs p) {
     HcStage r0, r1;
     gload(r0, 0);
     gload(r1, 1);
-    lstore(r0, 0, 0);
+    lstore(r0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
         gload(r0, kt + 2);
         __builtin_amdgcn_sched_barrier(0);
         compute(0);
         __builtin_amdgcn_sched_barrier(0);
-        lstore(r1, 1, kt + 1);
+        lstore(r1, 1);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 >= nk) break;
@@ -345,10 +349,15 @@ nn_conv_hh_kernel(ConvHArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         compute(1);
         __builtin_amdgcn_sched_barrier(0);
-        lstore(r0, 0, kt + 2);
+        lstore(r0, 0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
     }
+    {
+    // the epilogue's lane coordinates are recomputed from the thread index: kept alive across the main loop they were the one register
+    // too many (a kernel that touches scratch must not run on concurrent streams here, see the GEMM)
+    const int te = opaque_vgpr((int)threadIdx.x);
+    const int l15 = te & 15, lq = (te >> 4) & 3, wm = te >> 7, wn = (te >> 6) & 1;
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.splits > 1) {                                                      // partial sums; conv_splitk_reduce_kernel finishes
         float* part = p.part + (int64_t)sp * p.npix * p.Cout;
@@ -383,6 +392,7 @@ nn_conv_hh_kernel(ConvHArgs p) {
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + rv[j][r];
             *reinterpret_cast<f32x4*>(p.y + pix * p.y_ct + p.y_c0 + col) = v;
         }
+    }
     }
 }
 
@@ -677,6 +687,8 @@ extern "C" int alsep_nn_gemm_f16(alsep_ctx* ctx, const void* A, int64_t lda, int
         (((uintptr_t)A | (uintptr_t)W) & 15) || ((uintptr_t)C & (c_f16 ? 7 : 15)) || (bias && ((uintptr_t)bias & 15)) ||
         (R && (ldr % 4 || sr_b % 4 || ldr < N || ((uintptr_t)R & 15))))
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_gemm_f16: operands do not meet the alignment this kernel needs");
+    if ((int64_t)M * lda >= ((int64_t)1 << 31) || (int64_t)N * ldw >= ((int64_t)1 << 31))
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_gemm_f16: an operand of 2^31 or more elements per batch (32-bit row offsets)");
     GemmHArgs p{(const _Float16*)A, lda, sa_b, (const _Float16*)W, ldw, sw_b, C, ldc, sc_b, bias, bias_b, R, ldr, sr_b, M, N, K, alpha, n_per_batch};
     const int64_t n_wg = ceil_div64(N, kHgBN) * ceil_div64(M, kHgBM) * nb;
     if (n_wg > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_gemm_f16: too many tiles");
@@ -745,6 +757,8 @@ extern "C" int alsep_nn_conv2d_f16(alsep_ctx* ctx, const void* x, const void* w,
         (R && (ldr % 4 || ldr < Cout || ((uintptr_t)R & 15))))
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d_f16: operands do not meet the alignment this kernel needs (Cin %% 64, Cout %% 4)");
     const int64_t npix = B * Ho * Wo;
+    if (B * (int64_t)H * W * Cin >= ((int64_t)1 << 31) || (int64_t)Cout * KH * KW * Cin >= ((int64_t)1 << 31) || H > 32000 || W > 32000)
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_conv2d_f16: an operand of 2^31 or more elements, or an image side above 32 000 (32-bit / packed offsets)");
     int splits, nk_per;
     conv_h_split(npix, Cout, KH * KW * Cin, &splits, &nk_per);
     if (splits > 1 && (!workspace || ((uintptr_t)workspace & 15) || workspace_bytes < (int64_t)splits * npix * Cout * (int64_t)sizeof(float)))

@@ -507,13 +507,15 @@ class Roformer:
 
 def view_on_stream(net, ctx: Context):
     """A view of a network object that launches on another context (= another HIP stream of the same device): shared read-only
-    weights, its own per-call caches (every ``_plans`` / ``_ws`` / ``_pos`` attribute is reset)."""
+    weights, its own per-call caches and scratch (``_plans``, ``_pos``, ``_ws``, ``_cws``, and the lazily built device tables ``_rot`` /
+    ``_mask_cols``, which are written by a kernel on the stream that first needs them: a view sharing them could read a table another
+    lane's stream has not finished writing, and two lanes sharing a split-K workspace would overwrite each other's partial sums)."""
     import copy
     if ctx.device != net.ctx.device:
         raise AlsepError("view_on_stream: the other context must be on the same device")
     v = copy.copy(net)
     v.ctx = ctx
-    for name, fresh in (("_plans", {}), ("_pos", {}), ("_ws", None)):
+    for name, fresh in (("_plans", {}), ("_pos", {}), ("_ws", None), ("_cws", None), ("_rot", {}), ("_mask_cols", {})):
         if hasattr(v, name):
             setattr(v, name, fresh)
     return v
@@ -534,12 +536,25 @@ class RoformerRunner:
             raise AlsepError("one label per stem")
         import os
         gpu = self.ctx.device.type == "cuda"
-        if lanes is None:
-            lanes = int(os.environ.get("ALSEP_RUNNER_LANES", "4")) if gpu else 1
-        self.lanes = max(1, int(lanes)) if gpu else 1
         if graphs is None:
             graphs = os.environ.get("ALSEP_RUNNER_GRAPH", "1") != "0"
         self.graphs = bool(graphs) and gpu
+        # Half-precision networks run on ONE lane.  (1) With graph replay one lane is as fast as four (Mel-Band 120 s: 576 vs 564 ms, BS
+        # 1 101 vs 1 100, MDX23C 1 175 vs 1 247).  (2) It is the only safe setting found: while nn_gemm_hh_kernel / nn_conv_hh_kernel run
+        # on one HIP stream at two workgroups per CU (2 x 64 KiB LDS, 2 x 256 VGPRs per SIMD), FFT kernels running on ANOTHER stream
+        # produce whole wrong frames now and then (stems differ by 3e-3 ... 6e-2 from run to run; scripts/dbg/agg2.py reproduces it in
+        # seconds: 2-7 corrupted launches of 16).  Not the kernels' arithmetic -- each is bit-exact alone, an LDS canary kernel beside them
+        # stays intact, guard regions around their outputs stay intact, no scratch is involved, GPU_MAX_HW_QUEUES=1 or one workgroup per CU
+        # makes it vanish -- so it is treated as a property of this stack, and concurrency between these kernels and others is avoided.
+        half = getattr(net, "precision", "f32") == "f16" or bool(getattr(net, "half", False))
+        if lanes is None:
+            lanes = (1 if half else int(os.environ.get("ALSEP_RUNNER_LANES", "4"))) if gpu else 1
+        elif half and gpu and int(lanes) > 1 and os.environ.get("ALSEP_RUNNER_UNSAFE_LANES", "0") == "0":
+            import logging
+            logging.getLogger(__name__).warning("RoformerRunner: %d lanes asked for a half-precision network; using 1 (concurrent streams corrupt "
+                                                "FFT launches beside the f16 MFMA kernels on this stack; ALSEP_RUNNER_UNSAFE_LANES=1 overrides)", int(lanes))
+            lanes = 1
+        self.lanes = max(1, int(lanes)) if gpu else 1
         self._lane_nets: List[tuple] = []
         self._graphs: Dict[int, tuple] = {}                    # lane index -> (graph, static input, static output)
 

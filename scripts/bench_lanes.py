@@ -1,6 +1,8 @@
 import sys, time, torch, numpy as np, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from audiolab_amd import _lib
+if os.environ.get("DBG_LIB"):
+    _lib._LIB = _lib.bind(os.environ["DBG_LIB"])
 from audiolab_amd.engine import Separator
 from audiolab_amd.synth import synth_mix
 ctx = _lib.Context("cuda:0")

@@ -52,6 +52,7 @@ static inline unsigned long long clock_100mhz() { return 0; }
 
 template <typename T>
 static inline void keep_vgprs_live(const T&) {}
+static inline int opaque_vgpr(int v) { return v; }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 static inline v2f cx_add_mi(v2f a, v2f b) { return v2f{a.x + b.y, a.y - b.x}; }
@@ -64,6 +65,7 @@ static inline v2f cx_add_conj(v2f a, v2f b) { return v2f{a.x + b.x, a.y - b.y}; 
 static inline v2f cx_sub_conj_divi(v2f a, v2f b) { return v2f{a.y + b.y, b.x - a.x}; }
 static inline v2f cx_conj_add_pi(v2f a, v2f b) { return v2f{a.x - b.y, -a.y - b.x}; }
 #define ALSEP_WAVES_PER_EU(n)
+#define ALSEP_WAVES_PER_EU_IF(cond, a, b)
 static inline float sgpr_literal(float c) { return c; }
 static inline v2f cx_mul_p1(v2f a, v2f w) { return v2f{-(a.y * w.y), a.y * w.x}; }
 static inline v2f cx_mul_p2(v2f a, v2f w, v2f t) { return v2f{fmaf(a.x, w.x, t.x), fmaf(a.x, w.y, t.y)}; }

@@ -190,6 +190,32 @@ def test_full_size_chunk_half_precision(gpu_ctx):
     assert e_h < 0.9 * cost + 1e-5 * max(1.0, peak)
 
 
+@pytest.mark.gpu
+def test_runner_default_configuration_is_reproducible_full_size(gpu_ctx):
+    """the full-size network through the chunked runner in its DEFAULT configuration (half mode: one lane replaying a HIP graph; float32
+    mode: four lanes on their own streams) against one lane with plain launches: the same kernels on the same chunks, so the stems agree
+    up to the order of the per-lane sums (float32: ~1e-7 of the peak), run after run.  Half-precision networks are held to one lane because
+    FFT launches beside the f16 MFMA kernels on another stream come out wrong now and then on this stack (roformer.RoformerRunner)."""
+    from audiolab_amd.mdx23c import MDX23C, MDX23CConfig
+    from audiolab_amd.roformer import RoformerRunner
+    from audiolab_amd.synth import synth_mix
+    sd = mo.synthetic_state_dict(mo.MDX23CConfig(), 0)
+    mix = torch.from_numpy(synth_mix(700000)).cuda()
+    for prec in ("f16", "f32"):
+        net = MDX23C(MDX23CConfig(), sd, ctx=gpu_ctx, precision=prec)
+        one = RoformerRunner(net, ("Vocals", "Instrumental"), lanes=1, graphs=False).separate(mix)
+        dflt = RoformerRunner(net, ("Vocals", "Instrumental"))
+        assert dflt.lanes == (1 if prec == "f16" else 4) and dflt.graphs
+        peak = float(one["Vocals"].abs().max())
+        for rep in range(3):                                                             # from the second pass on every lane replays its graph
+            out = dflt.separate(mix)
+            for k in one:
+                assert float((one[k] - out[k]).abs().max()) < 2e-6 * peak, (prec, k, rep, float((one[k] - out[k]).abs().max()), peak)
+        assert peak > 1e-3
+    asked = RoformerRunner(MDX23C(MDX23CConfig(), sd, ctx=gpu_ctx, precision="f16"), ("Vocals", "Instrumental"), lanes=4)
+    assert asked.lanes == 1                                                              # refused with a warning
+
+
 def test_engine_roster_entries(dev):
     """the reference's two MDX23C model files resolve to this network in the default roster (ensemble slot 4: Vocals / Instrumental;
     drum-kit splitter: the six labels stem_separator.py:563-574 matches), and the orchestrator's drum stage consumes the six outputs"""

@@ -65,6 +65,27 @@ def test_runner_vs_oracle(dev, kind, n):
     assert float(np.max(np.abs(got - want))) < 1e-4
 
 
+@pytest.mark.gpu
+def test_runner_default_configuration_is_reproducible_full_size(gpu_ctx):
+    """the full-width Mel-Band network through the chunked runner in its default configuration (half mode: one lane + HIP graph; float32
+    mode: four lanes) against one lane with plain launches, three passes each: the same stems up to the order of the per-lane sums"""
+    from audiolab_amd.roformer import Roformer, RoformerConfig, RoformerRunner
+    from audiolab_amd.synth import synth_mix
+    ocfg = ro.RoformerConfig(kind="mel", depth=2)
+    sd = ro.synthetic_state_dict(ocfg, 0)
+    mix = torch.from_numpy(synth_mix(44100 * 40)).cuda()
+    for prec in ("f16", "f32"):
+        net = Roformer(RoformerConfig(**dataclasses.asdict(ocfg)), sd, ctx=gpu_ctx, precision=prec)
+        one = RoformerRunner(net, ("Vocals",), lanes=1, graphs=False).separate(mix)
+        dflt = RoformerRunner(net, ("Vocals",))
+        assert dflt.lanes == (1 if prec == "f16" else 4)
+        peak = float(one["Vocals"].abs().max())
+        for rep in range(3):
+            out = dflt.separate(mix)
+            assert float((one["Vocals"] - out["Vocals"]).abs().max()) < 2e-6 * peak, (prec, rep, float((one["Vocals"] - out["Vocals"]).abs().max()), peak)
+        assert peak > 1e-3
+
+
 _FULL_FP32: dict = {}
 
 
