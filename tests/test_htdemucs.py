@@ -68,6 +68,26 @@ def test_htdemucs_6s_full_size_segment_vs_oracle(gpu_ctx):
     assert np.max(np.abs(want)) > 1e-2 and err < 1e-4
 
 
+@pytest.mark.gpu
+def test_runner_lanes_reproducible_full_size(gpu_ctx):
+    """htdemucs_6s at full size through the runner: the default four lanes (units in flight on HIP streams of their own) against one
+    lane, three passes -- the same kernels on the same units, so the stems agree up to the order of the per-lane sums (the guard
+    against lanes sharing scratch or kernels interfering across streams: DESIGN section 4d)"""
+    from audiolab_amd.htdemucs import DemucsRunner, HTDemucs, HTDemucsConfig
+    cfg = HTDemucsConfig()
+    net = HTDemucs(cfg, ho.synthetic_state_dict(ho.HTDemucsConfig(), 0), ctx=gpu_ctx)
+    mix = torch.randn(2, 44100 * 25, generator=torch.Generator().manual_seed(4)).cuda() * 0.3
+    one = DemucsRunner(net, shifts=1, overlap=0.25, seed=0, lanes=1).separate(mix)
+    four = DemucsRunner(net, shifts=1, overlap=0.25, seed=0)
+    assert four.lanes == 4
+    peak = max(float(v.abs().max()) for v in one.values())
+    for rep in range(3):
+        out = four.separate(mix)
+        for k in one:
+            assert float((one[k] - out[k]).abs().max()) < 2e-6 * peak, (k, rep, float((one[k] - out[k]).abs().max()), peak)
+    assert peak > 1e-3
+
+
 def test_odd_lengths_pad_the_time_branch(dev):
     """segment lengths that are not multiples of stride**depth: every time-branch layer zero-pads its input (HEncLayer) and the
     decoder crops back to the recorded lengths"""
