@@ -743,6 +743,27 @@ static int launch_istft(alsep_ctx* ctx, const alsep_plan* p, const void* spec, i
             return ALSEP_OK;
         }
     }
+    if constexpr (N == 7680) {
+        static const int r30_on = [] { const char* e = getenv("ALSEP_ISTFT_R16"); return e ? atoi(e) : 1; }();
+        if (p->hop == 1024 && r30_on) {                      // the vocal models' geometry: three passes in the order 16, 16, 30
+            const size_t lds_r = r16::istft_r30_lds_bytes();
+            auto kern = r16::istft_r30_kernel<8, InT, LAYOUT>;
+            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+            static const int run_env = [] { const char* e = getenv("ALSEP_ISTFT_RUN"); return e ? atoi(e) : 0; }();
+            const int run = run_env > 0 ? run_env : istft_pick_run(j_hi - j_lo, Q, n_chunks, 2 * device_cu_count(ctx));
+            const int groups_r = (j_hi - j_lo + run - 1) / run;
+            for (int64_t b0 = 0; b0 < n_chunks; b0 += 32768) {
+                const int64_t nb = std::min<int64_t>(32768, n_chunks - b0);
+                const int64_t spec_off = b0 * 4 * (int64_t)p->dim_f * p->dim_t;
+                hipLaunchKernelGGL(kern, dim3(groups_r, (unsigned)nb), dim3(r16::kThreads), lds_r, ctx->stream, (const InT*)spec + spec_off,
+                                   p->dim_f, p->dim_t, (const float2*)p->tw, (const float*)p->env, j_lo, j_hi, run,
+                                   out + b0 * out_chunk_stride, out_ch_stride, out_chunk_stride, keep_lo, keep_hi,
+                                   out_limit - b0 * out_chunk_stride);
+            }
+            ALSEP_LAUNCH_CHECK(ctx, "istft_r30_kernel");
+            return ALSEP_OK;
+        }
+    }
     if constexpr (N % 1024 == 0 || N == 7680) {
         if (p->hop == 1024) {                                // production geometry: register ring, 3 workgroups per CU
             const size_t lds_r = sizeof(float2) * (size_t)N;

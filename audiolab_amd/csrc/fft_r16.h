@@ -722,4 +722,193 @@ istft_r16_kernel(const InT* __restrict__ spec, int dim_f, int T, const float2* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// iSTFT + overlap-add for n_fft = 7680 (the UVR vocal models' geometry), hop 1024: passes in the order 16, 16, 30.
+// The register overlap-add needs the LAST pass's outputs of a thread to be samples tid + 128 m: with radix 30 last (P = 256) butterfly
+// i in {tid, tid + 128} leaves samples i + 256 q = tid + 128 (bbit + 2 q), m < 60 (the accumulator is padded to 64 = 8 hop blocks of 8).
+// Pass A (radix 16, P = 1, inputs 480 apart) builds its inputs straight from the spectrogram with the Hermitian extension folded in,
+// as the 6144 kernel does: butterflies j and 480 - j are one work item whose 16 loaded bins j + 480 r and (480 - j) + 480 r (r < 8)
+// are everything both need (u_j[r >= 8] = conj Z[N - k] of the other's bins); j = 0 and j = 240 pair with themselves.  241 items on
+// 128 threads.  Passes A and B use the STFT kernel's LDS images (rows of 16 padded to 18; then plain).  y = conj(FFT(conj Z)) / N.
+// One wave per SIMD (the 64-entry accumulator + a radix-30 butterfly with its twiddles exceed 256 registers; no scratch).
+// ------------------------------------------------------------------------------------------------
+constexpr int istft_r30_lds_bytes() { return 480 * 18 * 8; }     // pass-A image 69 120 B >= the plain 7680 x 8 B of pass B
+
+template <int NBH, typename InT, int LAYOUT>
+__global__ void __launch_bounds__(kThreads) ALSEP_WAVES_PER_EU(1)
+istft_r30_kernel(const InT* __restrict__ spec, int dim_f, int T, const float2* __restrict__ tw_,
+                 const float* __restrict__ env, int j_lo, int j_hi, int run,
+                 float* __restrict__ out, int64_t out_ch_stride, int64_t out_chunk_stride, int64_t keep_lo,
+                 int64_t keep_hi, int64_t out_limit) {
+    constexpr int N = 7680, NT = kThreads, HOP = 128 * NBH, M = 480, NB = 4, RW = 18, NA = 64, R3 = 30;
+    constexpr int Q = (N + HOP - 1) / HOP;
+    static_assert(NT == 128 && NBH == 8, "geometry");
+    const v2f* __restrict__ tw = reinterpret_cast<const v2f*>(tw_);
+    v2f* buf = reinterpret_cast<v2f*>(alsep_smem);
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.y;
+    const int j0 = j_lo + blockIdx.x * run;
+    const int j1 = min(j0 + run, j_hi);
+    if (j0 >= j1) return;
+    v2f acc[NA];
+#pragma unroll
+    for (int m = 0; m < NA; ++m) acc[m] = mk(0.f, 0.f);
+    const v2f wt = tw[tid];                                   // (cos, -sin)(2 pi tid / N): the window, as in the 6144 kernel
+    const v2f wB1 = tw[(tid & 15) * (N / 256)];               // W_256^k of pass B
+    const int64_t plane = (int64_t)dim_f * T;
+
+    const int t_start = max(0, j0 - Q + 1);
+    for (int t = t_start; t < j1; ++t) {
+        if (t < T) {
+            // one bin (L, R) = (L_re + i L_im, R_re + i R_im); zero at and above dim_f (clamped address + select: no branch around a load)
+            auto fetch = [&](int k, v2f& L, v2f& R) {
+                const int kc = min(k, dim_f - 1);
+                if (LAYOUT == ALSEP_LAYOUT_NHWC) {
+                    load_bin<InT>(spec + ((b * T + t) * (int64_t)dim_f + kc) * 4, L, R);
+                } else {
+                    const InT* sp = spec + b * 4 * plane + (int64_t)kc * T + t;
+                    L = mk(to_f32(sp[0]), to_f32(sp[plane]));
+                    R = mk(to_f32(sp[2 * plane]), to_f32(sp[3 * plane]));
+                }
+                if (k >= dim_f) { L = mk(0.f, 0.f); R = mk(0.f, 0.f); }
+            };
+            auto store_row = [&](int j, v2f (&u)[16]) {
+                dft16(u);
+                f32x4* row = reinterpret_cast<f32x4*>(buf + j * RW);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const v2f lo = u[dft16_slot(2 * g)], hi = u[dft16_slot(2 * g + 1)];
+                    row[g] = f32x4{lo.x, lo.y, hi.x, hi.y};
+                }
+            };
+            // ---- pass A
+#pragma unroll 1
+            for (int it = 0; it < 2; ++it) {
+                const int j = tid + NT * it;                      // work item: butterflies j and 480 - j
+                if (j > M / 2) break;                             // 241 items
+                const bool self = (j == 0) || (j == M / 2);
+                v2f za[8], ma[8], zb[8], mb[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    v2f L, R;
+                    fetch(j + M * r, L, R);
+                    if (j == 0 && r == 0) { L.y = 0.f; R.y = 0.f; }   // c2r ignores Im of DC
+                    za[r] = cx_conj_add_pi(L, R);                 // conj Z[k]
+                    ma[r] = cx_add_mi(L, R);                      // conj Z[N - k]
+                }
+                if (!self) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        v2f L, R;
+                        fetch((M - j) + M * r, L, R);
+                        zb[r] = cx_conj_add_pi(L, R);
+                        mb[r] = cx_add_mi(L, R);
+                    }
+                }
+                v2f u[16];
+                if (j == 0) {
+                    // inputs 480 r: r < 8 direct, r = 8 the Nyquist bin (Im ignored), r > 8 the mirror of bin 480 (16 - r)
+                    v2f nyq = mk(0.f, 0.f);
+                    if (dim_f > N / 2) {
+                        v2f L, R;
+                        fetch(N / 2, L, R);
+                        nyq = mk(L.x, -R.x);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) u[r] = za[r];
+                    u[8] = nyq;
+#pragma unroll
+                    for (int r = 9; r < 16; ++r) u[r] = ma[16 - r];
+                    store_row(0, u);
+                } else if (j == M / 2) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { u[r] = za[r]; u[8 + r] = ma[7 - r]; }
+                    store_row(M / 2, u);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { u[r] = za[r]; u[8 + r] = mb[7 - r]; }      // index j + 480 (8 + r) = N - ((480 - j) + 480 (7 - r))
+                    store_row(j, u);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { u[r] = zb[r]; u[8 + r] = ma[7 - r]; }
+                    store_row(M - j, u);
+                }
+            }
+            __syncthreads();
+            // ---- pass B: radix 16, P = 16 (the STFT kernel's pass B on the padded rows)
+            {
+                v2f u[NB][16];
+                const int k = tid & 15;
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) {
+                    const int i = tid + NT * bb;
+                    const v2f* src = buf + (i >> 4) * RW + k;
+                    if (i < M) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) u[bb][r] = src[(M / 16) * RW * r];
+                    }
+                }
+                v2f w[16];
+                twiddle_powers<16>(wB1, w);
+                __syncthreads();                                  // every read of the pass-A image is done
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb) {
+                    const int i = tid + NT * bb;
+                    if (i < M) {
+                        cx_mul_n<16>(u[bb], w);
+                        dft16(u[bb]);
+                        v2f* dst = buf + (i >> 4) * 256 + k;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) dst[16 * q] = u[bb][dft16_slot(q)];
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- pass C: radix 30, P = 256; butterfly i = tid + 128 bbit leaves sample i + 256 q = tid + 128 (bbit + 2 q)
+#pragma unroll
+            for (int bbit = 0; bbit < 2; ++bbit) {
+                const int i = tid + NT * bbit;
+                v2f z[R3];
+#pragma unroll
+                for (int r = 0; r < R3; ++r) z[r] = buf[i + 256 * r];
+                v2f w[R3];
+                twiddle_powers<R3>(tw[i], w);
+                cx_mul_n<R3>(z, w);
+                LastDft<R3>::run(z);
+#pragma unroll
+                for (int q = 0; q < R3; ++q) {
+                    const int m = bbit + 2 * q;
+                    constexpr double kA = 6.283185307179586476925286766559 * (double)NT / (double)N;
+                    const float cm = (float)(-0.5 / N * __builtin_cos(kA * m)), sm = (float)(-0.5 / N * __builtin_sin(kA * m));
+                    const float wv = fmaf(wt.x, sgpr_literal(cm), fmaf(wt.y, sgpr_literal(sm), (float)(0.5 / N)));
+                    acc[m] += z[LastDft<R3>::slot(q)] * wv;      // conj applied at the store
+                }
+            }
+            __syncthreads();                                      // buf is rewritten by the next frame
+        }
+        if (t >= j0) {                                            // hop-block j = t is complete
+            float e[NBH];
+            const int64_t p_last = (int64_t)(T - 1) * HOP + N - 1;
+#pragma unroll
+            for (int j = 0; j < NBH; ++j) e[j] = env[min((int64_t)t * HOP + j * NT + tid, p_last)];
+#pragma unroll
+            for (int j = 0; j < NBH; ++j) {
+                const int64_t p = (int64_t)t * HOP + j * NT + tid;
+                const int64_t sidx = p - N / 2;
+                if (sidx >= keep_lo && sidx < keep_hi) {
+                    const int64_t o = b * out_chunk_stride + (sidx - keep_lo);
+                    if (o < out_limit) {
+                        const float r = 1.0f / e[j];
+                        out[o] = acc[j].x * r;
+                        out[out_ch_stride + o] = -acc[j].y * r;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NA - NBH; ++m) acc[m] = acc[m + NBH];
+#pragma unroll
+        for (int m = NA - NBH; m < NA; ++m) acc[m] = mk(0.f, 0.f);
+    }
+}
+
 }  // namespace r16
