@@ -131,6 +131,8 @@ _SIGNATURES = {
     "alsep_nn_instnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "alsep_nn_instnorm_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_int,
                                         C.c_void_p]),
+    "alsep_nn_instnorm_f16_t": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int,
+                                          C.c_void_p]),
     "alsep_nn_conv2d_f16_workspace_bytes": (C.c_int64, [C.c_int64] + [C.c_int] * 10),
     "alsep_nn_conv2d_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64] + [C.c_int] * 12 +
                             [C.c_void_p, C.c_int64]),

@@ -766,6 +766,42 @@ nn_chan_norm_apply_h_kernel(const float* __restrict__ x, _Float16* __restrict__ 
         *reinterpret_cast<h16x4*>(y + 4 * i) = o;
     }
 }
+// the same with the half result stored TRANSPOSED per frame: x [T][F][C] float32 -> y [T][C][F] IEEE half, i.e. frequency-contiguous rows
+// per (frame, channel): the "weight-side" operand of the TDF Linear over the frequency axis as nn_gemm_hh_kernel wants it (both operands
+// K-contiguous; the Linear is then one batched GEMM per frame with the shared weight matrix as A).  32 x 32 tiles through LDS: reads
+// contiguous along c, writes contiguous along f.
+__global__ void __launch_bounds__(kNnThreads)
+nn_chan_norm_apply_ht_kernel(const float* __restrict__ x, _Float16* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                             const float* __restrict__ stats, int F, int C, int act) {
+    float* tile = reinterpret_cast<float*>(alsep_smem);      // [32][33]
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int f0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int64_t t = blockIdx.z;
+    const int c = c0 + tx;
+    float mean = 0.f, rstd = 0.f, g = 1.f, b = 0.f;
+    if (c < C) {
+        mean = stats[2 * c];
+        rstd = stats[2 * c + 1];
+        if (gamma) { g = gamma[c]; b = beta[c]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = f0 + ty + 8 * j;
+        float v = 0.f;
+        if (f < F && c < C) {
+            v = (x[(t * F + f) * C + c] - mean) * rstd;
+            if (gamma) v = fmaf(v, g, b);
+            if (act == 3) v = gelu_erf(v);
+        }
+        tile[(ty + 8 * j) * 33 + tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cc = c0 + ty + 8 * j, f = f0 + tx;
+        if (cc < C && f < F) y[(t * C + cc) * F + f] = (_Float16)tile[tx * 33 + ty + 8 * j];
+    }
+}
 __global__ void __launch_bounds__(kNnThreads)
 nn_mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kNnThreads) y[i] = a[i] * b[i];
@@ -1239,6 +1275,20 @@ extern "C" int alsep_nn_instnorm_f16(alsep_ctx* ctx, const float* x, void* y, co
     hipLaunchKernelGGL(nn_chan_norm_apply_h_kernel, dim3(ew_grid(P * C / 4)), dim3(kNnThreads), 0, ctx->stream, x, (_Float16*)y, gamma, beta, stats,
                        P * C / 4, C, act);
     ALSEP_LAUNCH_CHECK(ctx, "nn_instnorm_f16 kernels");
+    return ALSEP_OK;
+}
+
+// InstanceNorm2d (+ GELU) of x [T][F][C] with the IEEE-half result stored as [T][C][F] (see nn_chan_norm_apply_ht_kernel)
+extern "C" int alsep_nn_instnorm_f16_t(alsep_ctx* ctx, const float* x, void* y, const float* gamma, const float* beta, int64_t T, int F, int C,
+                                       float eps, int act, void* workspace) {
+    ALSEP_ENTER(ctx);
+    NN_ARG(ctx && x && y && workspace && T > 0 && T < 65536 && F > 0 && C > 0 && (act == 0 || act == 3) && ((gamma == nullptr) == (beta == nullptr)) &&
+               ((uintptr_t)workspace & 7) == 0,
+           "alsep_nn_instnorm_f16_t");
+    const float* stats = instnorm_stats(ctx, x, T * F, C, eps, workspace);
+    hipLaunchKernelGGL(nn_chan_norm_apply_ht_kernel, dim3((unsigned)ceil_div64(F, 32), (unsigned)ceil_div64(C, 32), (unsigned)T), dim3(kNnThreads),
+                       32 * 33 * sizeof(float), ctx->stream, x, (_Float16*)y, gamma, beta, stats, F, C, act);
+    ALSEP_LAUNCH_CHECK(ctx, "nn_instnorm_f16_t kernels");
     return ALSEP_OK;
 }
 

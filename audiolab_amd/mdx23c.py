@@ -116,7 +116,9 @@ class MDX23C:
         ``use_autocast=True``).  The convolutions of the TFC-TDF blocks and of the down- / up-scaling layers -- 85 % of the arithmetic --
         read IEEE-half activations (written in that type by the InstanceNorm + GELU kernel in front of them; the shortcut branch's raw
         input by a conversion pass) and IEEE-half weights on v_mfma_f32_16x16x32_f16; their results, the residual stream, the statistics,
-        the TDF linears and the first / final 1x1 convolutions stay float32.  Storage-mode oracle: oracle/mdx23c_oracle.forward(half=True)."""
+        the first / final 1x1 convolutions stay float32.  The TDF linears over the frequency axis run on the f16 GEMM as well (operands
+        rounded to half, float32 result with the residual fused) wherever the level's frequency count is a multiple of 32 (every level of
+        the published models).  Storage-mode oracle: oracle/mdx23c_oracle.forward(half=True)."""
         if precision not in ("f32", "f16"):
             raise AlsepError(f"MDX23C: precision {precision!r} (f32, f16)")
         self.half = precision == "f16"
@@ -147,7 +149,9 @@ class MDX23C:
             out = []
             for i in range(cfg.num_blocks_per_scale):
                 q = f"{p}.blocks.{i}"
+                lh = (lambda k: v(k).to(torch.float16)) if self.half else (lambda k: None)
                 out.append(dict(short=conv(q + ".shortcut.weight"), n1=(v(q + ".tfc1.0.weight"), v(q + ".tfc1.0.bias")), c1=conv(q + ".tfc1.2.weight"),
+                                l1h=lh(q + ".tdf.2.weight"), l2h=lh(q + ".tdf.5.weight"),
                                 nt1=(v(q + ".tdf.0.weight"), v(q + ".tdf.0.bias")), l1=v(q + ".tdf.2.weight"),
                                 nt2=(v(q + ".tdf.3.weight"), v(q + ".tdf.3.bias")), l2=v(q + ".tdf.5.weight"),
                                 n2=(v(q + ".tfc2.0.weight"), v(q + ".tfc2.0.bias")), c2=conv(q + ".tfc2.2.weight")))
@@ -213,6 +217,27 @@ class MDX23C:
                                               _lib.ptr(self._cws) if need else None, need), "alsep_nn_conv2d_f16")
         return y, Ho, Wo
 
+    def _norm_act_t(self, x, T, Fw, Cn, gb):
+        """InstanceNorm2d + GELU of x [T * Fw, Cn] with the IEEE-half result stored [T][Cn][Fw] (the TDF Linear's operand layout)"""
+        ctx = self.ctx
+        need = int(ctx.lib.alsep_nn_instnorm_workspace_bytes(T * Fw, Cn))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = ctx.empty((max(need, 1 << 16),), torch.uint8)
+        y = ctx.empty((T, Cn, Fw), torch.float16)
+        ctx.check(ctx.lib.alsep_nn_instnorm_f16_t(ctx.handle, _lib.ptr(x), _lib.ptr(y), _lib.ptr(gb[0]), _lib.ptr(gb[1]), T, Fw, Cn, 1e-5, ACT_GELU,
+                                                  _lib.ptr(self._ws)), "alsep_nn_instnorm_f16_t")
+        return y
+
+    def _linear_f_h(self, xt, T, Fin, Cn, wh, res=None):
+        """Linear over the frequency axis in half precision: y[t, f', c] = sum_f w[f', f] xt[t, c, f] (+ res[t, f', c]) as ONE batched f16
+        GEMM -- per frame A = the shared weight matrix [Fo, Fin], "W" = the frame's [Cn, Fin] rows, float32 result [Fo, Cn]"""
+        ctx = self.ctx
+        Fo = int(wh.shape[0])
+        y = ctx.empty((T * Fo, Cn))
+        ctx.check(ctx.lib.alsep_nn_gemm_f16(ctx.handle, _lib.ptr(wh), Fin, 0, _lib.ptr(xt), Fin, Cn * Fin, _lib.ptr(y), 0, Cn, Fo * Cn, None, 0,
+                                            _lib.ptr(res) if res is not None else None, Cn, Fo * Cn, T, Fo, Cn, Fin, 1.0, 0, None), "alsep_nn_gemm_f16")
+        return y, Fo
+
     def _to_half(self, x):
         ctx = self.ctx
         y = ctx.empty(tuple(x.shape), torch.float16)
@@ -242,9 +267,13 @@ class MDX23C:
             if self.half:
                 s, _, _ = self._conv_h(self._to_half(x), T, Fw, L["short"])
                 x, _, _ = self._conv_h(self._norm_act(x, P, cin, L["n1"], True), T, Fw, L["c1"], pad=(1, 1))
-                t, Fh = self._linear_f(self._norm_act(x, P, c, L["nt1"]), T, Fw, c, L["l1"])
-                t, _ = self._linear_f(self._norm_act(t, T * Fh, c, L["nt2"]), T, Fh, c, L["l2"])
-                x = self._add(x, t, P * c)
+                if Fw % 32 == 0:                                # TDF linears on the f16 GEMM (K = the frequency count, in whole 8-groups)
+                    t, Fh = self._linear_f_h(self._norm_act_t(x, T, Fw, c, L["nt1"]), T, Fw, c, L["l1h"])
+                    x, _ = self._linear_f_h(self._norm_act_t(t, T, Fh, c, L["nt2"]), T, Fh, c, L["l2h"], res=x)       # x + tdf(x), fused
+                else:
+                    t, Fh = self._linear_f(self._norm_act(x, P, c, L["nt1"]), T, Fw, c, L["l1"])
+                    t, _ = self._linear_f(self._norm_act(t, T * Fh, c, L["nt2"]), T, Fh, c, L["l2"])
+                    x = self._add(x, t, P * c)
                 x, _, _ = self._conv_h(self._norm_act(x, P, c, L["n2"], True), T, Fw, L["c2"], pad=(1, 1), res=s)      # + shortcut, fused
                 continue
             s, _, _ = self._conv(x, T, Fw, L["short"])

@@ -335,6 +335,10 @@ int alsep_nn_instnorm(alsep_ctx* ctx, const float* x, float* y, const float* gam
  * stem_separator.py:106 use_autocast=True: convolutions in half, normalisation in float32) */
 int alsep_nn_instnorm_f16(alsep_ctx* ctx, const float* x, void* y, const float* gamma, const float* beta, int64_t P, int C, float eps, int act,
                           void* workspace);
+/* the same for x [T][F][C] with the half result stored [T][C][F] (frequency-contiguous rows per frame and channel): the operand layout
+ * of the TDF Linear over the frequency axis as one batched alsep_nn_gemm_f16 per frame (A = the shared weight matrix) */
+int alsep_nn_instnorm_f16_t(alsep_ctx* ctx, const float* x, void* y, const float* gamma, const float* beta, int64_t T, int F, int C, float eps,
+                            int act, void* workspace);
 /* Conv2d on v_mfma_f32_16x16x32_f16: x IEEE half channels-last [B, H, W, Cin], w IEEE half [Cout][KH][KW][Cin], float32 result into the
  * channel slice [y_coff, y_coff + Cout) of y [B, Ho, Wo, y_ctotal], optionally + R (float32 [pixels][ldr]: a block's shortcut branch).
  * Cin % 64 == 0, Cout % 4 == 0; no bias, no activation (this network has neither after a convolution).  Layers with few output tiles are

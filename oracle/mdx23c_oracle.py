@@ -68,8 +68,9 @@ def _tfc_tdf(w, p: str, x: torch.Tensor, l: int, half: bool = False) -> torch.Te
         q = f"{p}.blocks.{i}"
         s = F.conv2d(_h(x, half), _h(w[q + ".shortcut.weight"], half))
         x = F.conv2d(_h(_norm_act(w, q + ".tfc1.0", x), half), _h(w[q + ".tfc1.2.weight"], half), padding=1)
-        t = F.linear(_norm_act(w, q + ".tdf.0", x), w[q + ".tdf.2.weight"])
-        t = F.linear(_norm_act(w, q + ".tdf.3", t), w[q + ".tdf.5.weight"])
+        hl = half and x.shape[-1] % 32 == 0                  # the build runs the TDF linears in half where the frequency count allows (mdx23c._block)
+        t = F.linear(_h(_norm_act(w, q + ".tdf.0", x), hl), _h(w[q + ".tdf.2.weight"], hl))
+        t = F.linear(_h(_norm_act(w, q + ".tdf.3", t), hl), _h(w[q + ".tdf.5.weight"], hl))
         x = x + t
         x = F.conv2d(_h(_norm_act(w, q + ".tfc2.0", x), half), _h(w[q + ".tfc2.2.weight"], half), padding=1)
         x = x + s
@@ -79,9 +80,9 @@ def _tfc_tdf(w, p: str, x: torch.Tensor, l: int, half: bool = False) -> torch.Te
 @torch.no_grad()
 def forward(cfg: MDX23CConfig, w: Dict[str, torch.Tensor], audio: torch.Tensor, half: bool = False) -> torch.Tensor:
     """audio [B, 2, L] (L = hop * (T - 1)) -> [B, num_stems, 2, L].  ``half``: the storage-mode oracle of the build's half-precision mode
-    (audiolab_amd/mdx23c.py ``precision="f16"``): the inputs and weights of the TFC-TDF blocks' convolutions and of the down- / up-scaling
-    convolutions rounded to IEEE half, everything else float32 -- NOT torch autocast (which would also round those layers' outputs and
-    run the TDF linears in half); the reference's own autocast run is a third thing this oracle does not claim to reproduce."""
+    (audiolab_amd/mdx23c.py ``precision="f16"``): the inputs and weights of the TFC-TDF blocks' convolutions, of the down- / up-scaling
+    convolutions and of the TDF linears rounded to IEEE half, everything else float32 -- NOT torch autocast (which would also round
+    those layers' outputs); the reference's own autocast run is a third thing this oracle does not claim to reproduce."""
     B, C, L = audio.shape
     win = torch.hann_window(cfg.n_fft)
     z = torch.stft(audio.reshape(B * C, L), cfg.n_fft, cfg.hop, window=win, center=True, return_complex=True)

@@ -93,6 +93,24 @@ def test_instnorm_half_and_wide_statistics(dev):
         assert np.array_equal(host(y16), host(y32).astype(np.float16))
 
 
+def test_instnorm_half_transposed(dev):
+    """alsep_nn_instnorm_f16_t: [T][F][C] float32 -> [T][C][F] half = the half InstanceNorm's rows transposed per frame (ragged tiles)"""
+    from audiolab_amd import _lib
+    for T, Fw, Cn in ((3, 40, 36), (2, 32, 64), (5, 7, 100)):
+        g = torch.Generator().manual_seed(T * 100 + Fw)
+        x = torch.randn(T * Fw, Cn, generator=g) * 1.5 + 0.3
+        gamma, beta = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g) * 0.1
+        ws = dev.empty((int(dev.lib.alsep_nn_instnorm_workspace_bytes(T * Fw, Cn)),), torch.uint8)
+        xd, gd, bd = on(dev, x), on(dev, gamma), on(dev, beta)
+        y32 = dev.empty((T * Fw, Cn))
+        dev.check(dev.lib.alsep_nn_instnorm(dev.handle, _lib.ptr(xd), _lib.ptr(y32), _lib.ptr(gd), _lib.ptr(bd), T * Fw, Cn, 1e-5, 3, _lib.ptr(ws)), "instnorm")
+        yt = dev.empty((T, Cn, Fw), torch.float16)
+        dev.check(dev.lib.alsep_nn_instnorm_f16_t(dev.handle, _lib.ptr(xd), _lib.ptr(yt), _lib.ptr(gd), _lib.ptr(bd), T, Fw, Cn, 1e-5, 3, _lib.ptr(ws)),
+                  "instnorm_f16_t")
+        want = host(y32).reshape(T, Fw, Cn).transpose(0, 2, 1).astype(np.float16)
+        assert np.array_equal(host(yt), want)
+
+
 def test_half_mode_vs_storage_oracle(dev):
     """precision="f16" (half-precision convolutions on IEEE-half activations, everything else float32) against the storage-mode
     oracle: the same roundings, float32 arithmetic -- and, as the yardstick, against the float32 oracle (what the mode costs)"""
