@@ -198,7 +198,10 @@ def resample_poly(ctx: Context, x: torch.Tensor, sr_in: int, sr_out: int) -> tor
     n_pre_pad = down - half_len % down
     n_pre_remove = (half_len + n_pre_pad) // down
     y = ctx.empty((rows, n_out))
-    t = taps.to(ctx.device)
+    dkey = (up, down, str(ctx.device))
+    if dkey not in _POLY_TAPS:                              # the filter on this device, uploaded once
+        _POLY_TAPS[dkey] = taps.to(ctx.device)
+    t = _POLY_TAPS[dkey]
     ctx.check(ctx.lib.alsep_resample_poly(ctx.handle, _lib.ptr(x), _lib.ptr(y), rows, n_in, n_out, up, down, _lib.ptr(t), t.numel(),
                                           n_pre_pad, n_pre_remove), "alsep_resample_poly")
     return y
