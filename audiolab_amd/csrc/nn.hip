@@ -748,22 +748,63 @@ nn_chan_norm_apply_kernel(const float* __restrict__ x, float* __restrict__ y, co
         y[i] = act == 3 ? gelu_erf(v) : v;
     }
 }
+// the same, four consecutive channels per thread (C % 4 == 0, 16-byte aligned x / y): vector loads of the data, the statistics and the affine
+// parameters instead of one modulo and four scalar loads per element
+__global__ void __launch_bounds__(kNnThreads)
+nn_chan_norm_apply4_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                           const float* __restrict__ stats, int64_t n4, int C, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kNnThreads) {
+        const int c = (int)((4 * i) % C);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + 4 * i);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(stats + 2 * c), s1 = *reinterpret_cast<const f32x4*>(stats + 2 * c + 4);
+        const float mean[4] = {s0[0], s0[2], s1[0], s1[2]}, rstd[4] = {s0[1], s0[3], s1[1], s1[3]};
+        f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (gamma) { g = *reinterpret_cast<const f32x4*>(gamma + c); b = *reinterpret_cast<const f32x4*>(beta + c); }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = (xv[e] - mean[e]) * rstd[e];
+            if (gamma) v = fmaf(v, g[e], b[e]);
+            o[e] = act == 3 ? gelu_erf(v) : v;
+        }
+        *reinterpret_cast<f32x4*>(y + 4 * i) = o;
+    }
+}
 // the same with the result stored as IEEE half (the A operand of the half-precision convolution that follows; C % 4 == 0)
 __global__ void __launch_bounds__(kNnThreads)
 nn_chan_norm_apply_h_kernel(const float* __restrict__ x, _Float16* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
                             const float* __restrict__ stats, int64_t n4, int C, int act) {
     typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-    for (int64_t i = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kNnThreads) {
-        const int c = (int)((4 * i) % C);
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + 4 * i);
-        h16x4 o;
+    // four consecutive channels per thread: their (mean, rstd) pairs, gammas and betas as four 16-byte loads (C % 4 == 0: the quad never
+    // straddles a pixel), two quads in flight per thread
+    const int64_t stride = (int64_t)gridDim.x * kNnThreads;
+    for (int64_t i0 = (int64_t)blockIdx.x * kNnThreads + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+        f32x4 xv[2], s0[2], s1[2], g[2], b[2];
+        bool ok[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = (xv[e] - stats[2 * (c + e)]) * stats[2 * (c + e) + 1];
-            if (gamma) v = fmaf(v, gamma[c + e], beta[c + e]);
-            o[e] = (_Float16)(act == 3 ? gelu_erf(v) : v);
+        for (int u = 0; u < 2; ++u) {
+            const int64_t i = i0 + u * stride;
+            ok[u] = i < n4;
+            const int64_t ic = ok[u] ? i : i0;
+            const int c = (int)((4 * ic) % C);
+            xv[u] = *reinterpret_cast<const f32x4*>(x + 4 * ic);
+            s0[u] = *reinterpret_cast<const f32x4*>(stats + 2 * c);           // mean c, rstd c, mean c+1, rstd c+1
+            s1[u] = *reinterpret_cast<const f32x4*>(stats + 2 * c + 4);
+            if (gamma) { g[u] = *reinterpret_cast<const f32x4*>(gamma + c); b[u] = *reinterpret_cast<const f32x4*>(beta + c); }
         }
-        *reinterpret_cast<h16x4*>(y + 4 * i) = o;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!ok[u]) continue;
+            const float mean[4] = {s0[u][0], s0[u][2], s1[u][0], s1[u][2]}, rstd[4] = {s0[u][1], s0[u][3], s1[u][1], s1[u][3]};
+            h16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = (xv[u][e] - mean[e]) * rstd[e];
+                if (gamma) v = fmaf(v, g[u][e], b[u][e]);
+                o[e] = (_Float16)(act == 3 ? gelu_erf(v) : v);
+            }
+            *reinterpret_cast<h16x4*>(y + 4 * (i0 + u * stride)) = o;
+        }
     }
 }
 // the same with the half result stored TRANSPOSED per frame: x [T][F][C] float32 -> y [T][C][F] IEEE half, i.e. frequency-contiguous rows
@@ -1260,7 +1301,11 @@ extern "C" int alsep_nn_instnorm(alsep_ctx* ctx, const float* x, float* y, const
                ((uintptr_t)workspace & 7) == 0,
            "alsep_nn_instnorm");
     const float* stats = instnorm_stats(ctx, x, P, C, eps, workspace);
-    hipLaunchKernelGGL(nn_chan_norm_apply_kernel, dim3(ew_grid(P * C)), dim3(kNnThreads), 0, ctx->stream, x, y, gamma, beta, stats, P * C, C, act);
+    if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0)
+        hipLaunchKernelGGL(nn_chan_norm_apply4_kernel, dim3(ew_grid(P * C / 4)), dim3(kNnThreads), 0, ctx->stream, x, y, gamma, beta, stats, P * C / 4, C,
+                           act);
+    else
+        hipLaunchKernelGGL(nn_chan_norm_apply_kernel, dim3(ew_grid(P * C)), dim3(kNnThreads), 0, ctx->stream, x, y, gamma, beta, stats, P * C, C, act);
     ALSEP_LAUNCH_CHECK(ctx, "nn_instnorm kernels");
     return ALSEP_OK;
 }
