@@ -47,6 +47,8 @@ def test_config3_track_batch_mdx7680_ensemble_plus_htdemucs(gpu_ctx, tmp_path, m
     # configs[3] is "MDX + Demucs": the roster is cut to the MDX-Net files and htdemucs, so that the first two ensemble members
     # the orchestrator finds are the reference's MDX-Net vocal models at their real geometry (bench.py --workload tracks does the same)
     roster = {k: v for k, v in MODEL_ROSTER.items() if k.endswith(".onnx") or v[0] == "demucs"}
+    # one shift pass instead of the package's two: halves the CPU oracle's Demucs work (the two-pass runner has its own test, test_htdemucs.py)
+    roster["htdemucs_6s.yaml"] = (roster["htdemucs_6s.yaml"][0], roster["htdemucs_6s.yaml"][1], {"shifts": 1, "overlap": 0.25})
     members = ("UVR-MDX-NET-Voc_FT.onnx", "Kim_Vocal_2.onnx")
     for m in members:
         cfg = roster[m][2]
@@ -90,7 +92,7 @@ def test_config3_track_batch_mdx7680_ensemble_plus_htdemucs(gpu_ctx, tmp_path, m
         vocals = eo.blend_tracks(v, [6.9, 6.9])                                  # stem_separator.py:412
         inst = eo.blend_tracks(i, [14.9, 14.9])                                  # :413
         inst, _ = eo.debleed(mix, vocals, inst, 44100, 0.2)                      # :415-456 (residual_blend capped at 0.2, :389-390)
-        six = ho.separate(ocfg, dsd, torch.from_numpy(mix), shifts=2, overlap=0.25, seed=0).numpy()
+        six = ho.separate(ocfg, dsd, torch.from_numpy(mix), shifts=1, overlap=0.25, seed=0).numpy()
         want = {"(Vocals)": vocals, "(Instrumental)": inst}
         for idx, name in enumerate(ocfg.sources):
             if name != "vocals":                                                 # :491-500: the vocals output is ignored
@@ -143,8 +145,8 @@ def test_config4_f16_ola075_48k_8ch_vs_storage_oracle(gpu_ctx, tmp_path):
                 return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)), cfg.num_blocks, cfg.l,
                                              cfg.bn, storage=storage).numpy()
         return run
-    # oracle on the first and the last stereo pair (storage mode and fp32); the middle pairs are checked against the 2-channel path below
-    for c0 in (0, 6):
+    # oracle on the first stereo pair (storage mode and fp32); the other pairs are checked against the 2-channel path below
+    for c0 in (0,):
         pair = mix8[c0:c0 + 2]
         # the engine's sequence in this mode (normalise to 0.9, overlap-add, spectral inversion for the secondary stem): oracle/mdx_oracle.separate_ola
         want_st, _ = mo.separate_ola(pair, g, run_with(torch.float16), overlap=0.75, compensate=1.0)
@@ -161,7 +163,7 @@ def test_config4_f16_ola075_48k_8ch_vs_storage_oracle(gpu_ctx, tmp_path):
         r_sec = _rel(got["Instrumental"][c0:c0 + 2], sec_32)
         assert r_sec < 1.25 * r_oo * np.linalg.norm(want_32) / np.linalg.norm(sec_32) + 2e-3, r_sec
     # every pair of the 8-channel run equals the same pair run alone through the 2-channel path (bit for bit: same kernels, same order)
-    for c0 in (2, 4):
+    for c0 in (2, 4, 6):
         alone = eng.separate_array(mix8[c0:c0 + 2])["Vocals"].cpu().numpy()
         assert np.array_equal(alone, got["Vocals"][c0:c0 + 2])
 
