@@ -428,7 +428,13 @@ class Separator:
             seed = int.from_bytes(hashlib.sha256(model_filename.encode()).digest()[:4], "little")
             sd, weights = mdx23c_synth(cfg, seed=seed), "synthetic"
             logger.warning("%s: no weight file under %s -- SYNTHETIC random-init weights (allow_synthetic=True)", model_filename, self.model_file_dir)
-        net = MDX23C(cfg, sd, ctx=self.ctx, precision="f32" if self.dtype == torch.float32 else "f16")   # use_autocast: half-precision mode
+        # use_autocast: the half-precision mode -- where the checkpoint's channel counts allow it (its convolution wants input channels in
+        # multiples of 64: true of the published models); a model that does not fit runs in float32 with a WARNING instead of failing the stage
+        half_ok = self.dtype != torch.float32 and cfg.num_channels % 64 == 0 and cfg.growth % 64 == 0
+        if self.dtype != torch.float32 and not half_ok:
+            logger.warning("%s: num_channels %d / growth %d are not multiples of 64 -- running this MDX23C model in float32", model_filename,
+                           cfg.num_channels, cfg.growth)
+        net = MDX23C(cfg, sd, ctx=self.ctx, precision="f16" if half_ok else "f32")
         inst = _ModelInstance(model_filename, net, None, labels[0], None)
         inst.roformer = RoformerRunner(net, labels)             # the same chunked runner (training project's demix_track)
         inst.output_dir = self.output_dir

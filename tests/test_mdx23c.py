@@ -245,6 +245,9 @@ def test_engine_roster_entries(dev):
         pytest.skip("GPU only")
     name = "MDX23C-DrumSep-aufr33-jarredou.ckpt"
     small = MDX23CConfig(**dataclasses.asdict(small_cfg(instruments=("kick", "snare", "toms", "hh", "ride", "crash"))))
+    auto = Separator(ctx=dev, use_autocast=True, allow_synthetic=True, roster={name: ("mdx23c", small, MODEL_ROSTER[name][2])})
+    auto.load_model(name)                                                # 16 / 8 channels: no half mode for this one -- float32 with a warning, not an error
+    assert auto.model_instance.net.half is False
     eng = Separator(ctx=dev, use_autocast=False, allow_synthetic=True, roster={name: ("mdx23c", small, MODEL_ROSTER[name][2])})
     eng.load_model(name)
     drums = torch.randn(2, 2500, generator=torch.Generator().manual_seed(8)) * 0.3
