@@ -387,7 +387,11 @@ class Separator:
             sd, weights = roformer_synth(cfg, seed=seed), "synthetic"
             logger.warning("%s: no weight file under %s -- SYNTHETIC random-init weights (allow_synthetic=True)", model_filename, self.model_file_dir)
         # use_autocast=True (the reference's GPU setting, stem_separator.py:106): the network's half-precision mode; float32 otherwise
-        net = Roformer(cfg, sd, ctx=self.ctx, precision="f32" if self.dtype == torch.float32 else "f16")
+        # (a checkpoint whose head dimension is not the 64 the one-pass attention kernel is written for runs in float32 with a WARNING)
+        half_ok = self.dtype != torch.float32 and cfg.dim_head == 64
+        if self.dtype != torch.float32 and not half_ok:
+            logger.warning("%s: dim_head %d -- running this Roformer in float32 (its half-precision attention kernel handles 64)", model_filename, cfg.dim_head)
+        net = Roformer(cfg, sd, ctx=self.ctx, precision="f16" if half_ok else "f32")
         labels = tuple(opts.get("labels", ("Vocals",)))[: cfg.num_stems]
         inst = _ModelInstance(model_filename, net, None, labels[0], opts.get("secondary") if cfg.num_stems == 1 else None)
         inst.roformer = RoformerRunner(net, labels)
