@@ -438,19 +438,20 @@ extern "C" int alsep_resample(alsep_ctx* ctx, const float* x, float* y, int64_t 
 __global__ void __launch_bounds__(kThreads)
 resample_poly_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int64_t n_in, int64_t n_out, int up, int down,
                      const float* __restrict__ h, int n_taps, int n_pre_pad, int n_pre_remove) {
-    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i >= rows * n_out) return;
-    const int64_t r = i / n_out, j = i - r * n_out;
-    const int64_t top = (j + n_pre_remove) * (int64_t)down - n_pre_pad;     // tap index of x[0]
-    // tap = top - n up in [0, n_taps)  <=>  n in [ceil((top - n_taps + 1) / up), floor(top / up)]
-    int64_t n_hi = top >= 0 ? top / up : -1;
-    const int64_t lo_num = top - n_taps + 1;
-    int64_t n_lo = lo_num > 0 ? (lo_num + up - 1) / up : 0;
-    if (n_hi > n_in - 1) n_hi = n_in - 1;
-    const float* xr = x + r * n_in;
-    float acc = 0.f;
-    for (int64_t n = n_lo; n <= n_hi; ++n) acc = fmaf(xr[n], h[top - n * up], acc);
-    y[i] = acc;
+    // grid-stride: grid_for() caps the grid at kMaxBlocks workgroups
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < rows * n_out; i += (int64_t)gridDim.x * kThreads) {
+        const int64_t r = i / n_out, j = i - r * n_out;
+        const int64_t top = (j + n_pre_remove) * (int64_t)down - n_pre_pad;     // tap index of x[0]
+        // tap = top - n up in [0, n_taps)  <=>  n in [ceil((top - n_taps + 1) / up), floor(top / up)]
+        int64_t n_hi = top >= 0 ? top / up : -1;
+        const int64_t lo_num = top - n_taps + 1;
+        const int64_t n_lo = lo_num > 0 ? (lo_num + up - 1) / up : 0;
+        if (n_hi > n_in - 1) n_hi = n_in - 1;
+        const float* xr = x + r * n_in;
+        float acc = 0.f;
+        for (int64_t n = n_lo; n <= n_hi; ++n) acc = fmaf(xr[n], h[top - n * up], acc);
+        y[i] = acc;
+    }
 }
 
 extern "C" int alsep_resample_poly(alsep_ctx* ctx, const float* x, float* y, int64_t rows, int64_t n_in, int64_t n_out, int up, int down,

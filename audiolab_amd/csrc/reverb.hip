@@ -311,8 +311,8 @@ int dft_impl(alsep_ctx* ctx, const cplx* in, cplx* out, int64_t n, double sign, 
 // applied to L + i R resamples both).
 __global__ void __launch_bounds__(kRvThreads)
 pack_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, cplx* __restrict__ z, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * kRvThreads + threadIdx.x;
-    if (i < n) z[i] = cplx{(double)a[i], b ? (double)b[i] : 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * kRvThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kRvThreads)
+        z[i] = cplx{(double)a[i], b ? (double)b[i] : 0.0};
 }
 
 // Y (length num) from X (length nx), the spectrum copy of scipy.signal.resample's complex branch: N = min(num, nx), the N/2 + 1 lowest
@@ -320,29 +320,29 @@ pack_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, cplx*
 // to -N/2; downsampling: X[-N/2] added to the bin at -N/2).
 __global__ void __launch_bounds__(kRvThreads)
 resample_spectrum_kernel(const cplx* __restrict__ X, cplx* __restrict__ Y, int64_t nx, int64_t num) {
-    const int64_t k = (int64_t)blockIdx.x * kRvThreads + threadIdx.x;
-    if (k >= num) return;
     const int64_t N = num < nx ? num : nx, nyq = N / 2 + 1, neg = N - nyq;   // Y[num - neg ..] = X[nx - neg ..]
-    cplx v{0.0, 0.0};
-    if (k < nyq) v = X[k];
-    else if (N > 2 && k >= num - neg) v = X[nx - (num - k)];
-    if (N % 2 == 0) {
-        if (num < nx) {                                                      // index -N/2 of Y is num - N/2 = N/2 here (num == N)
-            if (k == num - N / 2) { const cplx e = X[nx - N / 2]; v.x += e.x; v.y += e.y; }
-        } else if (nx < num) {
-            if (k == N / 2) { v.x *= 0.5; v.y *= 0.5; }
-            if (k == num - N / 2) { v = X[N / 2]; v.x *= 0.5; v.y *= 0.5; }
+    for (int64_t k = (int64_t)blockIdx.x * kRvThreads + threadIdx.x; k < num; k += (int64_t)gridDim.x * kRvThreads) {
+        cplx v{0.0, 0.0};
+        if (k < nyq) v = X[k];
+        else if (N > 2 && k >= num - neg) v = X[nx - (num - k)];
+        if (N % 2 == 0) {
+            if (num < nx) {                                                  // index -N/2 of Y is num - N/2 = N/2 here (num == N)
+                if (k == num - N / 2) { const cplx e = X[nx - N / 2]; v.x += e.x; v.y += e.y; }
+            } else if (nx < num) {
+                if (k == N / 2) { v.x *= 0.5; v.y *= 0.5; }
+                if (k == num - N / 2) { v = X[N / 2]; v.x *= 0.5; v.y *= 0.5; }
+            }
         }
+        Y[k] = v;
     }
-    Y[k] = v;
 }
 
 __global__ void __launch_bounds__(kRvThreads)
 unpack_rows_kernel(const cplx* __restrict__ z, float* __restrict__ a, float* __restrict__ b, int64_t n, double scale) {
-    const int64_t i = (int64_t)blockIdx.x * kRvThreads + threadIdx.x;
-    if (i >= n) return;
-    a[i] = (float)(z[i].x * scale);
-    if (b) b[i] = (float)(z[i].y * scale);
+    for (int64_t i = (int64_t)blockIdx.x * kRvThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kRvThreads) {
+        a[i] = (float)(z[i].x * scale);
+        if (b) b[i] = (float)(z[i].y * scale);
+    }
 }
 
 int64_t dft_ws_points(int64_t n) {
@@ -388,6 +388,11 @@ extern "C" int alsep_reverb_xcorr_argmax(alsep_ctx* ctx, const float* wet, int c
     const int64_t need = alsep_reverb_workspace_bytes(n_wet, n_dry);
     if (need < 0 || ws_bytes < need) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_reverb_xcorr_argmax: workspace too small (or track too long)");
     const int64_t N = n_wet + n_dry - 1;
+    // probe indices are checked before anything is enqueued
+    const int n_pr = (n_probe > 0 && probe_idx && probe_out) ? n_probe : 0;
+    for (int i = 0; i < n_pr; ++i)
+        if (probe_idx[i] < 0 || probe_idx[i] >= N) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_reverb_xcorr_argmax: probe index out of range");
+    std::vector<cplx> pv(n_pr);
     const int lx = log2_ceil(N);
     const int64_t nx = (int64_t)1 << lx;
     cplx* z = (cplx*)ws;
@@ -406,27 +411,23 @@ extern "C" int alsep_reverb_xcorr_argmax(alsep_ctx* ctx, const float* wet, int c
     int64_t* cand_i = (int64_t*)(cand_v + 1024);
     hipLaunchKernelGGL(argmax_real_kernel, dim3(blocks), dim3(kRvThreads), kRvThreads * 16, ctx->stream, corr, N, cand_v, cand_i);
     ALSEP_LAUNCH_CHECK(ctx, "argmax_real_kernel");
-    double hv[1024];
-    int64_t hi[1024];
-    ALSEP_HIP(ctx, hipMemcpyAsync(hv, cand_v, blocks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    ALSEP_HIP(ctx, hipMemcpyAsync(hi, cand_i, blocks * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    std::vector<cplx> pv(n_probe > 0 ? n_probe : 0);
-    std::vector<int64_t> pidx(n_probe > 0 ? n_probe : 0);
-    if (n_probe > 0 && probe_idx && probe_out) {
-        for (int i = 0; i < n_probe; ++i) {
-            pidx[i] = probe_idx[i];
-            if (pidx[i] < 0 || pidx[i] >= N) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_reverb_xcorr_argmax: probe index out of range");
-            ALSEP_HIP(ctx, hipMemcpyAsync(&pv[i], corr + pidx[i], sizeof(cplx), hipMemcpyDeviceToHost, ctx->stream));
-        }
-    }
-    ALSEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // host landing buffers live on the heap and every path out of here passes the stream synchronisation below, so no pending copy
+    // ever targets a dead frame
+    std::vector<double> hv(blocks);
+    std::vector<int64_t> hi(blocks);
+    hipError_t e = hipMemcpyAsync(hv.data(), cand_v, blocks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hi.data(), cand_i, blocks * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+    for (int i = 0; i < n_pr && e == hipSuccess; ++i)
+        e = hipMemcpyAsync(&pv[i], corr + probe_idx[i], sizeof(cplx), hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t es = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess || es != hipSuccess)
+        return alsep_fail(ctx, ALSEP_ERR_HIP, "alsep_reverb_xcorr_argmax: copy back failed: %s", hipGetErrorString(e != hipSuccess ? e : es));
     double bv = hv[0];
     int64_t bi = hi[0];
     for (unsigned b = 1; b < blocks; ++b)
         if (hv[b] > bv || (hv[b] == bv && hi[b] < bi)) { bv = hv[b]; bi = hi[b]; }
     *argmax_out = bi;
-    if (n_probe > 0 && probe_idx && probe_out)
-        for (int i = 0; i < n_probe; ++i) probe_out[i] = pv[i].x / (double)nx;      // irfft's 1 / n
+    for (int i = 0; i < n_pr; ++i) probe_out[i] = pv[i].x / (double)nx;      // irfft's 1 / n
     return ALSEP_OK;
 }
 

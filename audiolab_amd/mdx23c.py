@@ -267,7 +267,7 @@ class MDX23C:
             if self.half:
                 s, _, _ = self._conv_h(self._to_half(x), T, Fw, L["short"])
                 x, _, _ = self._conv_h(self._norm_act(x, P, cin, L["n1"], True), T, Fw, L["c1"], pad=(1, 1))
-                if Fw % 32 == 0:                                # TDF linears on the f16 GEMM (K = the frequency count, in whole 8-groups)
+                if Fw % 32 == 0 and (Fw // self.cfg.bottleneck_factor) % 8 == 0:   # TDF linears on the f16 GEMM (both K -- the frequency count and the bottleneck width -- in whole 8-groups)
                     t, Fh = self._linear_f_h(self._norm_act_t(x, T, Fw, c, L["nt1"]), T, Fw, c, L["l1h"])
                     x, _ = self._linear_f_h(self._norm_act_t(t, T, Fh, c, L["nt2"]), T, Fh, c, L["l2h"], res=x)       # x + tdf(x), fused
                 else:

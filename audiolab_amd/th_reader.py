@@ -45,7 +45,7 @@ def _placeholder(module: str, name: str):
     return type(name, (Placeholder,), {"_alsep_path": f"{module}.{name}"})
 
 
-def _allowed() -> Dict[Tuple[str, str], object]:
+def _build_allowed() -> Dict[Tuple[str, str], object]:
     import torch._utils
     table = {
         ("collections", "OrderedDict"): collections.OrderedDict,
@@ -54,20 +54,33 @@ def _allowed() -> Dict[Tuple[str, str], object]:
         ("builtins", "set"): set, ("builtins", "frozenset"): frozenset, ("builtins", "slice"): slice, ("builtins", "complex"): complex,
         ("builtins", "dict"): dict, ("builtins", "list"): list, ("builtins", "tuple"): tuple, ("builtins", "int"): int,
         ("builtins", "float"): float, ("builtins", "bool"): bool, ("builtins", "str"): str, ("builtins", "bytes"): bytes,
-        ("torch._utils", "_rebuild_tensor_v2"): torch._utils._rebuild_tensor_v2,
-        ("torch._utils", "_rebuild_tensor"): torch._utils._rebuild_tensor,
-        ("torch._utils", "_rebuild_parameter"): torch._utils._rebuild_parameter,
         ("torch", "Size"): torch.Size, ("torch", "device"): torch.device,
-        ("torch.serialization", "_get_layout"): torch.serialization._get_layout,
     }
-    for name in ("float32", "float16", "bfloat16", "float64", "int64", "int32", "int16", "int8", "uint8", "bool"):
-        table[("torch", name)] = getattr(torch, name)
-    for name in ("FloatStorage", "HalfStorage", "BFloat16Storage", "DoubleStorage", "LongStorage", "IntStorage", "ShortStorage", "CharStorage",
+    # symbols that come and go between torch builds: allow the ones this build has
+    for module, owner, name in (("torch._utils", torch._utils, "_rebuild_tensor_v2"), ("torch._utils", torch._utils, "_rebuild_tensor"),
+                                ("torch._utils", torch._utils, "_rebuild_parameter"),
+                                ("torch.serialization", torch.serialization, "_get_layout"),
+                                ("torch.storage", torch.storage, "UntypedStorage"), ("torch.storage", torch.storage, "TypedStorage")):
+        obj = getattr(owner, name, None)
+        if obj is not None:
+            table[(module, name)] = obj
+    for name in ("float32", "float16", "bfloat16", "float64", "int64", "int32", "int16", "int8", "uint8", "bool",
+                 "FloatStorage", "HalfStorage", "BFloat16Storage", "DoubleStorage", "LongStorage", "IntStorage", "ShortStorage", "CharStorage",
                  "ByteStorage", "BoolStorage"):
-        table[("torch", name)] = getattr(torch, name)
-    table[("torch.storage", "UntypedStorage")] = torch.storage.UntypedStorage
-    table[("torch.storage", "TypedStorage")] = torch.storage.TypedStorage
+        obj = getattr(torch, name, None)
+        if obj is not None:
+            table[("torch", name)] = obj
     return table
+
+
+_ALLOWED: Dict[Tuple[str, str], object] = {}
+
+
+def _allowed() -> Dict[Tuple[str, str], object]:
+    """the allow-list, built once per process"""
+    if not _ALLOWED:
+        _ALLOWED.update(_build_allowed())
+    return _ALLOWED
 
 
 class RestrictedUnpickler(pickle.Unpickler):
@@ -111,9 +124,28 @@ def read_th(path: str) -> dict:
     return {"klass": klass_name, "kwargs": dict(kwargs), "state": {k: v.detach().float() for k, v in state.items()}}
 
 
+# demucs.htdemucs.HTDemucs.__init__'s own defaults (demucs 4.0.1, upstream; restated -- unpinned) for every option that is not a field of
+# HTDemucsConfig: a package that omits a key gets THIS value, which is then held against what this build implements.
+_DEMUCS_DEFAULTS = {
+    "channels_time": None, "wiener_iters": 0, "end_iters": 0, "wiener_residual": False, "cac": True, "rewrite": True, "multi_freqs": None,
+    "multi_freqs_depth": 3, "emb_smooth": True, "time_stride": 2, "norm_starts": 4, "norm_groups": 4, "dconv_mode": 1, "bottom_channels": 0,
+    "t_emb": "sin", "t_dropout": 0.0, "t_max_positions": 10000, "t_norm_in": True, "t_norm_in_group": False, "t_group_norm": False,
+    "t_norm_first": True, "t_norm_out": True, "t_weight_decay": 0.0, "t_lr": None, "t_layer_scale": True, "t_gelu": True,
+    "t_sin_random_shift": 0, "t_cape_mean_normalize": True, "t_cape_augment": True, "t_cape_glob_loc_scale": [5000.0, 1.0, 1.4],
+    "t_sparse_self_attn": False, "t_sparse_cross_attn": False, "t_mask_type": "diag", "t_mask_random_seed": 42, "t_sparse_attn_window": 500,
+    "t_global_window": 100, "t_sparsity": 0.95, "t_auto_sparsity": False, "t_cross_first": False, "rescale": 0.1, "use_train_segment": True,
+}
+# options that only act at training time or at construction (initial scales, dropout, optimiser groups, the sparse-attention mask of
+# switched-off sparse attention, augmentation of a positional embedding that is not the one in use): any value is fine
+_TRAINING_ONLY = {"t_dropout", "t_weight_decay", "t_lr", "rescale", "t_sin_random_shift", "t_cape_mean_normalize", "t_cape_augment",
+                  "t_cape_glob_loc_scale", "t_mask_type", "t_mask_random_seed", "t_sparse_attn_window", "t_global_window", "t_sparsity",
+                  "t_auto_sparsity", "use_train_segment", "t_max_positions", "multi_freqs_depth", "end_iters", "wiener_residual"}
+
+
 def htdemucs_config_from_kwargs(kwargs: dict):
-    """demucs.htdemucs.HTDemucs(**kwargs) -> HTDemucsConfig; an option this build's network does not implement with a non-default value
-    is an error, not something to ignore."""
+    """demucs.htdemucs.HTDemucs(**kwargs) -> HTDemucsConfig.  An option this build's network does not implement must sit at the value
+    htdemucs_6s was trained with -- whether the package spells it out or leaves it to demucs' own default -- and a keyword this reader
+    does not know at all is an error too: nothing is silently dropped."""
     import dataclasses
     from .htdemucs import HTDemucsConfig
     base = HTDemucsConfig()
@@ -127,14 +159,23 @@ def htdemucs_config_from_kwargs(kwargs: dict):
             over["segment_samples"] = int(fractions.Fraction(v) * sr) if not isinstance(v, float) else int(v * sr)
         elif k in fields:
             over[k] = type(getattr(base, k))(v)
+        elif k not in _DEMUCS_DEFAULTS:
+            raise AlsepError(f"demucs package: HTDemucs({k}={v!r}) is not an option this build knows")
+    # bottom_channels is a field here with htdemucs_6s' value as its default; demucs' own default is 0 (no bottleneck convolutions)
+    if "bottom_channels" not in kwargs:
+        over["bottom_channels"] = _DEMUCS_DEFAULTS["bottom_channels"]
     # structural switches of demucs' HTDemucs that must sit at the values htdemucs_6s was trained with
-    expect = {"cac": True, "wiener_iters": 0, "multi_freqs": None, "bottom_channels": over.get("bottom_channels", base.bottom_channels),
-              "t_cross_first": False, "t_norm_in": True, "t_norm_first": True, "t_norm_out": True, "t_layer_scale": True, "t_gelu": True,
-              "t_sparse_self_attn": False, "t_sparse_cross_attn": False, "t_emb": "sin", "dconv_mode": 3, "rewrite": True, "norm_starts": 4,
-              "norm_groups": 4, "freq_emb": over.get("freq_emb", base.freq_emb)}
+    expect = {"cac": True, "wiener_iters": 0, "multi_freqs": None, "channels_time": None, "emb_smooth": True, "time_stride": 2,
+              "t_cross_first": False, "t_norm_in": True, "t_norm_in_group": False, "t_group_norm": False, "t_norm_first": True,
+              "t_norm_out": True, "t_layer_scale": True, "t_gelu": True, "t_sparse_self_attn": False, "t_sparse_cross_attn": False,
+              "t_emb": "sin", "dconv_mode": 3, "rewrite": True, "norm_starts": 4, "norm_groups": 4}
     for k, want in expect.items():
-        if k in kwargs and kwargs[k] != want and not (want is None and not kwargs[k]):
-            raise AlsepError(f"demucs package: HTDemucs({k}={kwargs[k]!r}) is not implemented by this build (expects {want!r})")
+        have = kwargs.get(k, _DEMUCS_DEFAULTS[k])
+        if have != want and not (want is None and not have):
+            where = "" if k in kwargs else " (left at demucs' default by the package)"
+            raise AlsepError(f"demucs package: HTDemucs({k}={have!r}){where} is not implemented by this build (expects {want!r})")
+    if over.get("bottom_channels", base.bottom_channels) <= 0:
+        raise AlsepError("demucs package: HTDemucs(bottom_channels=0) is not implemented by this build (htdemucs_6s uses 512)")
     return dataclasses.replace(base, **over)
 
 

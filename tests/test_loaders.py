@@ -95,7 +95,7 @@ def _write_th(path, cfg, sd, evil=False):
     try:
         kwargs = dict(sources=list(cfg.sources), channels=cfg.channels, growth=cfg.growth, nfft=cfg.nfft, depth=cfg.depth, dconv_comp=cfg.dconv_comp,
                       bottom_channels=cfg.bottom_channels, t_layers=cfg.t_layers, t_heads=cfg.t_heads, samplerate=cfg.samplerate,
-                      segment=fractions.Fraction(cfg.segment_samples, cfg.samplerate), cac=True, wiener_iters=0)
+                      segment=fractions.Fraction(cfg.segment_samples, cfg.samplerate), cac=True, wiener_iters=0, dconv_mode=3, t_dropout=0.02)
         pkg = {"klass": HT, "args": (), "kwargs": kwargs, "state": {k: v.half() for k, v in sd.items()}, "training_args": DC({"lr": 3e-4})}
         if evil:
             import os
@@ -135,6 +135,15 @@ def test_demucs_th_package_is_read_without_importing_it(tmp_path):
     # an option this build does not implement is refused, not ignored
     with pytest.raises(AlsepError):
         th_reader.htdemucs_config_from_kwargs(dict(pkg["kwargs"], t_sparse_self_attn=True))
+    # ... and so is one the package leaves at a demucs default that differs from htdemucs_6s' value (dconv_mode: 1 upstream, 3 here),
+    # and a keyword the reader has never heard of
+    with pytest.raises(AlsepError) as e:
+        th_reader.htdemucs_config_from_kwargs({k: v for k, v in pkg["kwargs"].items() if k != "dconv_mode"})
+    assert "dconv_mode" in str(e.value) and "default" in str(e.value)
+    with pytest.raises(AlsepError):
+        th_reader.htdemucs_config_from_kwargs({k: v for k, v in pkg["kwargs"].items() if k != "bottom_channels"})
+    with pytest.raises(AlsepError):
+        th_reader.htdemucs_config_from_kwargs(dict(pkg["kwargs"], brand_new_option=1))
     # a package that smuggles another global in is refused before anything runs
     evil = str(tmp_path / "evil.th")
     _write_th(evil, cfg, sd, evil=True)

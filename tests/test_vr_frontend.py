@@ -80,6 +80,28 @@ def test_device_resamplers_vs_oracle(dev, n):
     assert ensemble.resample_poly(dev, xd, 7350, 7350) is xd
 
 
+def test_device_resamplers_long_tracks(dev):
+    """lengths past the grid caps of the launches (2048 x 256 outputs for the polyphase kernel, 65536 x 256 elements for the Fourier
+    resampler's pack / spectrum / unpack kernels): a stereo minute down the VR chain's first band ratio, and -- on the GPU, where the
+    2^25-point transforms take milliseconds -- 6.4 minutes up from 14.7 kHz (outputs beyond the cap were never written)"""
+    from audiolab_amd import ensemble
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 60 * 44100)).astype(np.float32)
+    got = host(ensemble.resample_poly(dev, on(dev, x), 44100, 14700))
+    want = vo.resample(x, 44100, 14700, "polyphase")
+    assert got.shape == want.shape and got.shape[1] * 2 > 2048 * 256
+    assert np.max(np.abs(got - want)) < 3e-6
+    assert np.max(np.abs(got[:, -1000:] - want[:, -1000:])) < 3e-6 and np.any(got[:, -1000:] != 0)
+    if dev.device.type != "cuda":
+        return
+    n = 65536 * 256 // 3 + 12345                                                        # output 3 n > 65536 x 256
+    x = rng.standard_normal((2, n)).astype(np.float32)
+    got = host(ensemble.resample_fft(dev, on(dev, x), 14700, 44100))
+    want = vo.resample(x, 14700, 44100, "scipy")
+    assert got.shape == want.shape and got.shape[1] > 65536 * 256
+    assert np.max(np.abs(got - want)) < 5e-6
+
+
 def test_front_and_back_end_vs_reference_vectors(dev):
     from audiolab_amd.vr_frontend import VRFrontEnd
     g = np.load(GOLD)
