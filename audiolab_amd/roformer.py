@@ -539,20 +539,19 @@ class RoformerRunner:
         if graphs is None:
             graphs = os.environ.get("ALSEP_RUNNER_GRAPH", "1") != "0"
         self.graphs = bool(graphs) and gpu
-        # Half-precision networks run on ONE lane.  (1) With graph replay one lane is as fast as four (Mel-Band 120 s: 576 vs 564 ms, BS
-        # 1 101 vs 1 100, MDX23C 1 175 vs 1 247).  (2) It is the only safe setting found: while nn_gemm_hh_kernel / nn_conv_hh_kernel run
-        # on one HIP stream at two workgroups per CU (2 x 64 KiB LDS, 2 x 256 VGPRs per SIMD), FFT kernels running on ANOTHER stream
-        # produce whole wrong frames now and then (stems differ by 3e-3 ... 6e-2 from run to run; scripts/dbg/agg2.py reproduces it in
-        # seconds: 2-7 corrupted launches of 16).  Not the kernels' arithmetic -- each is bit-exact alone, an LDS canary kernel beside them
-        # stays intact, guard regions around their outputs stay intact, no scratch is involved, GPU_MAX_HW_QUEUES=1 or one workgroup per CU
-        # makes it vanish -- so it is treated as a property of this stack, and concurrency between these kernels and others is avoided.
+        # Half-precision networks run on ONE lane, with no override.  (1) With graph replay one lane is as fast as four (Mel-Band 120 s: 576 vs
+        # 564 ms, BS 1 101 vs 1 100, MDX23C 1 175 vs 1 247).  (2) FFT launches must not share the GPU with 16-bit MFMA kernels of another
+        # stream: beside ANY kernel that issues f16 / bf16 MFMA and leaves room on its SIMDs -- a neutral 60-line GEMM does it 20 times out
+        # of 20 -- the packed-f32 FFT kernels return aligned 16-lane groups of slightly wrong values; f32 MFMA and VALU kernels do not do
+        # it, and the same FFT source compiled without packed arithmetic is immune (profiles/r04_cross_stream_discrimination.txt,
+        # scripts/dbg/discriminate.py).  The float32 modes (f32 MFMA only) keep their lanes.
         half = getattr(net, "precision", "f32") == "f16" or bool(getattr(net, "half", False))
         if lanes is None:
             lanes = (1 if half else int(os.environ.get("ALSEP_RUNNER_LANES", "4"))) if gpu else 1
-        elif half and gpu and int(lanes) > 1 and os.environ.get("ALSEP_RUNNER_UNSAFE_LANES", "0") == "0":
+        elif half and gpu and int(lanes) > 1:
             import logging
-            logging.getLogger(__name__).warning("RoformerRunner: %d lanes asked for a half-precision network; using 1 (concurrent streams corrupt "
-                                                "FFT launches beside the f16 MFMA kernels on this stack; ALSEP_RUNNER_UNSAFE_LANES=1 overrides)", int(lanes))
+            logging.getLogger(__name__).warning("RoformerRunner: %d lanes asked for a half-precision network; using 1 (FFT launches beside the "
+                                                "16-bit MFMA kernels of another stream come back corrupted on this stack)", int(lanes))
             lanes = 1
         self.lanes = max(1, int(lanes)) if gpu else 1
         self._lane_nets: List[tuple] = []

@@ -23,7 +23,7 @@ import torch
 
 from audiolab_amd import ensemble, wavio
 from audiolab_amd.engine import FOUR_STEM_SET, MODEL_ROSTER, Separator
-from audiolab_amd.handlers.config import app_path
+from audiolab_amd.handlers import config
 
 logger = logging.getLogger(__name__)
 
@@ -68,10 +68,22 @@ class EnsembleDemucsMDXMusicSeparationModel:
 
     def __init__(self, options: Dict, callback: Callable = None, separator: Optional[Separator] = None):
         self.options = options
+        # The engine the reference builds at :102-107 is audio-separator's: its MDX runner normalises to 0.9, overlap-adds Hann-windowed
+        # chunks (mdx_params overlap 0.25) and makes the secondary stem by spectral inversion (invert_using_spec=True, :104) -- that runner
+        # is ``chunker="ola"`` here and it is the default; ``chunker="margin"`` selects the in-tree runner (mdxnet.py) instead.  The
+        # knobs arrive from the wrapper's hidden inputs (wrappers/separate.py: precision / chunker / overlap / num_gpus).
+        num_gpus = int(options.get("num_gpus", 1) or 1)
+        if separator is None and num_gpus > 1:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() == num_gpus):
+                raise RuntimeError(f"num_gpus={num_gpus}: this build runs one process per GPU -- start {num_gpus} ranks with "
+                                   f"torch.distributed initialised (python -m torch.distributed.run --nproc-per-node {num_gpus} ...)")
         self.separator = separator if separator is not None else Separator(
-            log_level=logging.ERROR, model_file_dir=os.path.join(app_path, "models", "audio_separator"),
+            log_level=logging.ERROR, model_file_dir=os.path.join(config.app_path, "models", "audio_separator"),
             invert_using_spec=True, use_autocast=not options.get("cpu", False) and options.get("precision", "fp16") != "fp32",
-            dtype={"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}.get(options.get("precision", "fp16")))
+            dtype={"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}.get(options.get("precision", "fp16")),
+            chunker=options.get("chunker", "ola"), overlap=float(options.get("overlap", 0.25)), normalization_threshold=0.9,
+            sharded=num_gpus > 1)
         self.ctx = self.separator.ctx
         self.vocals_only = bool(options.get("vocals_only", False))
         self.separate_drums = bool(options.get("separate_drums", False))
@@ -441,8 +453,10 @@ def predict_with_model(options: Dict, callback: Callable = None, separator: Opti
 
 
 def separate_music(input_dict: Dict[str, List[str]], callback: Callable = None, **kwargs) -> List[str]:
-    """:949-1001 -- same option names and defaults; extra keys ``precision`` ("fp16"|"bf16"|"fp32") and
-    ``separator`` (a pre-built engine) are this build's."""
+    """:949-1001 -- same option names and defaults; extra keys of this build: ``precision`` ("fp16"|"bf16"|"fp32"), ``chunker``
+    ("ola": audio-separator's runner, what :281 runs -- the default; "margin": the in-tree mdxnet.py runner), ``overlap`` (of the
+    overlap-add runner), ``num_gpus`` (ranks of an initialised torch.distributed job that shard every model's chunks) and ``separator``
+    (a pre-built engine, which then carries its own settings)."""
     options = {
         "input_dict": input_dict,
         "cpu": kwargs.get("cpu", False),
@@ -469,5 +483,8 @@ def separate_music(input_dict: Dict[str, List[str]], callback: Callable = None, 
         "ensemble_strength": kwargs.get("ensemble_strength", 2),
         "residual_blend": kwargs.get("residual_blend", 0.4),
         "precision": kwargs.get("precision", "fp16"),
+        "chunker": kwargs.get("chunker", "ola"),
+        "overlap": kwargs.get("overlap", 0.25),
+        "num_gpus": kwargs.get("num_gpus", 1),
     }
     return predict_with_model(options, callback, separator=kwargs.get("separator"))

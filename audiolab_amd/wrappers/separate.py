@@ -65,9 +65,21 @@ class Separate(BaseWrapper):
         "crowd_removal_model": TypedInput(default="UVR-MDX-NET_Crowd_HQ_1.onnx", type=str, gradio_type="Dropdown",
                                           choices=["UVR-MDX-NET_Crowd_HQ_1.onnx", "mel_band_roformer_crowd_aufr33_viperx_sdr_8.7144.ckpt"],
                                           description="Select the model for crowd noise removal."),
+        # --- this build's engine knobs, after the reference's 15 keys and never rendered (base_wrapper.py:376-425 turns every entry of
+        # this table into a validated settings field; render=False keeps it out of the UI as bg_vocal_layers above) ---
+        "precision": TypedInput(default="fp16", type=str, choices=["fp16", "bf16", "fp32"], gradio_type="Dropdown", render=False,
+                                description="Arithmetic of the separation networks: fp16 (the reference's autocast), bf16, or fp32."),
+        "chunker": TypedInput(default="ola", type=str, choices=["ola", "margin"], gradio_type="Dropdown", render=False,
+                              description="MDX-Net runner: 'ola' = audio-separator's overlap-add (what the reference runs), "
+                                          "'margin' = the in-tree mdxnet.py margin chunker."),
+        "overlap": TypedInput(default=0.25, ge=0.0, le=0.99, type=float, gradio_type="Slider", render=False,
+                              description="Chunk overlap of the overlap-add runner."),
+        "num_gpus": TypedInput(default=1, ge=1, le=8, type=int, gradio_type="Slider", render=False,
+                               description="Ranks (one process per GPU, torch.distributed) that shard every model's chunks."),
     }
+    ENGINE_KNOBS = {"precision": "fp16", "chunker": "ola", "overlap": 0.25, "num_gpus": 1}
 
-    # engine-level options of this build (not rendered; reach separate_music when set on the instance)
+    # further engine-level options (a pre-built engine under "separator", ensemble_strength, ...) reach separate_music when set here
     engine_options: Dict[str, Any] = {}
 
     def process_audio(self, inputs: List[ProjectFiles], callback=None, **kwargs: Dict[str, Any]) -> List[ProjectFiles]:
@@ -102,6 +114,11 @@ class Separate(BaseWrapper):
                 "crowd_removal_model": g("crowd_removal_model", "UVR-MDX-NET_Crowd_HQ_1.onnx"),
                 "store_reverb_ir": g("store_reverb_ir", True),
             }
+            # an engine knob away from its default changes the stems: it joins the key then (at the defaults the key is the reference's)
+            for knob, dflt in self.ENGINE_KNOBS.items():
+                val = filtered_kwargs.get(knob, self.engine_options.get(knob, dflt))
+                if knob != "num_gpus" and val != dflt:
+                    current_config[knob] = val
             eng = self.engine_options.get("separator")
             if eng is not None and getattr(eng, "allow_synthetic", False):
                 # stems made from random-init weights (bench / tests) must never satisfy a later run with real models;
@@ -136,7 +153,7 @@ class Separate(BaseWrapper):
                 os.makedirs(stem_dir, exist_ok=True)
                 input_dict.setdefault(stem_dir, []).append(proj.src_file)
                 project_map[os.path.basename(proj.project_dir)] = (proj, cfg)
-            combined = separate_music(input_dict=input_dict, callback=callback, **filtered_kwargs, **self.engine_options)
+            combined = separate_music(input_dict=input_dict, callback=callback, **{**self.engine_options, **filtered_kwargs})
             results: Dict[str, List[str]] = {}
             skip_parts = os.path.join(config.output_path, "process").split(os.path.sep)
             for stem in combined:                                                                 # :343-351

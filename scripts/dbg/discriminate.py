@@ -1,4 +1,8 @@
-"""Discriminating experiments for the cross-stream corruption (VERDICT r3 "what's weak" 3).
+"""(neutral.hip aggressor codes: "neutral:<lds bytes>:<0 = 112 VGPRs | 1 = 256 VGPRs | 2 = no MFMA, VALU fma instead>"; victim "nv3" = a dense butterfly network in plain C++ that the compiler turns into packed f32 arithmetic, checked against an int32
+model; victim "nv2" = the
+instruction classes of the FFT kernels -- packed f32 arithmetic with op_sel / neg, scalar fma, the LDS access shapes -- self-checked.)
+
+Discriminating experiments for the cross-stream corruption (VERDICT r3 "what's weak" 3).
 
 Part A -- who is needed for the effect: aggressors {none, libalsep's f16 GEMM, libalsep's f16 convolution, a NEUTRAL f16 MFMA kernel at
 256 VGPRs x 64 KiB LDS (two workgroups per CU), the same at 112 VGPRs, the same at 36 KiB} on one stream x victims {libalsep STFT
@@ -16,6 +20,8 @@ import numpy as np
 import torch
 
 from audiolab_amd import _lib
+if os.environ.get("DBG_LIB"):                                   # a differently compiled libalsep (e.g. fft.hip without packed-f32 SLP)
+    _lib._LIB = _lib.bind(os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ["DBG_LIB"]))
 from audiolab_amd._lib import Context
 from audiolab_amd.mdx import StftPlan
 from audiolab_amd.synth import synth_mix
@@ -25,6 +31,10 @@ neu = C.CDLL(os.path.join(HERE, "libneutral.so"))
 neu.nv_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 neu.nv_launch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
 neu.na_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+neu.nv2_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+neu.nv3_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+neu.nv4_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+neu.nv5_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 
 ctx0 = _lib.Context("cuda:0")
 lib = ctx0.lib
@@ -67,6 +77,16 @@ def victim(kind):
     """-> (result tensor or None, self-check counts or None)"""
     if kind.startswith("stft"):
         return plans[int(kind[4:])].stft_strided(x, L, 2 * L, 1, torch.float32, _lib.LAYOUT_REF), None
+    if kind in ("nv3", "nv4", "nv5"):
+        bad.zero_()
+        rc = {"nv3": neu.nv3_launch, "nv4": neu.nv4_launch, "nv5": neu.nv5_launch}[kind](C.c_void_p(streams[0].cuda_stream), 2048, 64, C.c_void_p(bad.data_ptr()))
+        assert rc == 0, rc
+        return None, bad
+    if kind == "nv2":
+        bad.zero_()
+        rc = neu.nv2_launch(C.c_void_p(streams[0].cuda_stream), 1024, 24, C.c_void_p(bad.data_ptr()))
+        assert rc == 0, rc
+        return None, bad
     _, lds = kind.split(":")
     bad.zero_()
     rc = neu.nv_launch(C.c_void_p(streams[0].cuda_stream), 1024, C.c_void_p(tab.data_ptr()), NTAB, int(lds), 24, C.c_void_p(bad.data_ptr()))
@@ -74,8 +94,12 @@ def victim(kind):
     return None, bad
 
 
-AGGRESSORS = ["none", "lib_gemm_hh", "lib_conv_hh", "neutral:65536:1", "neutral:65536:0", "neutral:36864:1"]
-VICTIMS = ["stft8192", "stft2048", "stft4096", "nvictim:32768", "nvictim:49152", "nvictim:65536"]
+AGGRESSORS = ["none", "lib_gemm_hh", "lib_conv_hh", "neutral:65536:1", "neutral:65536:0", "neutral:36864:1", "neutral:65536:2"]
+VICTIMS = ["stft8192", "stft2048", "stft4096", "nvictim:32768", "nvictim:65536", "nv2", "nv3", "nv4", "nv5"]
+if os.environ.get("XS_VICTIMS"):
+    VICTIMS = os.environ["XS_VICTIMS"].split(",")
+if os.environ.get("XS_AGGRESSORS"):
+    AGGRESSORS = os.environ["XS_AGGRESSORS"].split(",")
 REPS = int(os.environ.get("XS_REPS", "10"))
 print("== part A: corrupted victim launches out of", REPS, "(victim on stream 0, aggressor on stream 1)", flush=True)
 refs = {}
@@ -107,9 +131,11 @@ for a in AGGRESSORS:
                             saved.append((a, t, got[0, :, :, t].cpu().numpy(), refs[v][0, :, :, t].cpu().numpy()))
             else:
                 cnt = counts.cpu().tolist()
-                if cnt[0] or cnt[1]:
+                if cnt[0] or cnt[1] or (v == "nv2" and cnt[2]):
                     nbad += 1
-                    detail = f" (table-in-register mismatches {cnt[0]}, after-LDS mismatches {cnt[1]}, workgroups {cnt[2]})"
+                    detail = (f" (wrong components {cnt[0]}, workgroups {cnt[1]})" if v in ("nv3", "nv4", "nv5") else
+                              f" (packed-f32 {cnt[0]}, scalar fma {cnt[1]}, LDS {cnt[2]}, workgroups {cnt[3]})" if v == "nv2" else
+                              f" (table-in-register mismatches {cnt[0]}, after-LDS mismatches {cnt[1]}, workgroups {cnt[2]})")
         row.append(f"{v}: {nbad}{detail}")
     print(f"aggressor {a:18s} | " + " | ".join(row), flush=True)
 

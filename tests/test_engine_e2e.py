@@ -85,6 +85,66 @@ def test_separate_end_to_end_vs_oracle(dev, tmp_path, monkeypatch):
     assert calls
 
 
+def test_separate_music_at_defaults_runs_the_reference_runner(dev, tmp_path, monkeypatch):
+    """Row a19: through the UNCHANGED wrapper with no pre-built engine, the orchestrator builds the engine the reference builds at
+    stem_separator.py:102-107 -- audio-separator's MDX runner: normalise 0.9, Hann overlap-add at overlap 0.25, compensate, secondary stem
+    by spectral inversion (:104) -- and an .onnx member found under <app>/models/audio_separator runs through it (:281).  Two MDX-Net vocal
+    files (small graphs written here; n_fft 7680 and the compensation come from the roster, as for the real files) stand for the
+    reference's .onnx ensemble members; ``precision`` travels as one of the wrapper's hidden inputs.  Against mdx_oracle.separate_ola."""
+    from audiolab_amd import wavio
+    from audiolab_amd.engine import MODEL_ROSTER
+    from audiolab_amd.handlers import config
+    from audiolab_amd.separator import stem_separator
+    from audiolab_amd.synth import synthetic_state_dict
+    from audiolab_amd.tdfnet import TDFNetConfig
+    from audiolab_amd.util.data_classes import ProjectFiles
+    from audiolab_amd.wrappers.separate import Separate
+    from tests.onnx_writer import write_mdx_onnx
+    monkeypatch.setattr(config, "app_path", str(tmp_path))
+    monkeypatch.setattr(config, "output_path", str(tmp_path / "outputs"))
+    Separate._instance = None
+    members = [("UVR-MDX-NET-Voc_FT.onnx", 6.9, 14.9), ("Kim_Vocal_2.onnx", 6.9, 14.9)]
+    monkeypatch.setattr(stem_separator.EnsembleDemucsMDXMusicSeparationModel, "ENSEMBLE", members)
+    mdir = tmp_path / "models" / "audio_separator"
+    os.makedirs(mdir)
+    nets = {}
+    for k, (name, _, _) in enumerate(members):
+        cfg = TDFNetConfig(dim_f=64, dim_t=16, n_fft=7680, hop=1024, num_blocks=3, g=16, bn=4 if k else 0)
+        sd = synthetic_state_dict(cfg, seed=40 + k)
+        write_mdx_onnx(str(mdir / name), sd, cfg)
+        nets[name] = (cfg, sd, MODEL_ROSTER[name][3]["compensate"])
+    n = 33000                                                    # chunk 15 360 samples, step 11 520: four chunks with a ragged tail
+    mix = synth_mix(n, seed=77) * 1.9                            # peaks above 0.9: the normalisation acts
+    assert np.abs(mix).max() > 0.9
+    src = tmp_path / "loud.wav"
+    wavio.write_wav(str(src), mix, 44100)
+    monkeypatch.setattr(Separate, "engine_options", {})          # nothing pre-built: separate_music's own defaults
+    out = Separate().process_audio([ProjectFiles(str(src))], precision="fp32", separate_bg_vocals=False)
+    stems = {os.path.basename(p).split("__")[1][:-4]: wavio.read_wav(p)[0] for p in out[0].last_outputs}
+    assert set(stems) == {"(Vocals)", "(Instrumental)"}
+    v, i = [], []
+    for name, (cfg, sd, comp) in nets.items():
+        g = mo.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
+
+        def run(spek, sd=sd, cfg=cfg):
+            return tdfnet_oracle.forward(sd, torch.from_numpy(np.ascontiguousarray(spek, dtype=np.float32)), cfg.num_blocks, cfg.l, cfg.bn).numpy()
+        assert len(mo.ola_plan(n, g, 0.25)["starts"]) >= 3
+        prim, sec = mo.separate_ola(mix, g, run, overlap=0.25, compensate=comp, invert_using_spec=True, normalization=0.9)
+        v.append(prim)
+        i.append(sec)
+    vocals = eo.blend_tracks(v, [6.9, 6.9])
+    inst = eo.blend_tracks(i, [14.9, 14.9])
+    inst, _ = eo.debleed(mix, vocals, inst, 44100, 0.2)
+    for k, want in (("(Vocals)", vocals), ("(Instrumental)", inst)):
+        err = float(np.max(np.abs(stems[k] - want)))
+        assert stems[k].shape == (2, n) and np.abs(want).max() > 1e-3 and err < 1e-4, f"{k}: {err:.3e}"
+    # the in-tree runner stays one hidden input away and gives a different (margin-stitched, mix - primary) result
+    Separate._instance = None
+    out2 = Separate().process_audio([ProjectFiles(str(src))], precision="fp32", chunker="margin", separate_bg_vocals=False)
+    v2 = [wavio.read_wav(p)[0] for p in out2[0].last_outputs if "(Vocals)" in p][0]
+    assert float(np.max(np.abs(v2 - stems["(Vocals)"]))) > 1e-3
+
+
 def test_multichannel_ola_075_vs_oracle(dev):
     """BASELINE configs[4] in miniature: multichannel input as stereo pairs (3 channels: one pair and an odd last channel), Hann overlap-add
     chunker at overlap 0.75, against the oracle run on every pair."""

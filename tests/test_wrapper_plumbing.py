@@ -73,9 +73,12 @@ def test_allowed_kwargs_match_reference_table():
     """SURVEY Appendix B."""
     from audiolab_amd.wrappers.separate import Separate
     ak = Separate.allowed_kwargs
-    assert list(ak) == ["delete_extra_stems", "separate_bg_vocals", "bg_vocal_layers", "vocals_only", "store_reverb_ir",
-                        "separate_drums", "separate_woodwinds", "alt_bass_model", "reverb_removal", "echo_removal",
-                        "crowd_removal", "noise_removal", "noise_removal_model", "delay_removal_model", "crowd_removal_model"]
+    assert list(ak)[:15] == ["delete_extra_stems", "separate_bg_vocals", "bg_vocal_layers", "vocals_only", "store_reverb_ir",
+                             "separate_drums", "separate_woodwinds", "alt_bass_model", "reverb_removal", "echo_removal",
+                             "crowd_removal", "noise_removal", "noise_removal_model", "delay_removal_model", "crowd_removal_model"]
+    # this build's engine knobs follow the reference's keys and are never rendered (SURVEY section 5)
+    assert list(ak)[15:] == ["precision", "chunker", "overlap", "num_gpus"] and all(ak[k].render is False for k in list(ak)[15:])
+    assert ak["chunker"].field.default == "ola" and ak["precision"].choices == ["fp16", "bf16", "fp32"] and ak["num_gpus"].field.le == 8
     assert ak["vocals_only"].field.default is True and ak["separate_bg_vocals"].field.default is False
     assert ak["bg_vocal_layers"].field.ge == 1 and ak["bg_vocal_layers"].field.le == 10 and ak["bg_vocal_layers"].render is False
     assert ak["reverb_removal"].choices == ["Nothing", "Main Vocals", "All Vocals", "All"]
