@@ -33,10 +33,13 @@ class AlsepError(RuntimeError):
     pass
 
 
+NET_SPLIT_F16 = 1          # alsep_net_config.flags: float32 storage, contractions as split-half products on the 16-bit matrix pipe
+
+
 class NetConfig(C.Structure):
     _fields_ = [("dim_f", C.c_int32), ("dim_t", C.c_int32), ("num_blocks", C.c_int32),
                 ("l", C.c_int32), ("g", C.c_int32), ("bn", C.c_int32), ("dtype", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("flags", C.c_int32)]
 
 
 class TensorEntry(C.Structure):
@@ -75,6 +78,7 @@ _SIGNATURES = {
     "alsep_resample_fft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                      C.c_int64]),
     "alsep_zero_low_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int]),
+    "alsep_net_range_flag": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "alsep_net_create": (C.c_int, [C.c_void_p, C.POINTER(NetConfig), C.POINTER(TensorEntry), C.c_int64,
                                    C.POINTER(C.c_void_p)]),
     "alsep_net_destroy": (C.c_int, [C.c_void_p]),

@@ -2813,6 +2813,10 @@ us_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf1
     }
 }
 
+#ifndef ALSEP_F16_TU
+#include "tdfnet_f32s.h"     // float32 storage with split-half contractions (the float32 network lives in the main translation unit)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // host side: packing + orchestration
 // ------------------------------------------------------------------------------------------
@@ -2828,11 +2832,15 @@ struct ConvLayer {       // 3x3
     DevBuf w_mq;             // conv3x3_bf16_mq_kernel's image (c = 96)
     int cin = 0, cout = 0;
     bool dma_path = false;   // packed for conv3x3_bf16_kernel (swizzled, unpadded)
+    int split = 0;           // float32 storage, split-half contraction (tdfnet_f32s.h): 24 = <24, 48> tiles, 16 = <16, 16>
+    unsigned* range_flag = nullptr;   // the network's range word (split layers)
 };
 struct GemmLayer {       // ds / us / tdf
     DevBuf w, bias, scale, shift;
     int M = 0, K = 0, Kp = 0, Mp = 0;
     bool has_bias = false;
+    bool split = false;      // float32 storage, split-half contraction: w = [hi | lo][Mp][Kp] halves (tdfnet_f32s.h)
+    unsigned* range_flag = nullptr;
     bool dma_path = false;   // packed for tdf_bf16_kernel
     DevBuf wfrag;            // [m-tile][k-step][lane][8] for the streaming ds/us kernels (bf16, levels 0 <-> 1 <-> 2)
     DevBuf wwide;            // fragment-order image for tdf_bf16_wide_kernel (bf16, M % 192 == 0)
@@ -2848,6 +2856,8 @@ struct alsep_net {
     alsep_ctx* ctx = nullptr;
     alsep_net_config cfg{};
     int n = 0;
+    bool split = false;      // cfg.flags & ALSEP_NET_SPLIT_F16 on a float32 network
+    DevBuf range_flag;       // split networks: one word the kernels raise when an operand leaves the half range
     std::vector<DevBuf> owned;
     DevBuf first_w, first_scale, first_shift, final_w, final_b, zero_page;
     std::vector<Block> enc, dec;
@@ -3006,6 +3016,14 @@ int make_conv(alsep_net* net, const TensorMap& tm, const std::string& p, int c, 
     if (!w || !sc || !sh) return ALSEP_ERR_ARG;
     L->cin = L->cout = c;
     int rc;
+#ifndef ALSEP_F16_TU
+    if (!is_bf16<T>() && net->split && (c % 48 == 0 || c % 16 == 0)) {
+        L->split = c % 48 == 0 ? 24 : 16;
+        L->range_flag = (unsigned*)net->range_flag.p;
+        const std::vector<hs_t> pk = L->split == 24 ? pack_conv3x3_split<24, 48>(*w, c, c) : pack_conv3x3_split<16, 16>(*w, c, c);
+        rc = upload(net, pk.data(), pk.size() * sizeof(hs_t), &L->w);
+    } else
+#endif
     if (is_bf16<T>() && c % 48 == 0) {
         L->dma_path = true;
         auto pk = pack_conv3x3_dma(*w, c, c);
@@ -3045,6 +3063,14 @@ template <typename T>
 int make_gemm_weights(alsep_net* net, const std::vector<float>& wmk, int M, int K, GemmLayer* L) {
     typedef GemmCfg<T> Gc;
     L->M = M; L->K = K;
+#ifndef ALSEP_F16_TU
+    if (!is_bf16<T>() && net->split) {
+        L->split = true;
+        L->range_flag = (unsigned*)net->range_flag.p;
+        const std::vector<hs_t> pk = pack_gemm_split(wmk, M, K, &L->Mp, &L->Kp);
+        return upload(net, pk.data(), pk.size() * sizeof(hs_t), &L->w);
+    }
+#endif
     L->Mp = (int)ceil_div64(M, Gc::BR) * Gc::BR;
     L->Kp = (int)ceil_div64(K, Gc::BK) * Gc::BK;
     std::vector<T> pk((size_t)L->Mp * L->Kp, host_cast<T>(0.f));
@@ -3165,6 +3191,7 @@ int build_net(alsep_net* net, const TensorMap& tm) {
         if ((rc = upload(net, fb->data(), 16, &net->final_b))) return rc;
         const std::vector<char> zeros(256, 0);
         if ((rc = upload(net, zeros.data(), zeros.size(), &net->zero_page))) return rc;
+        if ((rc = upload(net, zeros.data(), 16, &net->range_flag))) return rc;
     }
     net->enc.resize(n); net->dec.resize(n); net->ds.resize(n); net->us.resize(n);
     int c = g, f = cfg.dim_f;
@@ -3684,8 +3711,44 @@ int run_conv_dma(alsep_ctx* ctx, const ConvLayer&, const float*, float*, const f
     return alsep_fail(ctx, ALSEP_ERR_STATE, "LDS-DMA conv path is bf16 only");
 }
 
+#ifndef ALSEP_F16_TU
+template <int KC, int BN, int TW>
+int launch_conv_split(alsep_ctx* ctx, const ConvLayer& L, const float* X, float* Y, int64_t B, int Th, int Fw) {
+    typedef ConvSCfg<KC, BN, TW> Cf;
+    const int tiles_t = (int)ceil_div64(Th, Cf::TH), tiles_f = (int)ceil_div64(Fw, TW);
+    const int64_t ntiles = B * tiles_t * tiles_f;
+    const int nyc = L.cout / BN;
+    if (ntiles * nyc > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "conv3x3: too many tiles");
+    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)conv3x3_f32s_kernel<KC, BN, TW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)Cf::lds_bytes));
+    ProfScope prof(ctx, TW >= 32 ? ALSEP_PROF_CONV3X3 : ALSEP_PROF_CONV3X3_SMALL);
+    prof.work(18.0 * (double)L.cin * L.cout * B * Th * Fw, 4.0 * B * Th * Fw * (L.cin + L.cout));
+    const int nyf = (ntiles % 8 == 0 && nyc > 1) ? 1 : 0;
+    const dim3 grid = nyf ? dim3((unsigned)(ntiles * nyc)) : dim3((unsigned)ntiles, nyc);
+    hipLaunchKernelGGL((conv3x3_f32s_kernel<KC, BN, TW>), grid, dim3(kThreads), Cf::lds_bytes, ctx->stream, X, Y,
+                       (const hs_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, Th, Fw, L.cin, L.cout, tiles_t, tiles_f,
+                       (int)ntiles, nyf, L.range_flag);
+    ALSEP_LAUNCH_CHECK(ctx, "conv3x3_f32s_kernel");
+    return ALSEP_OK;
+}
+template <int KC, int BN>
+int run_conv_split_tw(alsep_ctx* ctx, const ConvLayer& L, const float* X, float* Y, int64_t B, int Th, int Fw) {
+    if (Fw >= 32) return launch_conv_split<KC, BN, 32>(ctx, L, X, Y, B, Th, Fw);      // 8 x 32 tiles: 76 KiB, two workgroups per CU
+    return launch_conv_split<KC, BN, 16>(ctx, L, X, Y, B, Th, Fw);
+}
+int run_conv_split(alsep_ctx* ctx, const ConvLayer& L, const float* X, float* Y, int64_t B, int Th, int Fw) {
+    return L.split == 24 ? run_conv_split_tw<24, 48>(ctx, L, X, Y, B, Th, Fw) : run_conv_split_tw<16, 16>(ctx, L, X, Y, B, Th, Fw);
+}
+int run_conv_split(alsep_ctx* ctx, const ConvLayer&, const bf16_t*, bf16_t*, int64_t, int, int) {
+    return alsep_fail(ctx, ALSEP_ERR_STATE, "split contraction is a float32 mode");
+}
+#endif
+
 template <typename T>
 int run_conv(alsep_ctx* ctx, const ConvLayer& L, const T* X, T* Y, int64_t B, int Th, int Fw, const void* zero_page) {
+#ifndef ALSEP_F16_TU
+    if (L.split) return run_conv_split(ctx, L, X, Y, B, Th, Fw);
+#endif
     if (L.dma_path) return run_conv_dma(ctx, L, X, Y, (const T*)zero_page, B, Th, Fw);
     if (conv_uses_main<T>(L.cin, L.cout)) return run_conv_tw<T, ConvSel<T>::KC, ConvSel<T>::BN>(ctx, L, X, Y, B, Th, Fw);
     return run_conv_tw<T, ConvSel16<T>::KC, ConvSel16<T>::BN>(ctx, L, X, Y, B, Th, Fw);
@@ -3738,9 +3801,59 @@ int run_pix_stream(alsep_ctx* ctx, int, const GemmLayer&, const float*, float*, 
     return alsep_fail(ctx, ALSEP_ERR_STATE, "streaming ds/us path is bf16 only");
 }
 
+#ifndef ALSEP_F16_TU
+template <int MODE>
+int run_pix_split(alsep_ctx* ctx, const GemmLayer& L, const float* X, float* Y, const float* skip, int64_t ncols, int Tp, int Fp, int C, int C2) {
+    typedef GemmSCfg Gc;
+    const int64_t gx = ceil_div64(ncols, Gc::BC);
+    if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "pix_gemm: too many column tiles");
+    ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)pix_gemm_f32s_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Gc::lds_bytes));
+    ProfScope prof(ctx, ALSEP_PROF_PIX);
+    const int nrb = L.Mp / Gc::BR;
+    const int fast = (nrb > 1 && gx % 8 == 0 && gx * nrb <= 0x7fffffff) ? nrb : 0;
+    hipLaunchKernelGGL((pix_gemm_f32s_kernel<MODE>), fast ? dim3((unsigned)(gx * nrb)) : dim3((unsigned)gx, nrb), dim3(kThreads), Gc::lds_bytes,
+                       ctx->stream, X, Y, (const hs_t*)L.w.p, (const float*)L.scale.p, (const float*)L.shift.p, skip, L.M, L.Mp, L.K, L.Kp, ncols,
+                       Tp, Fp, C, C2, L.range_flag, fast);
+    ALSEP_LAUNCH_CHECK(ctx, "pix_gemm_f32s_kernel");
+    return ALSEP_OK;
+}
+template <int MODE>
+int run_pix_split(alsep_ctx* ctx, const GemmLayer&, const bf16_t*, bf16_t*, const bf16_t*, int64_t, int, int, int, int) {
+    return alsep_fail(ctx, ALSEP_ERR_STATE, "split contraction is a float32 mode");
+}
+int run_tdf_split(alsep_ctx* ctx, const GemmLayer& L, const float* X, float* Y, const float* R, int64_t BT, int C) {
+    typedef GemmSCfg Gc;
+    const int64_t nunits = BT * (C / 16);
+    const int64_t gx = ceil_div64(nunits, 8);
+    if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "tdf_gemm: too many column tiles");
+    const float* bias = L.has_bias ? (const float*)L.bias.p : nullptr;
+    ProfScope prof(ctx, ALSEP_PROF_TDF);
+    const int nrb = L.Mp / Gc::BR;
+    const int fast = (nrb > 1 && gx % 8 == 0 && gx * nrb <= 0x7fffffff) ? nrb : 0;
+    const dim3 grid = fast ? dim3((unsigned)(gx * nrb)) : dim3((unsigned)gx, nrb);
+    if (R) {
+        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)tdf_gemm_f32s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Gc::lds_bytes));
+        hipLaunchKernelGGL((tdf_gemm_f32s_kernel<true>), grid, dim3(kThreads), Gc::lds_bytes, ctx->stream, X, Y, (const hs_t*)L.w.p, bias,
+                           (const float*)L.scale.p, (const float*)L.shift.p, R, L.M, L.Mp, L.K, L.Kp, nunits, C, L.range_flag, fast);
+    } else {
+        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)tdf_gemm_f32s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Gc::lds_bytes));
+        hipLaunchKernelGGL((tdf_gemm_f32s_kernel<false>), grid, dim3(kThreads), Gc::lds_bytes, ctx->stream, X, Y, (const hs_t*)L.w.p, bias,
+                           (const float*)L.scale.p, (const float*)L.shift.p, R, L.M, L.Mp, L.K, L.Kp, nunits, C, L.range_flag, fast);
+    }
+    ALSEP_LAUNCH_CHECK(ctx, "tdf_gemm_f32s_kernel");
+    return ALSEP_OK;
+}
+int run_tdf_split(alsep_ctx* ctx, const GemmLayer&, const bf16_t*, bf16_t*, const bf16_t*, int64_t, int) {
+    return alsep_fail(ctx, ALSEP_ERR_STATE, "split contraction is a float32 mode");
+}
+#endif
+
 template <typename T, int MODE>
 int run_pix(alsep_ctx* ctx, const GemmLayer& L, const T* X, T* Y, const T* skip, int64_t ncols, int Tp, int Fp, int C, int C2) {
     typedef GemmCfg<T> Gc;
+#ifndef ALSEP_F16_TU
+    if (L.split) return run_pix_split<MODE>(ctx, L, X, Y, skip, ncols, Tp, Fp, C, C2);
+#endif
     if (L.wfrag.p && pix_stream_enabled() && Fp % 64 == 0) return run_pix_stream(ctx, MODE, L, X, Y, skip, ncols, Tp, Fp);
     const int64_t gx = ceil_div64(ncols, Gc::BC);
     if (gx > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "pix_gemm: too many column tiles");
@@ -3825,6 +3938,9 @@ int run_tdf_dma(alsep_ctx* ctx, const GemmLayer&, const float*, float*, const fl
 template <typename T>
 int run_tdf(alsep_ctx* ctx, const GemmLayer& L, const T* X, T* Y, const T* R, int64_t BT, int C, const void* zero_page) {
     typedef GemmCfg<T> Gc;
+#ifndef ALSEP_F16_TU
+    if (L.split) return run_tdf_split(ctx, L, X, Y, R, BT, C);
+#endif
     if (L.dma_path) return run_tdf_dma(ctx, L, X, Y, R, (const T*)zero_page, BT, C);
     const int64_t nunits = BT * (C / 16);
     const int64_t gx = ceil_div64(nunits, 8);
@@ -3976,6 +4092,8 @@ extern "C" int ALSEP_TU_NAME(alsep_net_create)(alsep_ctx* ctx, const alsep_net_c
     if (cfg->num_blocks < 1 || cfg->l < 1 || cfg->g < 16 || cfg->g % 16 != 0 || cfg->bn < 0 ||
         (cfg->dtype != ALSEP_F32 && cfg->dtype != ALSEP_HALF_DTYPE))
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_create: unsupported config (g must be a multiple of 16)");
+    if ((cfg->flags & ~ALSEP_NET_SPLIT_F16) != 0 || ((cfg->flags & ALSEP_NET_SPLIT_F16) && cfg->dtype != ALSEP_F32))
+        return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_create: unknown flags, or ALSEP_NET_SPLIT_F16 on a network that is not float32");
     if (cfg->dim_f % (1 << n) != 0 || cfg->dim_t % (1 << n) != 0 ||
         (cfg->bn > 0 && (cfg->dim_f >> n) % cfg->bn != 0))
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_create: dim_f/dim_t not divisible by 2^%d (and bn)", n);
@@ -3992,6 +4110,7 @@ extern "C" int ALSEP_TU_NAME(alsep_net_create)(alsep_ctx* ctx, const alsep_net_c
     net->ctx = ctx;
     net->cfg = *cfg;
     net->n = n;
+    net->split = cfg->dtype == ALSEP_F32 && (cfg->flags & ALSEP_NET_SPLIT_F16) != 0;
     const int rc = cfg->dtype == ALSEP_F32 ? build_net<float>(net, tm) : build_net<bf16_t>(net, tm);
     if (rc) {
         const std::string keep = ctx->err;
@@ -4041,6 +4160,24 @@ extern "C" int ALSEP_TU_NAME(alsep_net_forward)(alsep_ctx* ctx, const alsep_net*
         return forward_impl<float>(ctx, net, (const float*)spec_in, (float*)spec_out, B, (char*)workspace, in_scale, out_alpha, out_beta);
     return forward_impl<bf16_t>(ctx, net, (const bf16_t*)spec_in, (bf16_t*)spec_out, B, (char*)workspace, in_scale, out_alpha, out_beta);
 }
+
+// 1 when a float32 network with split-half contractions (ALSEP_NET_SPLIT_F16) has met an operand beyond the half range (|x| > 65504, or
+// not a number) in any forward since the last call -- its results are then invalid; reads and clears the word (synchronises the stream).
+// 0 for every other network.
+#ifndef ALSEP_F16_TU
+extern "C" int alsep_net_range_flag(alsep_ctx* ctx, alsep_net* net, int32_t* out) {
+    ALSEP_ENTER(ctx);
+    if (!ctx || !net || !out) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_net_range_flag: null argument");
+    *out = 0;
+    if (!net->split || !net->range_flag.p) return ALSEP_OK;
+    unsigned v = 0;
+    ALSEP_HIP(ctx, hipMemcpyAsync(&v, net->range_flag.p, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    ALSEP_HIP(ctx, hipMemsetAsync(net->range_flag.p, 0, sizeof(v), ctx->stream));
+    ALSEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = v != 0;
+    return ALSEP_OK;
+}
+#endif
 
 extern "C" int alsep_net_forward_pcm_f16tu(alsep_ctx*, const alsep_net*, const alsep_plan*, const float*, int64_t, int64_t, void*, int64_t, void*,
                                            int64_t, float, float, float, int);

@@ -174,7 +174,7 @@ class Separator:
                  dtype: Optional[torch.dtype] = None, sample_rate: int = 44100, chunks: int = 0, margin: int = 44100,
                  denoise: bool = False, max_batch: int = 32, sharded: bool = False, roster: Optional[Dict[str, tuple]] = None,
                  chunker: str = "margin", overlap: float = 0.25, compensate: Optional[float] = None,
-                 allow_synthetic: bool = False, normalization_threshold: float = 0.9, **_ignored):
+                 allow_synthetic: bool = False, normalization_threshold: float = 0.9, f32_contraction: str = "split", **_ignored):
         """``allow_synthetic=True`` (bench, tests): a roster name without a weight file gets seeded random-init weights.
         The default refuses to: a missing model file is an error, never plausible-looking noise."""
         self.log_level = log_level
@@ -199,6 +199,11 @@ class Separator:
             raise AlsepError("chunker must be 'margin' (in-tree runner, pinned) or 'ola' (audio-separator style, unpinned)")
         self.chunker, self.overlap, self.compensate = chunker, overlap, compensate
         self.allow_synthetic = bool(allow_synthetic)
+        # float32 TFC-TDF networks: "split" = float32 storage with the contractions as (hi, lo) half products on the 16-bit matrix pipe
+        # (float32 accuracy at ~3 x the speed; activations limited to the half range, checked per run), "exact" = f32 MFMA fmaf chains
+        if f32_contraction not in ("split", "exact"):
+            raise AlsepError("f32_contraction must be 'split' or 'exact'")
+        self.f32_contraction = f32_contraction
         self.model_instance: Optional[_ModelInstance] = None
         self._cache: Dict[str, _ModelInstance] = {}
 
@@ -274,7 +279,8 @@ class Separator:
             else:
                 raise AlsepError(f"model '{model_filename}': no weight file ({os.path.join(self.model_file_dir, model_filename)} "
                                  f"or {pt}); random-init weights are only used with Separator(allow_synthetic=True)")
-            net = TDFNet(cfg, sd, ctx=self.ctx, dtype=self.dtype, max_batch=self.max_batch)
+            net = TDFNet(cfg, sd, ctx=self.ctx, dtype=self.dtype, max_batch=self.max_batch,
+                         contraction=self.f32_contraction if self.dtype == torch.float32 else None)
             dim_t_arg = int(cfg.dim_t).bit_length() - 1
             args = types.SimpleNamespace(margin=self.margin, chunks=self.chunks, denoise=self.denoise, dim_f=cfg.dim_f,
                                          dim_t=dim_t_arg, n_fft=cfg.n_fft)

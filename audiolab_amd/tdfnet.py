@@ -127,7 +127,16 @@ class TDFNet:
     surface of the reference seam (``run(None, {"input": spek[B,4,dim_f,dim_t]}) -> [pred]``)."""
 
     def __init__(self, cfg: TDFNetConfig, state_dict: Dict[str, torch.Tensor], ctx: Optional[Context] = None,
-                 dtype: torch.dtype = torch.float32, max_batch: int = 4):
+                 dtype: torch.dtype = torch.float32, max_batch: int = 4, contraction: Optional[str] = None):
+        """``contraction`` (float32 networks only): "split" (default) = float32 storage with every contraction as three f16 MFMA products
+        of (hi, lo) half pairs, float32 accumulation -- the float32 mode's accuracy (2^-22 per product) at five times its matrix
+        throughput, activations limited to the half range (65504; beyond it the output is Inf / NaN and the runners raise); "exact" =
+        v_mfma_f32_16x16x4_f32, bit for bit an fmaf chain."""
+        if contraction is None:
+            contraction = "split" if dtype == torch.float32 else "native"
+        if (dtype == torch.float32) != (contraction in ("split", "exact")) or contraction not in ("split", "exact", "native"):
+            raise AlsepError(f"contraction={contraction!r} does not fit dtype {dtype} ('split' / 'exact' are the float32 modes)")
+        self.contraction = contraction
         if cfg.k != 3:
             raise AlsepError("only k=3 TFC convolutions are implemented")
         if cfg.bn is None:
@@ -152,7 +161,8 @@ class TDFNet:
             entries[i].name = name.encode()
             entries[i].data = d.data_ptr()
             entries[i].numel = d.numel()
-        ncfg = _lib.NetConfig(cfg.dim_f, cfg.dim_t, cfg.num_blocks, cfg.l, cfg.g, cfg.bn, _lib.dtype_code(dtype), 0)
+        ncfg = _lib.NetConfig(cfg.dim_f, cfg.dim_t, cfg.num_blocks, cfg.l, cfg.g, cfg.bn, _lib.dtype_code(dtype),
+                               _lib.NET_SPLIT_F16 if contraction == "split" else 0)
         self.ctx.synchronize()
         h = C.c_void_p()
         self.ctx.check(self.ctx.lib.alsep_net_create(self.ctx.handle, C.byref(ncfg), entries, len(table), C.byref(h)),
@@ -169,6 +179,15 @@ class TDFNet:
                 self.handle = None
         except Exception:
             pass
+
+    def range_exceeded(self) -> bool:
+        """split-contraction networks: True when a forward since the last call met an activation beyond the half range (its results are
+        invalid); reads and clears the network's range word (synchronises the stream).  Always False for the other modes."""
+        if self.contraction != "split":
+            return False
+        flag = C.c_int32(0)
+        self.ctx.check(self.ctx.lib.alsep_net_range_flag(self.ctx.handle, self.handle, C.byref(flag)), "alsep_net_range_flag")
+        return bool(flag.value)
 
     def workspace(self, batch: int) -> torch.Tensor:
         if self._ws is None or self._ws_batch < batch:

@@ -695,18 +695,20 @@ def main() -> None:
             accuracy[args.dtype] = acc_entry(preds[0].demix(mix[:, :n_acc]).cpu().numpy())
         del stems, preds, nets
         torch.cuda.empty_cache()
-        for name in ("f16", "bf16", "f32"):
+        # "f32": float32 storage, contractions as split-half products on the f16 matrix pipe (TDFNet's float32 default: the 1e-4 mode as
+        # shipped); "f32_exact": the same storage on v_mfma_f32_16x16x4_f32 (fmaf chains)
+        for name in ("f16", "bf16", "f32", "f32_exact"):
             if name == args.dtype:
                 continue
-            dtp = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[name]
-            pb = args.batch if name != "f32" else min(args.batch, 13)          # fp32 activations: twice the workspace per window
-            p_nets = [TDFNet(cfg, sd, ctx=ctx, dtype=dtp, max_batch=pb) for sd in sds]
+            dtp = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32_exact": torch.float32}[name]
+            pb = args.batch if not name.startswith("f32") else min(args.batch, 13)   # fp32 activations: twice the workspace per window
+            p_nets = [TDFNet(cfg, sd, ctx=ctx, dtype=dtp, max_batch=pb, contraction="exact" if name == "f32_exact" else None) for sd in sds]
             p_preds = [Predictor(pargs, net, ctx=ctx, max_batch=0) for net in p_nets]
             if accuracy is not None:
                 accuracy[name] = acc_entry(p_preds[0].demix(mix[:, :n_acc]).cpu().numpy())      # also the warm-up of this type's kernels
             else:
                 p_preds[0].demix(mix[:, :2 * gen - 1])
-            p_steps = 1 if name == "f32" else max(1, min(args.steps, 3))
+            p_steps = 1 if name == "f32_exact" else max(1, min(args.steps, 3))
             [p.demix(mix) for p in p_preds]                  # untimed: workspaces of every model allocated, every kernel of this type loaded
             fence()
             t0 = time.perf_counter()
@@ -717,6 +719,9 @@ def main() -> None:
             assert bool(torch.isfinite(out_p[0]).all())
             precision[name] = {"ms_per_step": round(dtp_s / p_steps * 1e3, 2), "value": round(N_STEMS * (n_samples / SR) * p_steps / dtp_s, 2),
                                "steps": p_steps, "windows_per_launch": pb}
+            if name.startswith("f32"):
+                precision[name]["contraction"] = p_nets[0].contraction
+                precision[name]["realtime_factor_4stem"] = round((n_samples / SR) * p_steps / dtp_s, 1)
             del out_p, p_preds, p_nets
             torch.cuda.empty_cache()
 

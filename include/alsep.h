@@ -168,9 +168,14 @@ typedef struct alsep_net_config {
     int32_t l;            /* convs per TFC block */
     int32_t g;            /* channel growth */
     int32_t bn;           /* TDF bottleneck factor (f -> f/bn -> f); 0 = single f->f linear */
-    int32_t dtype;        /* ALSEP_F32 | ALSEP_BF16 */
-    int32_t reserved;
+    int32_t dtype;        /* ALSEP_F32 | ALSEP_BF16 | ALSEP_F16 */
+    int32_t flags;        /* 0, or ALSEP_NET_SPLIT_F16 (float32 networks only) */
 } alsep_net_config;
+/* float32 storage with the contractions (3x3 convolutions, ds / us, TDF linears) on the 16-bit matrix pipe: every float32 operand is
+ * carried as two IEEE halves (hi, scaled lo) and a product costs three f16 MFMAs accumulated in float32 -- 2^-22 relative per product,
+ * the float32 mode's accuracy at 5 x its matrix throughput; activations must stay inside the half range (|x| <= 65504), beyond it the
+ * outputs are Inf / NaN.  Without the flag a float32 network runs on v_mfma_f32_16x16x4_f32 (exact fmaf chains). */
+#define ALSEP_NET_SPLIT_F16 1
 
 typedef struct alsep_tensor {
     const char* name;     /* e.g. "encoding_blocks.0.tfc.H.1.0.weight", "...scale", "...shift" */
@@ -197,6 +202,11 @@ int alsep_net_forward(alsep_ctx* ctx, const alsep_net* net, const void* spec_in,
 int alsep_net_forward_pcm(alsep_ctx* ctx, const alsep_net* net, const alsep_plan* plan, const float* pcm, int64_t ch_stride,
                           int64_t chunk_stride, void* spec_out, int64_t B, void* workspace, int64_t workspace_bytes, float in_scale,
                           float out_alpha, float out_beta, int zero_low_bins);
+
+/* ALSEP_NET_SPLIT_F16 networks: *out = 1 when any forward since the last call met an operand beyond the half range (|x| > 65504, or not
+ * a number) -- the results of those forwards are invalid (rebuild the network without the flag for such input).  Reads and clears the
+ * network's range word; synchronises ctx's stream.  *out = 0 for every other network. */
+int alsep_net_range_flag(alsep_ctx* ctx, alsep_net* net, int32_t* out);
 
 /* Element-wise / reduction ops of the ensemble stage (stem_separator.py:241-262,173-239,
  * 415-456) and of the MDX runner (mdxnet.py:168-173 denoise average, :211 secondary stem). */

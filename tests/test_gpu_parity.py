@@ -257,19 +257,51 @@ def _full_size_case():
     return _FULL
 
 
-def test_full_size_mdx_f32_vs_oracle(ctx):
-    """The bench architecture in fp32 against the CPU oracle end to end: |delta| < 1e-4 PCM (north_star)."""
+@pytest.mark.parametrize("contraction", ["split", "exact"])
+def test_full_size_mdx_f32_vs_oracle(ctx, contraction):
+    """The bench architecture in float32 storage against the CPU oracle end to end: |delta| < 1e-4 PCM (north_star) -- in BOTH float32
+    modes: "split" (TDFNet's default: every contraction as three f16 MFMA products of (hi, lo) half pairs, csrc/tdfnet_f32s.h) and "exact"
+    (v_mfma_f32_16x16x4_f32 fmaf chains).  Which kernels produced the checked stems is asserted by launch count."""
     from audiolab_amd.mdx import Predictor
     from audiolab_amd.tdfnet import TDFNet
     c = _full_size_case()
     cfg, want = c["cfg"], c["want"]
-    net = TDFNet(cfg, c["sd"], ctx=ctx, dtype=torch.float32, max_batch=2)
+    net = TDFNet(cfg, c["sd"], ctx=ctx, dtype=torch.float32, max_batch=2, contraction=contraction)
+    assert net.contraction == contraction and TDFNet(cfg, c["sd"], ctx=ctx, dtype=torch.float32, max_batch=1).contraction == "split"
     args = types.SimpleNamespace(margin=44100, chunks=0, denoise=False, dim_f=cfg.dim_f, dim_t=8, n_fft=cfg.n_fft)
+    ctx.launch_counts_reset()
     got = Predictor(args, net, ctx=ctx).demix(torch.from_numpy(c["mix"]).cuda()).cpu().numpy()
+    counts = {k: ctx.launch_count(k) for k in ("conv3x3_f32s_kernel", "tdf_gemm_f32s_kernel", "pix_gemm_f32s_kernel", "conv3x3_kernel",
+                                               "tdf_gemm_kernel", "pix_gemm_kernel")}
     err = float(np.max(np.abs(got - want)))
-    print(f"full-size fp32: max|delta| = {err:.3e}, peak = {np.max(np.abs(want)):.3f}, rms = {np.sqrt(np.mean(want ** 2)):.3f}")
+    print(f"full-size fp32 ({contraction}): max|delta| = {err:.3e}, peak = {np.max(np.abs(want)):.3f}, rms = {np.sqrt(np.mean(want ** 2)):.3f}, launches {counts}")
+    if contraction == "split":
+        assert counts["conv3x3_f32s_kernel"] > 0 and counts["tdf_gemm_f32s_kernel"] > 0 and counts["pix_gemm_f32s_kernel"] > 0
+        assert counts["conv3x3_kernel"] == counts["tdf_gemm_kernel"] == counts["pix_gemm_kernel"] == 0
+        assert counts["conv3x3_f32s_kernel"] % 33 == 0 and counts["tdf_gemm_f32s_kernel"] % 22 == 0 and counts["pix_gemm_f32s_kernel"] % 10 == 0   # L = 11: 33 convs, 22 linears, 5 + 5 ds / us per forward
+    else:
+        assert counts["conv3x3_f32s_kernel"] == counts["tdf_gemm_f32s_kernel"] == counts["pix_gemm_f32s_kernel"] == 0
+        assert counts["conv3x3_kernel"] > 0 and counts["tdf_gemm_kernel"] > 0 and counts["pix_gemm_kernel"] > 0
     assert np.max(np.abs(want)) > 1e-2
     assert err < 1e-4
+
+
+def test_split_contraction_reports_activations_beyond_the_half_range(ctx):
+    """an activation above 65504 cannot be carried as an IEEE-half pair: the runner raises instead of returning Inf / NaN stems"""
+    from audiolab_amd._lib import AlsepError
+    from audiolab_amd.mdx import Predictor
+    from audiolab_amd.synth import synth_mix, synthetic_state_dict
+    from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
+    cfg = TDFNetConfig(dim_f=256, dim_t=32, n_fft=512, hop=128, num_blocks=3, g=48)
+    sd = synthetic_state_dict(cfg, seed=0, calib_frames=32)
+    args = types.SimpleNamespace(margin=2205, chunks=0, denoise=False, dim_f=cfg.dim_f, dim_t=5, n_fft=cfg.n_fft)
+    mix = torch.from_numpy(synth_mix(12000)).cuda()
+    ok = Predictor(args, TDFNet(cfg, sd, ctx=ctx, dtype=torch.float32), ctx=ctx, hop=cfg.hop).demix(mix)
+    assert bool(torch.isfinite(ok).all())
+    with pytest.raises(AlsepError, match="half range"):
+        Predictor(args, TDFNet(cfg, sd, ctx=ctx, dtype=torch.float32), ctx=ctx, hop=cfg.hop).demix(mix * 3.0e5)
+    exact = Predictor(args, TDFNet(cfg, sd, ctx=ctx, dtype=torch.float32, contraction="exact"), ctx=ctx, hop=cfg.hop).demix(mix * 3.0e5)
+    assert bool(torch.isfinite(exact).all())
 
 
 def test_full_size_mdx_bf16_vs_oracle(ctx):
