@@ -2360,6 +2360,11 @@ __device__ __forceinline__ void tdfw_read_x(bf16x8 (&xf)[3], const bf16_t* base)
     xf[2] = tdfw_read_frag<OFF + 64>(base);
 }
 
+// timing-only ablation of the wide kernel (variant libraries built with -DALSEP_TDF_ABL=n, never the product; results are wrong):
+// bit 0 the weight fragments of the first K tile are reused for all tiles, bit 1 no residual loads, bit 2 no X tiles beyond the first two
+#ifndef ALSEP_TDF_ABL
+#define ALSEP_TDF_ABL 0
+#endif
 template <int WM, bool RESIDUAL, int RPF = 2>               // RPF: units of residual rows requested ahead of the stores
 __global__ void __launch_bounds__(64 * WM, 2)
 tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wf,
@@ -2434,7 +2439,7 @@ tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const
 #pragma unroll
         for (int ni = 0; ni < 3; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 3; ++mi) mma_step(acc[u][ni][mi], xf[ni], wf[par][ks][mi]);
+            for (int mi = 0; mi < 3; ++mi) mma_step(acc[u][ni][mi], xf[ni], wf[(ALSEP_TDF_ABL & 1) ? 0 : par][ks][mi]);
     };
     // tile it sits in stage S_ (= it % 3), its weights in wf[P_] (P_ = it % 2); all indices compile-time
 #define ALSEP_TDFW_STEP(it_, S_, P_)                                                              \
@@ -2442,8 +2447,8 @@ tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const
         wait_vmcnt<Tc::GLDS>();            /* all but X(it+1): W(it) and X(it) have landed */     \
         if ((it_) + 1 >= ntile) wait_vmcnt<0>();         /* last tile: nothing was issued behind */ \
         barrier_nodrain();                 /* every wave's part of X(it); compute(it-1) finished */ \
-        if ((it_) + 1 < ntile) issue_w((it_) + 1, 1 - (P_));                                      \
-        if ((it_) + 2 < ntile) issue_x((it_) + 2, ((S_) + 2) % 3);                                \
+        if ((it_) + 1 < ntile && !(ALSEP_TDF_ABL & 1)) issue_w((it_) + 1, 1 - (P_));              \
+        if ((it_) + 2 < ntile && !(ALSEP_TDF_ABL & 4)) issue_x((it_) + 2, ((S_) + 2) % 3);        \
         const bf16_t* xs_ = xlane + (size_t)(S_) * Tc::STAGE_ELEMS;                               \
         bf16x8 xa[3], xb[3];                                                                      \
         tdfw_read_x<0, 0>(xa, xs_);                                                               \
@@ -2512,14 +2517,14 @@ tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const
         for (int it = 0; it < 5; ++it)
             if (it * 64 + lane < Tc::TR * 6) rr[u][it] = *reinterpret_cast<const ALSEP_GLOBAL bf16x8*>(rb + loff[it]);
     };
-    if (RESIDUAL) {
+    if (RESIDUAL && !(ALSEP_TDF_ABL & 2)) {
 #pragma unroll
         for (int u = 0; u < PF && u < Tc::UN; ++u) load_res(u);
     }
 #pragma unroll
     for (int u = 0; u < Tc::UN; ++u) {
         const int cb = (int)((u0 + u) % upc) * Tc::UC;
-        if (RESIDUAL && u + PF < Tc::UN) load_res(u + PF);
+        if (RESIDUAL && u + PF < Tc::UN && !(ALSEP_TDF_ABL & 2)) load_res(u + PF);
         ALSEP_GLOBAL char* yb = const_cast<ALSEP_GLOBAL char*>(opaque_uniform_gptr(reinterpret_cast<const char*>(Y + unit_base(u))));
 #pragma unroll
         for (int ni = 0; ni < 3; ++ni) {
