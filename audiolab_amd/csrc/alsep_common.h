@@ -142,6 +142,20 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
 
+// A 16-byte store of a streamed activation (written once, read by a later kernel after gigabytes of other traffic).  ALSEP_NT_STORES=1
+// makes these stores non-temporal (no L2 allocation); which one the product uses is decided by a same-box A/B (profiles/r04_nt_stores_ab.txt).
+#ifndef ALSEP_NT_STORES
+#define ALSEP_NT_STORES 0
+#endif
+template <typename P, typename V>
+__device__ __forceinline__ void stream_store(P p, const V& v) {
+#if ALSEP_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // XCD-aware remap of a linear workgroup id: the dispatcher deals consecutive ids round-robin
 // over the 8 XCDs, so ids b and b+8 share an L2.  Give each XCD a contiguous run of tiles
 // (bijective for any n; cdna_hip_programming.md T1).  Speed only, never correctness.

@@ -465,11 +465,11 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
 #pragma unroll
                     for (int u = 0; u < U; ++u) x[u] = xs[bl + kFirstConvBinsPerRound * (i + u)];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) *reinterpret_cast<s16x8*>(dst + (int64_t)kRoundBytes * (i + u)) = one(x[u]);
+                    for (int u = 0; u < U; ++u) stream_store(reinterpret_cast<s16x8*>(dst + (int64_t)kRoundBytes * (i + u)), one(x[u]));
                 }
                 for (; i < rounds; ++i) {
                     const int bin = bl + kFirstConvBinsPerRound * i;
-                    if (bin < dim_f) *reinterpret_cast<s16x8*>(dst + (int64_t)kRoundBytes * i) = one(xs[bin]);
+                    if (bin < dim_f) stream_store(reinterpret_cast<s16x8*>(dst + (int64_t)kRoundBytes * i), one(xs[bin]));
                 }
             }
         } else {

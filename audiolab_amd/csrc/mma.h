@@ -56,7 +56,7 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     bf16x8 q;
 #pragma unroll
     for (int e = 0; e < 8; ++e) q[e] = (bf16_t)v[e];
-    *reinterpret_cast<bf16x8*>(p) = q;
+    stream_store(reinterpret_cast<bf16x8*>(p), q);
 }
 __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
     const float4 q = *reinterpret_cast<const float4*>(p);

@@ -2306,7 +2306,7 @@ tdf_bf16_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16
                 bf16x8 q;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) q[e] = (bf16_t)y[e];
-                *reinterpret_cast<bf16x8*>(Y + o) = q;
+                stream_store(reinterpret_cast<bf16x8*>(Y + o), q);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -2554,7 +2554,7 @@ tdf_bf16_wide_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const
                 bf16x8 q;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) q[e] = (bf16_t)y[e];
-                *reinterpret_cast<ALSEP_GLOBAL bf16x8*>(yb + loff[it]) = q;
+                stream_store(reinterpret_cast<ALSEP_GLOBAL bf16x8*>(yb + loff[it]), q);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -2812,7 +2812,7 @@ us_stream_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf1
             bf16x8 q;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { q[e] = (bf16_t)(lo[e] * (float)sk[e]); q[4 + e] = (bf16_t)(hi[e] * (float)sk[4 + e]); }
-            *reinterpret_cast<bf16x8*>(Y + o) = q;
+            stream_store(reinterpret_cast<bf16x8*>(Y + o), q);
         }
         __syncthreads();
     }

@@ -463,8 +463,10 @@ def main() -> None:
     ap.add_argument("--no-precision", action="store_true",
                     help="skip the `precision` / `accuracy` objects (full steps in the other storage types after the timed region; N = 1 only)")
     ap.add_argument("--cpu-windows", type=int, default=2)
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: N x --seconds of audio on N GPUs (per-GPU work fixed); strong: --seconds in total")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="strong (default): the --seconds track in total, its model windows sharded over the N GPUs -- what 'scaling to 8 GPUs' "
+                         "means for one track (52 windows: 6-7 per rank at N = 8); weak: N x --seconds of audio on N GPUs (per-GPU work fixed). "
+                         "At N > 1 the line carries the other mode too (`other_scaling`), measured after the timed region.")
     ap.add_argument("--model", default="vocals_mel_band_roformer.ckpt", help="roster name of the model workload")
     ap.add_argument("--workload", default="mdx4", choices=["mdx4", "demucs6", "tracks", "longform", "model"],
                     help="mdx4 (default): BASELINE configs[1], the graded line.  Supplementary lines for the other configs: demucs6 = "
@@ -558,6 +560,38 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     assert stems[0].shape == (1, 2, n_samples) and bool(torch.isfinite(stems[0]).all())
+    # the other scaling mode, after the timed region (N > 1 only; at N = 1 the two coincide): same models, the other track length
+    other_scaling = None
+    if world > 1:
+        o_mode = "weak" if args.scaling == "strong" else "strong"
+        o_samples = args.seconds * SR * (world if o_mode == "weak" else 1)
+        o_mix = torch.from_numpy(synth_mix(o_samples)).to(device)
+        from audiolab_amd.dist import window_range as _wr2
+        _gen2 = cfg.hop * (cfg.dim_t - 1) - cfg.n_fft
+        _lo2, _hi2 = _wr2(o_samples // _gen2 + 1, world, rank)
+        for net in nets:
+            net.max_batch = max(1, min(_hi2 - _lo2, 64))
+
+        def o_step():
+            pending = [p.demix(o_mix, defer=True) for p in preds]
+            return [f() for f in pending]
+        o_step()
+        fence()
+        o_steps = max(1, min(args.steps, 3))
+        t0 = time.perf_counter()
+        for _ in range(o_steps):
+            o_out = o_step()
+        fence()
+        o_dt = time.perf_counter() - t0
+        t = torch.tensor([o_dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        o_dt = float(t[0])
+        other_scaling = {"scaling": o_mode, "value": round(N_STEMS * (o_samples / SR) * o_steps / o_dt, 2), "ms_per_step": round(o_dt / o_steps * 1e3, 2),
+                         "steps": o_steps, "audio_seconds": o_samples / SR, "windows_per_rank": int(_hi2 - _lo2)}
+        del o_out, o_mix
+        for net in nets:
+            net.max_batch = args.batch
+        torch.cuda.empty_cache()
 
     # windows this rank pushed through the network per step (per model)
     gen = cfg.hop * (cfg.dim_t - 1) - cfg.n_fft
@@ -631,7 +665,8 @@ def main() -> None:
             gbs = alg * nb * reps / (ms * 1e-3) / 1e9
             # PMC HBM bytes per launch of the stage's kernel, scaled to this launch's chunk count (the committed pass ran
             # the same 52-chunk launches; traffic is linear in the chunk count)
-            tr = pmc_traffic("stft_r16_kernel" if name == "stft" else "istft_r16_kernel") if (not tag and plan.n_fft in (4096, 6144)) else None
+            r2 = plan.n_fft // 256                                             # the three-pass kernels are keyed by their radix (scripts/pmc_summary.py)
+            tr = pmc_traffic(f"stft_r16_kernel<{r2}>" if name == "stft" else f"istft_r16_kernel<{r2}>") if (not tag and plan.n_fft in (4096, 6144)) else None
             stages[name + tag] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                   "frac": round(gbs / PEAK_HBM_GBS, 4), "n_fft": plan.n_fft, "dim_f": plan.dim_f,
                                   "bytes_per_chunk": alg, "chunks_per_launch": nb,
@@ -661,7 +696,8 @@ def main() -> None:
             stages["stft_first_conv"] = {"kernel": "stft_r16_kernel<FUSE> (STFT + first 1x1 conv + BN + ReLU)", "bound": "hbm", "achieved": round(gbs, 1),
                                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "n_fft": plan0.n_fft,
                                          "bytes_per_chunk": alg, "chunks_per_launch": nb, "us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
-                                         "us_per_chunk": round(ms * 1e3 / max(launches, 1) / nb, 3), "traffic": None,
+                                         "us_per_chunk": round(ms * 1e3 / max(launches, 1) / nb, 3),
+                                         "traffic": pmc_traffic(f"stft_r16_kernel<{plan0.n_fft // 256}><fused>", nb),
                                          "algorithmic_bytes_per_launch": alg * nb,
                                          "note": "replaces stages.stft + first_conv_kernel in the timed step; bit-identical to them"}
         del buf
@@ -742,7 +778,7 @@ def main() -> None:
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"MDX-Net UVR 4-stem (4x TFC-TDF U-Net L=11 g=48 dim_f=3072 dim_t=256 n_fft=6144), "
-                                   f"{args.seconds} s 44.1 kHz stereo {'per GPU' if args.scaling == 'weak' else 'in total'}, margin chunker, "
+                                   f"{args.seconds} s 44.1 kHz stereo {'per GPU' if args.scaling == 'weak' and world > 1 else 'in total'}, margin chunker, "
                                    f"windows/launch={args.batch}",
                        "stems": N_STEMS, "audio_seconds": audio_seconds, "sharding": f"windows/{world} + all_gather"},
             "realtime_factor_4stem": round(audio_seconds * args.steps / dt, 2),
@@ -752,6 +788,7 @@ def main() -> None:
             "precision": precision,
             "accuracy": accuracy,
             "cpu_baseline": cpu,
+            "other_scaling": other_scaling,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -22,6 +22,12 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
                 short += f"<{tw.group(1)}>"
             if "Lb1" in name:
                 short += "<res>"
+            # demangled names (rocprofv3 prints the r16 kernels that way): "void r16::stft_r16_kernel<24, __bf16, 1, true>(...)" -- the
+            # fused STFT + first-layer kernel (last argument true) must not be averaged with the plain STFT under one name
+            dm = re.search(r"(i?stft_r\d+_kernel)<([^>]*)>", name)
+            if dm:
+                targs = [a.strip() for a in dm.group(2).split(",")]
+                short = f"{dm.group(1)}<{targs[0]}>" + ("<fused>" if targs[-1] == "true" and dm.group(1).startswith("stft") else "")
             key = f'{short} grid={int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)}'
             a = agg[key][r["Counter_Name"]]
             a[0] += 1

@@ -406,9 +406,9 @@ HALF_BOUNDS = {
 
 @pytest.mark.parametrize("storage", ["bf16", "f16"])
 def test_half_storage_error_per_depth(ctx, storage):
-    """bf16 / f16 storage at network depths 1 and 5 (bench widths; depth 11 is the full-size test above), one model window each, against
-    the storage oracle and the fp32 oracle, with a bound per depth (HALF_BOUNDS; the table of all depths 1 ... 11 was measured once:
-    profiles/r03_half_storage_per_depth.txt) instead of one cap."""
+    """bf16 / f16 storage at network depths 1, 3, 7 and 11 (bench widths), one model window each, against the storage oracle and the fp32
+    oracle, with a bound per depth (HALF_BOUNDS; depths 5 and 9 keep their rows there: profiles/r03_half_storage_per_depth.txt) instead of
+    one cap."""
     from audiolab_amd.mdx import Predictor
     from audiolab_amd.synth import synth_mix, synthetic_state_dict
     from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
@@ -420,7 +420,7 @@ def test_half_storage_error_per_depth(ctx, storage):
         d = (a - b).astype(np.float64)
         return float(np.sqrt((d ** 2).sum() / (b.astype(np.float64) ** 2).sum()))
     rows = []
-    for depth in (1, 5):                                       # depth 11 is test_full_size_mdx_bf16 / f16_vs_oracle above (the full table of depths 1 ... 11: profiles/r03_half_storage_per_depth.txt)
+    for depth in (1, 3, 7, 11):                                # (5 and 9 keep their rows in HALF_BOUNDS: profiles/r03_half_storage_per_depth.txt)
         cfg = TDFNetConfig(num_blocks=depth)
         sd = synthetic_state_dict(cfg, seed=depth)
         g = mdx_oracle.MDXGeometry(cfg.dim_f, cfg.dim_t, cfg.n_fft, cfg.hop)
