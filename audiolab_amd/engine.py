@@ -400,7 +400,7 @@ class Separator:
         net = Roformer(cfg, sd, ctx=self.ctx, precision="f16" if half_ok else "f32")
         labels = tuple(opts.get("labels", ("Vocals",)))[: cfg.num_stems]
         inst = _ModelInstance(model_filename, net, None, labels[0], opts.get("secondary") if cfg.num_stems == 1 else None)
-        inst.roformer = RoformerRunner(net, labels)
+        inst.roformer = RoformerRunner(net, labels, sharded=self.sharded)
         inst.output_dir = self.output_dir
         inst.weights = weights
         self._cache[model_filename] = inst
@@ -446,7 +446,7 @@ class Separator:
                            cfg.num_channels, cfg.growth)
         net = MDX23C(cfg, sd, ctx=self.ctx, precision="f16" if half_ok else "f32")
         inst = _ModelInstance(model_filename, net, None, labels[0], None)
-        inst.roformer = RoformerRunner(net, labels)             # the same chunked runner (training project's demix_track)
+        inst.roformer = RoformerRunner(net, labels, sharded=self.sharded)   # the same chunked runner (training project's demix_track)
         inst.output_dir = self.output_dir
         inst.weights = weights
         self._cache[model_filename] = inst

@@ -524,14 +524,17 @@ def view_on_stream(net, ctx: Context):
 class RoformerRunner:
     """chunked inference (``demix_track`` of the training project the checkpoints come from): mix [2, L] -> {label: [2, L]}"""
 
-    def __init__(self, net, labels: Tuple[str, ...], lanes: Optional[int] = None, graphs: Optional[bool] = None):
-        """``net``: a Roformer, or any network of the same training project with ``cfg.chunk_size / num_overlap / num_stems`` and
+    def __init__(self, net, labels: Tuple[str, ...], lanes: Optional[int] = None, graphs: Optional[bool] = None, sharded: bool = False,
+                 group=None):
+        """``sharded=True``: the chunks of a track are split into contiguous ranges over the ranks of ``group`` (torch.distributed; one
+        process per GPU); see ``demix``.  ``net``: a Roformer, or any network of the same training project with ``cfg.chunk_size / num_overlap / num_stems`` and
         ``forward([2, chunk]) -> [num_stems, 2, chunk]`` (MDX23C).  ``lanes``: chunks in flight at once, each on a HIP stream of its
         own (default ``ALSEP_RUNNER_LANES`` or 4 on a GPU, 1 elsewhere); per-lane weighted sums are added at the end.
         ``graphs`` (default ``ALSEP_RUNNER_GRAPH`` or on, GPU only): a chunk is ~100-600 small launches issued from Python, which the host
         cannot issue as fast as the GPU retires them; every lane therefore captures ONE chunk forward into a HIP graph (its launches go
         to the lane's stream, which is the capturing stream) and replays it per chunk: static input / output buffers, one graph launch."""
         self.net, self.ctx, self.labels = net, net.ctx, labels
+        self.sharded, self.group = bool(sharded), group
         if len(labels) != net.cfg.num_stems:
             raise AlsepError("one label per stem")
         import os
@@ -590,6 +593,10 @@ class RoformerRunner:
         return static_out
 
     def demix(self, mix: torch.Tensor) -> torch.Tensor:
+        """Sharded: rank r runs a contiguous range of the chunks and owns the output samples from its first chunk's start to
+        the next rank's.  Its chunks reach up to ``chunk - step`` samples beyond that span: those seam sums of all ranks travel in one
+        small all-gather and every rank adds the pieces that fall into its span; it then divides its span by the summed window weights,
+        and ONE all-gather of the finished stem segments gives every rank the track -- no full-length all-reduce."""
         ctx, net = self.ctx, self.net
         cfg = net.cfg
         lib, h = ctx.lib, ctx.handle
@@ -614,9 +621,20 @@ class RoformerRunner:
         wins = [w.to(ctx.device) for w in (w_start, w_mid, w_fin)]
         S = cfg.num_stems
         starts = list(range(0, total, step))
-        lanes = self._lanes()[: max(1, min(self.lanes, len(starts)))]
+        rank, world = 0, 1
+        if self.sharded:
+            import torch.distributed as tdist
+            rank, world = tdist.get_rank(self.group), tdist.get_world_size(self.group)
+        from . import dist as adist
+        c_lo, c_hi = adist.window_range(len(starts), world, rank)
+        mine = starts[c_lo:c_hi]
+        lanes = self._lanes()[: max(1, min(self.lanes, len(mine)))]
         results = [ctx.zeros((S * 2, total)) for _ in lanes]     # one weighted sum per lane
-        counter = torch.zeros(total)
+        counter = torch.zeros(total)                             # every rank needs the whole counter (host arithmetic, no model)
+        for i in starts:
+            length = min(Cn, total - i)
+            kind = 0 if i == 0 else (2 if i + step >= total else 1)
+            counter[i:i + length] += (w_start, w_mid, w_fin)[kind][:length]
         main = torch.cuda.current_stream(ctx.device) if (len(lanes) > 1 or self.graphs) else None
         for _, st in lanes:
             if st is not None:
@@ -640,9 +658,8 @@ class RoformerRunner:
             kind = 0 if i == 0 else (2 if i + step >= total else 1)
             lctx.check(lctx.lib.alsep_nn_vec_fma(lctx.handle, C.c_void_p(res.data_ptr() + 4 * i), _lib.ptr(y), _lib.ptr(wins[kind]), S * 2,
                                                  length, total, Cn), "alsep_nn_vec_fma")
-            counter[i:i + length] += (w_start, w_mid, w_fin)[kind][:length]
 
-        for n, i in enumerate(starts):
+        for n, i in enumerate(mine):
             k = n % len(lanes)
             lane_net, st = lanes[k]
             if st is None:
@@ -657,7 +674,42 @@ class RoformerRunner:
             if k > 0:
                 ctx.check(lib.alsep_axpby(h, 1.0, _lib.ptr(results[k]), 1.0, _lib.ptr(result), result.numel()), "alsep_axpby")
         cnt = counter.to(ctx.device)
-        ctx.check(lib.alsep_nn_vec_div(h, _lib.ptr(result), _lib.ptr(cnt), S * 2, total), "alsep_nn_vec_div")
+        if world > 1:
+            # own spans: from a rank's first chunk start to the next rank's (the last rank with chunks: to the end).  window_range deals
+            # the chunks so that ranks WITHOUT any (tracks of fewer chunks than ranks) are the last ones: they own the empty span at the end
+            bounds = [adist.window_range(len(starts), world, q) for q in range(world)]
+            m = sum(1 for b in bounds if b[1] > b[0])
+            ranges = []
+            for q in range(world):
+                if q >= m:
+                    ranges.append((total, total))
+                else:
+                    ranges.append((starts[bounds[q][0]], starts[bounds[q + 1][0]] if q + 1 < m else total))
+            own_lo, own_hi = ranges[rank]
+            # seam: what this rank's chunks wrote beyond its own span (at most `border` samples), for every rank in one all-gather
+            seam = max(border, 1)
+            tail = ctx.zeros((S * 2, seam))
+            t_lo = own_hi
+            t_hi = min(total, (mine[-1] + Cn) if mine else own_hi)
+            if t_hi > t_lo:
+                tail[:, : t_hi - t_lo] = result[:, t_lo:t_hi]
+            tails = adist.all_gather_fixed(tail, self.group)                       # [world, S * 2, seam]
+            for q in range(world):
+                if q == rank or bounds[q][1] <= bounds[q][0]:
+                    continue
+                q_lo = ranges[q][1]                                                # rank q's tail starts where its span ends
+                q_hi = min(total, starts[bounds[q][1] - 1] + Cn)
+                a, b = max(q_lo, own_lo), min(q_hi, own_hi)
+                if b > a:
+                    piece = tails[q][:, a - q_lo: b - q_lo].contiguous()
+                    dst = result[:, a:b]
+                    result[:, a:b] = dst + piece
+            seg = result[:, own_lo:own_hi].contiguous()
+            if own_hi > own_lo:
+                ctx.check(lib.alsep_nn_vec_div(h, _lib.ptr(seg), _lib.ptr(cnt[own_lo:own_hi].contiguous()), S * 2, own_hi - own_lo), "alsep_nn_vec_div")
+            result = adist.all_gather_ranges(seg, ranges, total, self.group)       # ONE all-gather of the finished stem segments
+        else:
+            ctx.check(lib.alsep_nn_vec_div(h, _lib.ptr(result), _lib.ptr(cnt), S * 2, total), "alsep_nn_vec_div")
         out = result.view(S, 2, total)
         return out[..., border:border + L0].contiguous() if padded else out
 

@@ -149,3 +149,64 @@ def test_sharded_ola_and_demucs_world2_gloo(emul_lib_path, tmp_path):
     errs = np.load(out_path)
     assert errs[0] < 1e-4, f"sharded Hann overlap-add: {errs[0]:.3e}"
     assert errs[1] < 1e-4, f"sharded Demucs runner: {errs[1]:.3e}"
+
+
+def _worker_world3(rank, world, port, emul_so, out_path):
+    """world-3 over gloo (an odd rank count: uneven ranges, a middle rank whose span has neighbours on both sides): the chunked Roformer /
+    MDX23C runner with its chunks sharded (span all-gather + seam all-gather), a track with fewer chunks than ranks (ranks without any),
+    and the Demucs runner -- each against the single-process oracle."""
+    import dataclasses
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from audiolab_amd import _lib
+    _lib._LIB = _lib.bind(emul_so)
+    _lib.DEVICE_TYPE = "cpu"
+    ctx = _lib.Context("cpu")
+    from audiolab_amd.htdemucs import DemucsRunner, HTDemucs, HTDemucsConfig
+    from audiolab_amd.roformer import Roformer, RoformerConfig, RoformerRunner
+    from audiolab_amd.synth import synthetic_state_dict
+    from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
+    from oracle import htdemucs_oracle as ho
+    from oracle import mdx_oracle as mo
+    from oracle import roformer_oracle as ro
+    from oracle import tdfnet_oracle
+    from oracle.toy import synth_mix
+    errs = []
+    # (1) Roformer runner: chunk 1200, overlap 4 -> step 300; 7 000 samples -> 30 chunks over 3 ranks; then 500 samples -> 2 chunks (rank 2 has none)
+    rcfg = ro.RoformerConfig(kind="bs", dim=32, depth=1, heads=2, dim_head=16, n_fft=256, hop=60, sample_rate=8000, chunk_size=1200, num_overlap=4,
+                             freqs_per_bands=(4,) * 16 + (8,) * 8 + (1,), mlp_expansion_factor=2)
+    rsd = ro.synthetic_state_dict(rcfg, 4)
+    rnet = Roformer(RoformerConfig(**dataclasses.asdict(rcfg)), rsd, ctx=ctx)
+    worst = 0.0
+    for n in (7000, 500):
+        rm = torch.from_numpy(synth_mix(n, seed=60 + n))
+        got = RoformerRunner(rnet, ("Vocals",), sharded=True).demix(rm).numpy()
+        want = ro.demix_track(rcfg, rsd, rm).numpy()
+        worst = max(worst, float(np.max(np.abs(got - want))))
+    errs.append(worst)
+    # (2) Demucs units over three ranks, two shift passes (the overlap-add runner's span logic is the same code as in the world-2 test)
+    ocfg = ho.HTDemucsConfig(sources=("drums", "bass"), channels=16, nfft=256, depth=2, dconv_comp=4, bottom_channels=32, t_layers=2,
+                             t_heads=4, segment_samples=2560, samplerate=4000)
+    hsd = ho.synthetic_state_dict(ocfg, 5)
+    hnet = HTDemucs(HTDemucsConfig(**dataclasses.asdict(ocfg)), hsd, ctx=ctx)
+    hm = torch.randn(2, 6000, generator=torch.Generator().manual_seed(9)) * 0.2
+    out = DemucsRunner(hnet, shifts=2, overlap=0.25, seed=1, sharded=True).separate(hm)
+    hw = ho.separate(ocfg, hsd, hm, shifts=2, overlap=0.25, seed=1).numpy()
+    errs.append(float(max(np.max(np.abs(out[k].numpy() - hw[i])) for i, k in enumerate(ocfg.sources))))
+    res = torch.tensor(errs)
+    dist.all_reduce(res, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        np.save(out_path, res.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_runners_world3_gloo(emul_lib_path, tmp_path):
+    out_path = str(tmp_path / "err3.npy")
+    mp.spawn(_worker_world3, args=(3, _free_port(), emul_lib_path, out_path), nprocs=3, join=True)
+    errs = np.load(out_path)
+    assert errs[0] < 1e-4, f"sharded Roformer runner: {errs[0]:.3e}"
+    assert errs[1] < 1e-4, f"sharded Demucs runner (world 3): {errs[1]:.3e}"
