@@ -578,196 +578,9 @@ conv3x3_bf16_regw_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, c
 #undef ALSEP_RW_STAGE
 }
 
-#ifdef ALSEP_EXPERIMENTS   // superseded by the big-tile / mq kernels; kept for A/B runs (-DALSEP_EXPERIMENTS), not in the product build
-// ------------------------------------------------------------------------------------------
-// bf16 3x3 convolution, deeper levels (Cout = 48*NY, NY = 2..6): persistent + software-pipelined.
-// One workgroup per CU walks tiles; for each tile and input chunk q the halo patch is staged ONCE
-// and all NY 48-channel weight blocks are streamed against it (accumulators for all NY blocks live
-// in registers), instead of re-staging the patch per output block.  Patch and weight blocks each
-// have a 2-slot LDS ring (2*38,016 + 2*43,008 B = 158.3 KiB); the LDS-DMA of the next weight block
-// -- and, on the first block of a patch, of the next patch -- is in flight while the MFMAs of the
-// current one run (counted s_waitcnt vmcnt + raw s_barrier), and a tile's stores drain under the next
-// tile's first stage.
-// Stage s of a workgroup: ny = s % NY, q = (s / NY) % nq, tile = s / (NY*nq).
-// ------------------------------------------------------------------------------------------
-template <int NY>
-struct ConvPipe {
-    static constexpr int TW = 64, TH = 4, KC = 48, BN = 48, CG = 6, NG = 54, NS = 14, WGRP = 56;
-    static constexpr int PW = TW + 2, PH = TH + 2;
-    static constexpr int PGROUPS = PH * PW * CG;            // 2376
-    static constexpr int WGROUPS = BN * WGRP;               // 2688
-    static constexpr int PINST = (PGROUPS + 63) / 64;       // 38 LDS-DMA instructions per patch (last one partial)
-    static constexpr int WINST = WGROUPS / 64;              // 42 per weight block
-    static constexpr int ST = NY * 12;                      // stores per wave per tile
-    static constexpr size_t ring_bytes = 16 * (size_t)(2 * PGROUPS + 2 * WGROUPS);     // 162,048
-    static constexpr size_t lds_bytes = ring_bytes + 2 * NY * BN * sizeof(float);      // + scale/shift (NY <= 4 fits 160 KiB)
-    static_assert(lds_bytes <= 160 * 1024, "ConvPipe: LDS budget");
-};
-
-template <int N> __device__ __forceinline__ void wait_vmcnt_capped() { wait_vmcnt<(N > 63 ? 63 : N)>(); }
-
-template <int NY>
-__global__ void __launch_bounds__(kThreads, 1)
-conv3x3_bf16_pipe_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
-                         const float* __restrict__ scale, const float* __restrict__ shift,
-                         const bf16_t* __restrict__ zero_page, int Th, int Fw, int Cin, int Cout, int tiles_t,
-                         int tiles_f, int ntiles) {
-    typedef ConvPipe<NY> Cf;
-    bf16_t* pring = reinterpret_cast<bf16_t*>(alsep_smem);
-    bf16_t* wring = pring + (size_t)2 * Cf::PGROUPS * 8;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, lq = lane >> 4;
-    const int nq = Cin / Cf::KC;
-    const int wswz = l15 >> 1;
-
-    int pbase[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) pbase[ni] = (wave * Cf::PW + ni * 16 + l15) * Cf::KC;
-    auto koff_of = [&](int s) {
-        const int grp = 4 * s + lq;
-        const int gc = grp < Cf::NG ? grp : Cf::NG - 1;
-        const int tap = gc / Cf::CG, cg = gc % Cf::CG;
-        return ((tap / 3) * Cf::PW + (tap % 3)) * Cf::KC + cg * 8;
-    };
-
-    // scale/shift of all output channels sit in LDS: an ordinary global load inside the stage loop
-    // would make hipcc drain vmcnt(0) (and with it the ring) at its first use
-    float* ss = reinterpret_cast<float*>(alsep_smem + Cf::ring_bytes);
-    for (int i = tid; i < NY * Cf::BN; i += kThreads) {
-        ss[i] = scale[i];
-        ss[NY * Cf::BN + i] = shift[i];
-    }
-    __syncthreads();
-
-    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int spt = NY * nq;                                 // stages per tile
-    const int nstage = my_tiles * spt;
-    const int npatch = my_tiles * nq;
-
-    auto tile_coords = [&](int k, int& t0, int& f0, int64_t& b) {
-        int tile = (int)blockIdx.x + k * (int)gridDim.x;
-        const int tf = tile % tiles_f;  tile /= tiles_f;
-        const int tt = tile % tiles_t;
-        b = tile / tiles_t;
-        t0 = tt * Cf::TH;
-        f0 = tf * Cf::TW;
-    };
-    // patch-stage ps = (tile k = ps / nq, chunk q = ps % nq) -> slot ps & 1.  Waves 0,1 issue 10, waves 2,3 issue 9.
-    auto issue_patch = [&](int ps) {
-        int t0, f0; int64_t b;
-        tile_coords(ps / nq, t0, f0, b);
-        const bf16_t* xb = X + b * (int64_t)Th * Fw * Cin + (ps % nq) * Cf::KC;
-        bf16_t* dst = pring + (size_t)(ps & 1) * Cf::PGROUPS * 8;
-#pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            const int i = wave + 4 * j;
-            if (i < Cf::PINST) {                             // wave-uniform: i = 38, 39 do not exist
-                const int gidx = i * 64 + lane;
-                if (gidx < Cf::PGROUPS) {
-                    const int pix = gidx / Cf::CG, g = gidx % Cf::CG;
-                    const int t = t0 - 1 + pix / Cf::PW, f = f0 - 1 + pix % Cf::PW;
-                    const bool inb = t >= 0 && t < Th && f >= 0 && f < Fw;
-                    const bf16_t* src = inb ? xb + ((int64_t)t * Fw + f) * Cin + g * 8 : zero_page;
-                    glds16(src, dst + (size_t)i * 64 * 8);
-                }
-            }
-        }
-    };
-    // weight block of stage s -> slot s & 1.  Waves 0,1 issue 11, waves 2,3 issue 10.
-    auto issue_weights = [&](int s) {
-        const int ny = s % NY, q = (s / NY) % nq;
-        const bf16_t* wsrc = Wp + ((int64_t)ny * nq + q) * (Cf::WGROUPS * 8);
-        bf16_t* dst = wring + (size_t)(s & 1) * Cf::WGROUPS * 8;
-#pragma unroll
-        for (int j = 0; j < 11; ++j) {
-            const int i = wave + 4 * j;
-            if (i < Cf::WINST) glds16(wsrc + ((size_t)i * 64 + lane) * 8, dst + (size_t)i * 64 * 8);
-        }
-    };
-
-    f32x4 acc[NY][3][4];
-
-    // What is younger than stage s's weight block when we wait for it (in issue order):
-    //   [patch ps+1, issued at stage s-1 when ny(s-1) == 0]  [stores of the tile that ended at s-1]
-    //   [weights s+1]  [patch ps+1, issued now when ny(s) == 0]
-    // HI = waves 0,1 (11 weight / 10 patch instructions), else 10 / 9.
-#define ALSEP_PIPE_WAIT(HI_)                                                                        \
-    do {                                                                                            \
-        constexpr int GW = (HI_) ? 11 : 10, GP = (HI_) ? 10 : 9;                                    \
-        if (last) wait_vmcnt<0>();                                                                  \
-        else if (ny == 0 && newtile && havep) wait_vmcnt_capped<Cf::ST + GW + GP>();                \
-        else if (ny == 0 && newtile) wait_vmcnt_capped<Cf::ST + GW>();                              \
-        else if (ny == 0 && havep) wait_vmcnt_capped<GW + GP>();                                    \
-        else if (ny == 0) wait_vmcnt_capped<GW>();                                                  \
-        else if (ny == 1 && hadp) wait_vmcnt_capped<GP + GW>();                                     \
-        else wait_vmcnt_capped<GW>();                                                               \
-    } while (0)
-
-    if (nstage > 0) { issue_patch(0); issue_weights(0); }
-    for (int s = 0; s < nstage; ++s) {
-        const int ny = s % NY, ps = s / NY, q = ps % nq;
-        const bool last = s + 1 >= nstage;
-        const bool havep = ny == 0 && ps + 1 < npatch;      // this stage prefetches the next patch
-        const bool hadp = ny == 1 && ps + 1 < npatch;       // the previous stage did
-        const bool newtile = ny == 0 && q == 0 && s > 0;    // the previous stage ended a tile (stores were issued)
-        if (!last) issue_weights(s + 1);
-        if (havep) issue_patch(ps + 1);
-        if (wave < 2) ALSEP_PIPE_WAIT(true); else ALSEP_PIPE_WAIT(false);
-        barrier_nodrain();
-        {
-            const bf16_t* patch = pring + (size_t)(ps & 1) * Cf::PGROUPS * 8;
-            const bf16_t* wts = wring + (size_t)(s & 1) * Cf::WGROUPS * 8;
-            // ny is a run-time value but acc must be indexed statically: dispatch over NY
-#pragma unroll
-            for (int yy = 0; yy < NY; ++yy) {
-                if (yy == ny) {
-                    if (q == 0) {
-#pragma unroll
-                        for (int mi = 0; mi < 3; ++mi)
-#pragma unroll
-                            for (int ni = 0; ni < 4; ++ni) acc[yy][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-#pragma unroll 2
-                    for (int st = 0; st < Cf::NS; ++st) {
-                        const int ko = koff_of(st);
-                        bf16x8 xf[4], wf[3];
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni) xf[ni] = lds_frag<bf16_t>(patch + pbase[ni] + ko);
-#pragma unroll
-                        for (int mi = 0; mi < 3; ++mi) wf[mi] = lds_frag<bf16_t>(wts + ((mi * 16 + l15) * Cf::WGRP + ((4 * st + lq) ^ wswz)) * 8);
-#pragma unroll
-                        for (int mi = 0; mi < 3; ++mi)
-#pragma unroll
-                            for (int ni = 0; ni < 4; ++ni) mma_step(acc[yy][mi][ni], wf[mi], xf[ni]);
-                    }
-                }
-            }
-        }
-        barrier_nodrain();                                   // both slots read by this stage may be refilled
-        if (ny == NY - 1 && q == nq - 1) {                   // tile finished: NY*12 stores per wave
-            int t0, f0; int64_t b;
-            tile_coords(ps / nq, t0, f0, b);
-            bf16_t* yb = Y + ((b * Th + t0 + wave) * (int64_t)Fw + f0) * Cout;
-#pragma unroll
-            for (int yy = 0; yy < NY; ++yy)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < 3; ++mi) {
-                        const int co = yy * Cf::BN + mi * 16 + 4 * lq;
-                        const f32x4 scv = *reinterpret_cast<const f32x4*>(ss + co);      // ext-vector load: see regw kernel
-                        const f32x4 shv = *reinterpret_cast<const f32x4*>(ss + NY * Cf::BN + co);
-                        float y[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[yy][mi][ni][r], scv[r], shv[r]), 0.f);
-                        store4(yb + (int64_t)(ni * 16 + l15) * Cout + co, y);
-                    }
-        }
-    }
-#undef ALSEP_PIPE_WAIT
-}
-
-#endif  // ALSEP_EXPERIMENTS (pipe kernel)
+#ifdef ALSEP_EXPERIMENTS   // conv3x3_bf16_pipe_kernel: superseded, kept for A/B runs and the emulation's bit-identity cross-checks
+#include "tdfnet_exp_pipe.inc"
+#endif
 // ------------------------------------------------------------------------------------------
 // bf16 3x3 convolution, levels >= 1 (Cout = 48*NY, NY = 2..4): big-tile persistent kernel.
 // The ablations (profiles/r01_conv_ablation_*) show the plain kernel bounded by what goes through
@@ -1097,340 +910,9 @@ conv3x3_bf16_big_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, co
     }
 }
 
-#ifdef ALSEP_EXPERIMENTS   // superseded by conv3x3_bf16_mq_kernel (c = 96); equal to the big-tile kernel at c = 144
-// ------------------------------------------------------------------------------------------
-// bf16 3x3 convolution, levels 1 and 2, "merged" form of the big-tile kernel (round 2).
-// In-kernel stamps of conv3x3_bf16_big_kernel (profiles/r02_big_conv_stamps.txt) showed (a) its software-pipelined k-loop already
-// at the MFMA issue floor in cycles, (b) the chip answering with a lower clock (1.4-1.5 GHz): the launch is energy-bound.  What
-// is left is energy per MFMA: LDS bytes and VALU instructions.  Same tile, same patch, same two 43 KiB weight slots, but the K
-// range of a (tile, input chunk) is cut into NY parts instead of the output channels into NY blocks:
-//   a weight slot holds ALL 48 NY output rows x (14 / NY) k-steps, so one k-step reads its 4 patch fragments once for all
-//   3 NY row blocks: 4 + 3 NY LDS reads per 12 NY MFMAs (NY = 2: 10 per 24 instead of 14; NY = 3: 13 per 36 instead of 21);
-//   every LDS address is a per-lane base + an instruction immediate (no VALU in the loop), reads of k-step s + 1 are in flight
-//   during the MFMAs of s (asm reads, own lgkmcnt waits), the next weight slot arrives one LDS-DMA per k-step.
-// Per accumulator the MFMAs run in the same order as in the other conv kernels: bit-identical outputs.
-// ------------------------------------------------------------------------------------------
-template <int NY>
-struct ConvMny {
-    typedef ConvBig<NY> Big;
-    static constexpr int TW = 64, TH = 8, KC = 48, CG = 6, NG = 54, NS = 14, PW = TW + 2, PH = TH + 2;
-    static constexpr int PARTS = NY;                        // k-step ranges per (tile, chunk)
-    static constexpr int KS = (NS + PARTS - 1) / PARTS;     // k-steps of a part (the last one: the remainder): 7 / 5
-    static constexpr int WG = 4 * KS;                       // 16-byte groups per weight row in a slot
-    static constexpr int ROWS = 48 * NY, NB = 3 * NY;
-    static constexpr int PGROUPS = PH * PW * CG, PINST = (PGROUPS + 63) / 64;
-    static constexpr int WGROUPS = ROWS * WG, WINST = (WGROUPS + 63) / 64;      // 2688 -> 42; 2880 -> 45
-    static constexpr int WJ = (WINST + 7) / 8;              // weight pieces per wave (6)
-    static constexpr size_t ring_bytes = 16 * (size_t)(PGROUPS + 2 * WGROUPS);
-    static constexpr size_t lds_bytes = ring_bytes + 2 * ROWS * sizeof(float) + 1024;   // + 1 KiB scratch (surplus DMA pieces)
-    static_assert(lds_bytes <= 160 * 1024, "ConvMny: LDS budget");
-    __host__ __device__ static constexpr int ksteps_of_part(int kt) { return kt < PARTS - 1 ? KS : NS - KS * (PARTS - 1); }
-    // position of k-group lq of a k-step inside its 4-group block, by weight row: makes the ds_read_b128 of 16 rows x {lq, lq ^ 1}
-    // (the instruction's lane groups mix two lq values) conflict-free for row strides of 28 and 20 groups (simulated:
-    // scripts/lds_bank_sim.py)
-    __host__ __device__ static constexpr int wswz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
-};
-
-template <typename Cf, int KT, int STL>
-__device__ __forceinline__ void mny_issue_reads(bf16x8 (&xf)[4], bf16x8 (&wf)[Cf::NB], const bf16_t* patch, const int (&pk)[Cf::NS],
-                                                const bf16_t* wl) {
-    const bf16_t* pl = patch + pk[KT * Cf::KS + STL];
-    lds_read_async_b128<0 * 16 * Cf::KC * 2>(xf[0], pl);
-    lds_read_async_b128<1 * 16 * Cf::KC * 2>(xf[1], pl);
-    lds_read_async_b128<2 * 16 * Cf::KC * 2>(xf[2], pl);
-    lds_read_async_b128<3 * 16 * Cf::KC * 2>(xf[3], pl);
-    lds_read_async_b128<(0 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[0], wl);
-    lds_read_async_b128<(1 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[1], wl);
-    lds_read_async_b128<(2 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[2], wl);
-    lds_read_async_b128<(3 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[3], wl);
-    lds_read_async_b128<(4 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[4], wl);
-    lds_read_async_b128<(5 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[5], wl);
-    if constexpr (Cf::NB > 6) {
-        lds_read_async_b128<(6 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[6], wl);
-        lds_read_async_b128<(7 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[7], wl);
-        lds_read_async_b128<(8 * 16 * Cf::WG * 8 + STL * 32) * 2>(wf[8], wl);
-    }
-}
-template <typename Cf>
-__device__ __forceinline__ void mny_mma(f32x4 (&acc)[Cf::NB][4], const bf16x8 (&wf)[Cf::NB], const bf16x8 (&xf)[4]) {
-#pragma unroll
-    for (int b = 0; b < Cf::NB; ++b)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) mma_step(acc[b][ni], wf[b], xf[ni]);
-}
-template <typename Cf, int KT, int STL>
-__device__ __forceinline__ void mny_issue_x(bf16x8 (&xf)[4], const bf16_t* patch, const int (&pk)[Cf::NS]) {
-    const bf16_t* pl = patch + pk[KT * Cf::KS + STL];
-    lds_read_async_b128<0 * 16 * Cf::KC * 2>(xf[0], pl);
-    lds_read_async_b128<1 * 16 * Cf::KC * 2>(xf[1], pl);
-    lds_read_async_b128<2 * 16 * Cf::KC * 2>(xf[2], pl);
-    lds_read_async_b128<3 * 16 * Cf::KC * 2>(xf[3], pl);
-}
-template <typename Cf, int STL, int B>
-__device__ __forceinline__ void mny_issue_w1(bf16x8& wf, const bf16_t* wl) {
-    lds_read_async_b128<(B * 16 * Cf::WG * 8 + STL * 32) * 2>(wf, wl);
-}
-// k-steps STL, STL + 1 of part KT: fragments of STL in (xa, wa) (requested by the caller / the previous pair), STL + 1 goes to (xb, wb)
-template <typename Cf, int KT, int STL, typename Dma>
-__device__ __forceinline__ void mny_steps(f32x4 (&acc)[Cf::NB][4], bf16x8 (&xa)[4], bf16x8 (&wa)[Cf::NB], bf16x8 (&xb)[4],
-                                          bf16x8 (&wb)[Cf::NB], const bf16_t* patch, const int (&pk)[Cf::NS], const bf16_t* wl, Dma dma) {
-    constexpr int N = Cf::ksteps_of_part(KT);
-    if constexpr (STL < N) {
-        if constexpr (STL == 0) mny_issue_reads<Cf, KT, 0>(xa, wa, patch, pk, wl);
-        lds_wait_n<0>();                                     // the fragments of STL have landed
-        if constexpr (STL + 1 < N) mny_issue_reads<Cf, KT, STL + 1>(xb, wb, patch, pk, wl);
-        mny_mma<Cf>(acc, wa, xa);
-        dma(STL);
-        sched_fence();
-        if constexpr (STL + 1 < N) {
-            lds_wait_n<0>();
-            if constexpr (STL + 2 < N) mny_issue_reads<Cf, KT, STL + 2>(xa, wa, patch, pk, wl);
-            mny_mma<Cf>(acc, wb, xb);
-            dma(STL + 1);
-            sched_fence();
-            mny_steps<Cf, KT, STL + 2>(acc, xa, wa, xb, wb, patch, pk, wl, dma);
-        }
-    }
-}
-// the same with ONE set of weight fragments (NY = 3: two sets of 9 beside 144 accumulator registers do not fit 256 VGPRs): the patch
-// fragments of step STL + 1 are requested before the MFMAs of STL, each weight fragment of STL + 1 right after the four MFMAs that
-// consumed its register (the LDS answers long after those have read their operands)
-template <typename Cf, int KT, int STL, int B>
-__device__ __forceinline__ void mny_blocks(f32x4 (&acc)[Cf::NB][4], bf16x8 (&wf)[Cf::NB], const bf16x8 (&xf)[4], const bf16_t* wl) {
-    if constexpr (B < Cf::NB) {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) mma_step(acc[B][ni], wf[B], xf[ni]);
-        if constexpr (STL + 1 < Cf::ksteps_of_part(KT)) {
-            sched_fence();
-            mny_issue_w1<Cf, STL + 1, B>(wf[B], wl);
-        }
-        mny_blocks<Cf, KT, STL, B + 1>(acc, wf, xf, wl);
-    }
-}
-template <typename Cf, int KT, int STL, typename Dma>
-__device__ __forceinline__ void mny_steps1w(f32x4 (&acc)[Cf::NB][4], bf16x8 (&xa)[4], bf16x8 (&xb)[4], bf16x8 (&wf)[Cf::NB],
-                                            const bf16_t* patch, const int (&pk)[Cf::NS], const bf16_t* wl, Dma dma) {
-    constexpr int N = Cf::ksteps_of_part(KT);
-    if constexpr (STL < N) {
-        if constexpr (STL == 0) mny_issue_reads<Cf, KT, 0>(xa, wf, patch, pk, wl);
-        lds_wait_n<0>();
-        if constexpr (STL + 1 < N) mny_issue_x<Cf, KT, STL + 1>(xb, patch, pk);
-        mny_blocks<Cf, KT, STL, 0>(acc, wf, xa, wl);
-        dma(STL);
-        sched_fence();
-        mny_steps1w<Cf, KT, STL + 1>(acc, xb, xa, wf, patch, pk, wl, dma);
-    }
-}
-
-// ABL (timing experiments with STAMP, wrong results): 1 no weight LDS-DMA after the first slot, 2 no patch LDS-DMA after the first,
-// 4 epilogue stores predicated off (on a value test, so that the arithmetic stays)
-template <int NY, bool STAMP = false, int ABL = 0>
-__global__ void __launch_bounds__(kBigThreads, 2)
-conv3x3_bf16_mny_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, const bf16_t* __restrict__ Wp,
-                        const float* __restrict__ scale, const float* __restrict__ shift, const bf16_t* __restrict__ zero_page, int Th,
-                        int Fw, int Cin, int Cout, int tiles_t, int tiles_f, int ntiles, unsigned long long* __restrict__ stamps = nullptr) {
-    typedef ConvMny<NY> Cf;
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tk0 = 0, tr0 = 0, tlast = 0;
-    auto stamp = [&](int k) {
-        if constexpr (STAMP) {
-            const unsigned long long now = clock_cycles();
-            tacc[k] += now - tlast;
-            tlast = now;
-        }
-    };
-    if constexpr (STAMP) {
-        tk0 = tlast = clock_cycles();
-        tr0 = clock_100mhz();
-    }
-    bf16_t* patch = reinterpret_cast<bf16_t*>(alsep_smem);
-    bf16_t* wring = patch + (size_t)Cf::PGROUPS * 8;
-    float* ss = reinterpret_cast<float*>(alsep_smem + Cf::ring_bytes);
-    bf16_t* const scratch = reinterpret_cast<bf16_t*>(alsep_smem + Cf::lds_bytes - 1024);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, lq = lane >> 4;
-    const int nq = Cin / Cf::KC;
-    for (int i = tid; i < Cf::ROWS; i += kBigThreads) {
-        ss[i] = scale[i];
-        ss[Cf::ROWS + i] = shift[i];
-    }
-    __syncthreads();
-
-    // per-lane LDS element offsets, computed once: patch pixel (row = wave, col = l15) + k-group 4 st + lq of every k-step;
-    // weight row l15 + this lane's swizzled group position
-    int pk[Cf::NS];
-#pragma unroll
-    for (int st = 0; st < Cf::NS; ++st) {
-        const int grp = 4 * st + lq;
-        const int gc = grp < Cf::NG ? grp : Cf::NG - 1;
-        const int tap = gc / Cf::CG, cg = gc % Cf::CG;
-        pk[st] = (wave * Cf::PW + l15) * Cf::KC + ((tap / 3) * Cf::PW + (tap % 3)) * Cf::KC + cg * 8;
-    }
-    const int wl_off = (l15 * Cf::WG + (lq ^ Cf::wswz(l15))) * 8;
-
-    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int nstage = my_tiles * nq * Cf::PARTS;
-    auto tile_coords = [&](int k, int& t0, int& f0, int64_t& b) {
-        int tile = (int)blockIdx.x + k * (int)gridDim.x;
-        const int tf = tile % tiles_f;  tile /= tiles_f;
-        const int tt = tile % tiles_t;
-        b = tile / tiles_t;
-        t0 = tt * Cf::TH;
-        f0 = tf * Cf::TW;
-    };
-    // LDS-DMA descriptors of the halo patch (see conv3x3_bf16_big_kernel)
-    constexpr int PJ = (Cf::PINST + 7) / 8;
-    int prel[PJ];
-    unsigned pflags = 0;
-    bool plast_ok = true;
-#pragma unroll
-    for (int j = 0; j < PJ; ++j) {
-        const int gidx = (wave + 8 * j) * 64 + lane;
-        const int gi = gidx < Cf::PGROUPS ? gidx : Cf::PGROUPS - 1;
-        const int pix = gi / Cf::CG, g = gi % Cf::CG;
-        const int dt = pix / Cf::PW - 1, df = pix % Cf::PW - 1;
-        prel[j] = (dt * Fw + df) * Cin + g * 8;
-        pflags |= (unsigned)((dt < 0) | ((dt >= Cf::TH) << 1) | ((df < 0) << 2) | ((df >= Cf::TW) << 3)) << (4 * j);
-        if (j == PJ - 1) plast_ok = gidx < Cf::PGROUPS;
-    }
-    auto issue_patch = [&](int ps) {
-        int t0, f0; int64_t b;
-        tile_coords(ps / nq, t0, f0, b);
-        const bf16_t* xb = X + ((b * Th + t0) * (int64_t)Fw + f0) * Cin + (ps % nq) * Cf::KC;
-        const unsigned border = (unsigned)(t0 == 0) | ((unsigned)(t0 + Cf::TH >= Th) << 1) | ((unsigned)(f0 == 0) << 2) |
-                                ((unsigned)(f0 + Cf::TW >= Fw) << 3);
-#pragma unroll
-        for (int j = 0; j < PJ; ++j) {
-            const int i = wave + 8 * j;
-            if (j < PJ - 1 || i < Cf::PINST) {
-                const bool out = (pflags & (border << (4 * j))) != 0;
-                const bf16_t* src = out ? zero_page : xb + prel[j];
-                if (j < PJ - 1 || plast_ok) glds16(src, patch + (size_t)i * 64 * 8);
-            }
-        }
-    };
-    // weight slot of stage s: part (q, kt) of the image [q][kt][ROWS][WG][8]; WJ LDS-DMA pieces per wave, branch-free (a wave
-    // without a last piece copies piece 0 into the scratch: see conv3x3_bf16_big_kernel)
-    const bf16_t* wsrc_next = Wp;
-    bf16_t* wdst_next = wring;
-    auto weights_prep = [&](int s) {
-        const int kt = s % Cf::PARTS, q = (s / Cf::PARTS) % nq;
-        wsrc_next = Wp + ((int64_t)q * Cf::PARTS + kt) * (Cf::WGROUPS * 8);
-        wdst_next = wring + (size_t)(s & 1) * Cf::WGROUPS * 8;
-    };
-    auto weights_one = [&](int j) {
-        const int i = wave + 8 * j;
-        const bool real = i < Cf::WINST;
-        glds16(wsrc_next + ((size_t)(real ? i : 0) * 64 + lane) * 8, real ? wdst_next + (size_t)i * 64 * 8 : scratch);
-    };
-    auto dma_of_step = [&](int st, int n) {                 // the WJ pieces spread over the n k-steps of a part
-        if constexpr ((ABL & 1) != 0) return;
-        if (n >= Cf::WJ) {
-            if (st < Cf::WJ) weights_one(st);
-        } else {                                             // fewer k-steps than pieces (NY = 3, last part): two pieces per step
-            if (2 * st < Cf::WJ) weights_one(2 * st);
-            if (2 * st + 1 < Cf::WJ) weights_one(2 * st + 1);
-        }
-    };
-
-    constexpr int ST = 4 * (Cf::Big::NPAIR + Cf::NB % 2);    // epilogue stores per wave
-    f32x4 acc[Cf::NB][4];
-    if (nstage > 0) {
-        issue_patch(0);
-        weights_prep(0);
-#pragma unroll
-        for (int j = 0; j < Cf::WJ; ++j) weights_one(j);
-    }
-    for (int s = 0; s < nstage; ++s) {
-        const int kt = s % Cf::PARTS, ps = s / Cf::PARTS, q = ps % nq;
-        const bool after_epilogue = kt == 0 && q == 0 && s > 0;
-        if (after_epilogue) wait_vmcnt<ST>();
-        else wait_vmcnt<0>();
-        stamp(0);
-        barrier_nodrain();
-        stamp(1);
-        weights_prep(s + 1);                                 // (the DMA of the last stage refills the free slot once more: branch-free loop)
-        if (q == 0 && kt == 0) {
-#pragma unroll
-            for (int b = 0; b < Cf::NB; ++b)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[b][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        {
-            const bf16_t* wl = wring + (size_t)(s & 1) * Cf::WGROUPS * 8 + wl_off;
-            if constexpr (Cf::NB <= 6) {
-                bf16x8 xa[4], wa[Cf::NB], xb[4], wb[Cf::NB];
-#pragma unroll
-                for (int k = 0; k < Cf::PARTS; ++k) {
-                    if (k == kt) {
-                        if (k == 0) mny_steps<Cf, 0, 0>(acc, xa, wa, xb, wb, patch, pk, wl, [&](int st) { dma_of_step(st, Cf::ksteps_of_part(0)); });
-                        if (k == 1) mny_steps<Cf, 1, 0>(acc, xa, wa, xb, wb, patch, pk, wl, [&](int st) { dma_of_step(st, Cf::ksteps_of_part(1)); });
-                    }
-                }
-            } else {
-                bf16x8 xa[4], xb[4], wf[Cf::NB];
-#pragma unroll
-                for (int k = 0; k < Cf::PARTS; ++k) {
-                    if (k == kt) {
-                        if (k == 0) mny_steps1w<Cf, 0, 0>(acc, xa, xb, wf, patch, pk, wl, [&](int st) { dma_of_step(st, Cf::ksteps_of_part(0)); });
-                        if (k == 1) mny_steps1w<Cf, 1, 0>(acc, xa, xb, wf, patch, pk, wl, [&](int st) { dma_of_step(st, Cf::ksteps_of_part(1)); });
-                        if (k == 2) mny_steps1w<Cf, 2, 0>(acc, xa, xb, wf, patch, pk, wl, [&](int st) { dma_of_step(st, Cf::ksteps_of_part(2)); });
-                    }
-                }
-            }
-        }
-        stamp(2);
-        if (kt == Cf::PARTS - 1) {
-            barrier_nodrain();                               // every wave has left the patch: it may be refilled
-            stamp(3);
-            if (s + 1 < nstage && !(ABL & 2)) issue_patch(ps + 1);
-            stamp(4);
-            if (q == nq - 1) {
-                int t0, f0; int64_t b;
-                tile_coords(ps / nq, t0, f0, b);
-                bf16_t* yb = Y + ((b * Th + t0 + wave) * (int64_t)Fw + f0) * Cout;
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    bf16_t* yp = yb + (int64_t)(ni * 16 + l15) * Cout;
-#pragma unroll
-                    for (int j = 0; j < Cf::Big::NPAIR; ++j) {       // blocks 2 j, 2 j + 1: channels 32 j + 8 lq + [0, 8) (ConvBig::channel_of_row)
-                        const int co = j * 32 + lq * 8;
-                        float y[8];
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const f32x4 scv = *reinterpret_cast<const f32x4*>(ss + co + 4 * h);
-                            const f32x4 shv = *reinterpret_cast<const f32x4*>(ss + Cf::ROWS + co + 4 * h);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) y[4 * h + r] = fmaxf(fmaf(acc[2 * j + h][ni][r], scv[r], shv[r]), 0.f);
-                        }
-                        if (!(ABL & 4) || y[0] == 12345.678f) store8(yp + co, y);
-                    }
-                    if constexpr (Cf::NB % 2 == 1) {
-                        constexpr int bb = Cf::NB - 1;
-                        const int co = bb * 16 + lq * 4;
-                        const f32x4 scv = *reinterpret_cast<const f32x4*>(ss + co);
-                        const f32x4 shv = *reinterpret_cast<const f32x4*>(ss + Cf::ROWS + co);
-                        float y[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) y[r] = fmaxf(fmaf(acc[bb][ni][r], scv[r], shv[r]), 0.f);
-                        store4(yp + co, y);
-                    }
-                }
-                stamp(5);
-            }
-        }
-    }
-    wait_vmcnt<0>();                                         // the surplus LDS-DMA of the last stage lands before the wave ends
-    if constexpr (STAMP) {
-        if (lane == 0 && stamps) {
-            unsigned long long* o = stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
-            for (int k = 0; k < 6; ++k) o[k] = tacc[k];
-            o[6] = clock_cycles() - tk0;
-            o[7] = clock_100mhz() - tr0;
-        }
-    }
-}
-
-#endif  // ALSEP_EXPERIMENTS (merged kernel)
+#ifdef ALSEP_EXPERIMENTS   // conv3x3_bf16_mny_kernel: superseded by conv3x3_bf16_mq_kernel, kept for A/B runs and the emulation
+#include "tdfnet_exp_mny.inc"
+#endif
 // ------------------------------------------------------------------------------------------
 // bf16 3x3 convolution, level 1 (c = 96): everything double-buffered.
 // Stamps of the merged kernel (profiles/r02_big_conv_stamps.txt): with its k-loop at 89 % of the MFMA issue floor, 17 % of the launch is
