@@ -11,8 +11,8 @@
 // 5.3 x the matrix throughput of the exact float32 kernels at the same storage and the same roundings everywhere else.  The lo parts
 // are scaled so that they stay NORMAL halves wherever hi is (an unscaled residual of 2^-11 x would be subnormal for |x| < 0.25: gfx950's
 // MFMA does keep subnormal inputs -- scripts/dbg/f16_denorm.hip -- but their spacing would cap the precision at 2^-25 absolute).
-// Range: |activation| <= 65504 (half); every staging pass checks its operands and raises the network's range flag, which the host
-// runners read after each track and turn into an error (mdx.py check_split_range).
+// Range: |activation| <= 65504 (half); every staging pass checks its operands and raises the network's range word; the host side reads it
+// after each batch and runs an out-of-range batch again on the exact f32 MFMA kernels (tdfnet.py forward_nhwc).
 // Weights are split once on the host (float64 -> hi / lo), activations where they are staged into LDS (VALU: cvt, sub, mul, cvt).
 //
 // Reference seam: the same network as the other modes (handlers/patch_separate.py:52; topology oracle/tdfnet_oracle.py).

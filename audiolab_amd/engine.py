@@ -200,7 +200,7 @@ class Separator:
         self.chunker, self.overlap, self.compensate = chunker, overlap, compensate
         self.allow_synthetic = bool(allow_synthetic)
         # float32 TFC-TDF networks: "split" = float32 storage with the contractions as (hi, lo) half products on the 16-bit matrix pipe
-        # (float32 accuracy at ~3 x the speed; activations limited to the half range, checked per run), "exact" = f32 MFMA fmaf chains
+        # (float32 accuracy at ~3 x the speed; activations limited to the half range, checked per batch: an out-of-range batch is redone on the exact kernels), "exact" = f32 MFMA fmaf chains
         if f32_contraction not in ("split", "exact"):
             raise AlsepError("f32_contraction must be 'split' or 'exact'")
         self.f32_contraction = f32_contraction

@@ -141,16 +141,6 @@ def get_models(device, dim_f, dim_t, n_fft, ctx: Optional[Context] = None):
                           dim_t=dim_t, n_fft=n_fft, ctx=ctx)
 
 
-def check_split_range(net, out: torch.Tensor) -> torch.Tensor:
-    """The float32 networks' split-half contractions (TDFNet(contraction="split"), csrc/tdfnet_f32s.h) carry activations as IEEE-half
-    pairs: an activation beyond 65504 makes the stems garbage (finite garbage on gfx950).  The kernels raise the network's range word
-    where they split their operands; it is read here, once per track, and never passes silently."""
-    if getattr(net, "contraction", None) == "split" and net.range_exceeded():
-        raise AlsepError("float32 network in split-half contraction mode: an activation left the half range (|x| > 65504); the stems of this "
-                         "track are invalid -- build the network with contraction='exact' (Separator(f32_contraction='exact')) for this input")
-    return out
-
-
 class Predictor:
     """Reference ``Predictor`` (mdxnet.py:90-197) on the GPU.
 
@@ -223,7 +213,7 @@ class Predictor:
             pos += n
         if pos != samples:
             raise AlsepError(f"demix stitched {pos} samples, expected {samples}")
-        return check_split_range(self.model, out)
+        return out
 
     # -- inner framing + inference + stitch of one segment, mdxnet.py:147-183 -------------------
     def demix_segment(self, cmix: torch.Tensor, async_gather: bool = False):
@@ -359,7 +349,7 @@ class OlaRunner:
             out = ctx.empty((2, n), torch.float32)
             ctx.check(ctx.lib.alsep_ola_combine(ctx.handle, _lib.ptr(waves), n_chunks, chunk, step, total, use_window,
                                                 compensate, _lib.ptr(out), n, trim, n), "alsep_ola_combine")
-            return out if match_mix else check_split_range(self.net, out)
+            return out
         # own output ranges in padded coordinates, clipped to the kept region [trim, trim + n): rank q owns from its first chunk's start
         # (rank 0: from trim) to the next rank's (the last rank: to the end)
         bounds = [adist.window_range(n_chunks, world, q) for q in range(world)]
@@ -392,5 +382,4 @@ class OlaRunner:
         if own_hi > own_lo:
             ctx.check(ctx.lib.alsep_ola_finish(ctx.handle, _lib.ptr(own), compensate, _lib.ptr(seg), seg.shape[1], own_hi - own_lo), "alsep_ola_finish")
         ranges = [(starts[q] - trim, starts[q + 1] - trim) for q in range(world)]
-        full = adist.all_gather_ranges(seg[:, : own_hi - own_lo].contiguous(), ranges, n, self.group)
-        return full if match_mix else check_split_range(self.net, full)
+        return adist.all_gather_ranges(seg[:, : own_hi - own_lo].contiguous(), ranges, n, self.group)

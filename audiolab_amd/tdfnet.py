@@ -130,7 +130,8 @@ class TDFNet:
                  dtype: torch.dtype = torch.float32, max_batch: int = 4, contraction: Optional[str] = None):
         """``contraction`` (float32 networks only): "split" (default) = float32 storage with every contraction as three f16 MFMA products
         of (hi, lo) half pairs, float32 accumulation -- the float32 mode's accuracy (2^-22 per product) at five times its matrix
-        throughput, activations limited to the half range (65504; beyond it the output is Inf / NaN and the runners raise); "exact" =
+        throughput, activations limited to the half range (65504; a batch that exceeds it is detected on the device and run again on the
+        exact kernels, see forward_nhwc); "exact" =
         v_mfma_f32_16x16x4_f32, bit for bit an fmaf chain."""
         if contraction is None:
             contraction = "split" if dtype == torch.float32 else "native"
@@ -153,6 +154,14 @@ class TDFNet:
             table = folded_tensors(state_dict, cfg)
         except KeyError as e:
             raise AlsepError(f"state_dict is missing {e} for this TDFNetConfig") from e
+        self._table = table if contraction == "split" else None       # kept (host tensors, a few MB) for the exact twin of a split network
+        self.handle = self._create(table, _lib.NET_SPLIT_F16 if contraction == "split" else 0)
+        self._exact = None                                             # the same weights on the f32 MFMA kernels, built on first need
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_batch = 0
+
+    def _create(self, table: Dict[str, torch.Tensor], flags: int) -> C.c_void_p:
+        cfg = self.cfg
         keep: List[torch.Tensor] = []
         entries = (_lib.TensorEntry * len(table))()
         for i, (name, t) in enumerate(table.items()):
@@ -161,22 +170,20 @@ class TDFNet:
             entries[i].name = name.encode()
             entries[i].data = d.data_ptr()
             entries[i].numel = d.numel()
-        ncfg = _lib.NetConfig(cfg.dim_f, cfg.dim_t, cfg.num_blocks, cfg.l, cfg.g, cfg.bn, _lib.dtype_code(dtype),
-                               _lib.NET_SPLIT_F16 if contraction == "split" else 0)
+        ncfg = _lib.NetConfig(cfg.dim_f, cfg.dim_t, cfg.num_blocks, cfg.l, cfg.g, cfg.bn, _lib.dtype_code(self.dtype), flags)
         self.ctx.synchronize()
         h = C.c_void_p()
-        self.ctx.check(self.ctx.lib.alsep_net_create(self.ctx.handle, C.byref(ncfg), entries, len(table), C.byref(h)),
-                       "alsep_net_create")
-        self.handle = h
-        self._ws: Optional[torch.Tensor] = None
-        self._ws_batch = 0
+        self.ctx.check(self.ctx.lib.alsep_net_create(self.ctx.handle, C.byref(ncfg), entries, len(table), C.byref(h)), "alsep_net_create")
         del keep
+        return h
 
     def __del__(self):
         try:
-            if getattr(self, "handle", None) and self.ctx.handle:
-                self.ctx.lib.alsep_net_destroy(self.handle)
-                self.handle = None
+            for attr in ("handle", "_exact"):
+                h = getattr(self, attr, None)
+                if h and self.ctx.handle:
+                    self.ctx.lib.alsep_net_destroy(h)
+                    setattr(self, attr, None)
         except Exception:
             pass
 
@@ -197,11 +204,11 @@ class TDFNet:
         return self._ws
 
     def _forward(self, spek: torch.Tensor, out: torch.Tensor, in_scale: float = 1.0, alpha: float = 1.0,
-                 beta: float = 0.0) -> None:
+                 beta: float = 0.0, handle=None) -> None:
         b = spek.shape[0]
         ws = self.workspace(b)
         base = (ws.data_ptr() + 255) & ~255
-        self.ctx.check(self.ctx.lib.alsep_net_forward(self.ctx.handle, self.handle, _lib.ptr(spek), _lib.ptr(out), b,
+        self.ctx.check(self.ctx.lib.alsep_net_forward(self.ctx.handle, handle or self.handle, _lib.ptr(spek), _lib.ptr(out), b,
                                                       C.c_void_p(base), ws.numel() - 256, in_scale, alpha, beta),
                        "alsep_net_forward")
 
@@ -212,15 +219,28 @@ class TDFNet:
                              f"{tuple(spek.shape)} {spek.dtype}")
         spek = spek.contiguous()
         out = torch.empty_like(spek)
-        step = self.max_batch if self.max_batch > 0 else spek.shape[0]
-        for b0 in range(0, spek.shape[0], step):
-            x = spek[b0:b0 + step]
-            y = out[b0:b0 + step]
-            if denoise:                                   # 0.5*f(x) - 0.5*f(-x), mdxnet.py:168-173
-                self._forward(x, y, 1.0, 0.5, 0.0)
-                self._forward(x, y, -1.0, -0.5, 1.0)
-            else:
-                self._forward(x, y)
+
+        def run(handle):
+            step = self.max_batch if self.max_batch > 0 else spek.shape[0]
+            for b0 in range(0, spek.shape[0], step):
+                x = spek[b0:b0 + step]
+                y = out[b0:b0 + step]
+                if denoise:                                   # 0.5*f(x) - 0.5*f(-x), mdxnet.py:168-173
+                    self._forward(x, y, 1.0, 0.5, 0.0, handle)
+                    self._forward(x, y, -1.0, -0.5, 1.0, handle)
+                else:
+                    self._forward(x, y, handle=handle)
+        run(self.handle)
+        # split-half contractions carry activations as IEEE-half pairs (|x| <= 65504).  A forward that met a larger activation raised the
+        # network's range word: its result is discarded and the same windows run again on the exact f32 MFMA kernels (same weights, the
+        # twin network is built on first need) -- slower, never wrong, never on the CPU.
+        if self.contraction == "split" and self.range_exceeded():
+            if self._exact is None:
+                import logging
+                logging.getLogger(__name__).warning("TDFNet: an activation left the half range (|x| > 65504) -- this and every later such batch "
+                                                    "runs on the exact float32 kernels (contraction='exact' avoids the double work)")
+                self._exact = self._create(self._table, 0)
+            run(self._exact)
         return out
 
     def forward_pcm(self, plan, pcm: torch.Tensor, ch_stride: int, chunk_stride: int, n_chunks: int, pcm_offset: int = 0,
