@@ -79,6 +79,8 @@ _SIGNATURES = {
                                      C.c_int64]),
     "alsep_zero_low_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int]),
     "alsep_net_range_flag": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    "alsep_nn_set_contraction": (C.c_int, [C.c_void_p, C.c_int]),
+    "alsep_nn_range_flag": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "alsep_net_create": (C.c_int, [C.c_void_p, C.POINTER(NetConfig), C.POINTER(TensorEntry), C.c_int64,
                                    C.POINTER(C.c_void_p)]),
     "alsep_net_destroy": (C.c_int, [C.c_void_p]),
@@ -238,11 +240,25 @@ class Context:
         if rc != 0:
             raise AlsepError(f"alsep_create failed ({rc})")
         self.handle = h
+        self.nn_split = False
 
     def check(self, rc: int, what: str) -> None:
         if rc != 0:
             msg = self.lib.alsep_last_error(self.handle)
             raise AlsepError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def set_nn_contraction(self, split: bool) -> None:
+        """the generic float32 GEMM / convolution entry points of this context: split-half products on the f16 matrix pipe (True) or
+        exact f32 MFMA (False, the library's default).  Not inside a stream capture (the first switch to True allocates a device word)."""
+        self.check(self.lib.alsep_nn_set_contraction(self.handle, 1 if split else 0), "alsep_nn_set_contraction")
+        self.nn_split = bool(split)
+
+    def nn_range_exceeded(self) -> bool:
+        """True when a split-contraction launch of this context met an operand beyond the half range since the last call (the results
+        since then are invalid); reads and clears the word, synchronises the stream"""
+        flag = C.c_int32(0)
+        self.check(self.lib.alsep_nn_range_flag(self.handle, C.byref(flag)), "alsep_nn_range_flag")
+        return bool(flag.value)
 
     def profile_begin(self, category: int) -> None:
         self.check(self.lib.alsep_profile_begin(self.handle, category), "alsep_profile_begin")

@@ -47,6 +47,10 @@ struct alsep_ctx {
     // launches per kernel name since alsep_create / alsep_launch_counts_reset (tests assert WHICH kernel ran)
     std::map<std::string, int64_t> launches;
     int cu_count = 0;                        // multiprocessors of `device`, read once per ctx
+    // generic float32 GEMM / convolution (alsep_nn_*): 1 = split-half contraction on the f16 matrix pipe (alsep_nn_set_contraction);
+    // nn_range: one device word the split kernels raise when an operand leaves the half range (allocated with the first switch to 1)
+    int nn_split = 0;
+    unsigned* nn_range = nullptr;
 };
 
 static inline void note_launch(alsep_ctx* ctx, const char* kernel) {

@@ -273,6 +273,7 @@ extern "C" int alsep_create(int device_id, void* hip_stream, alsep_ctx** out) {
 extern "C" int alsep_destroy(alsep_ctx* ctx) {
     if (ctx)
         for (hipEvent_t ev : ctx->prof_events) (void)hipEventDestroy(ev);
+    if (ctx && ctx->nn_range) (void)hipFree(ctx->nn_range);
     delete ctx;
     return ALSEP_OK;
 }

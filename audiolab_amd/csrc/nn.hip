@@ -252,6 +252,9 @@ nn_gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B, floa
         }
 }
 
+#define ALSEP_NN_F32S_GEMM
+#include "nn_f32s.h"
+
 // 0: not applicable; 1: B [N][K] (K contiguous); 2: B [K][N] (N contiguous).  A is K-contiguous with 16-byte aligned rows that can
 // be read up to K rounded up to 4 (row stride >= that), likewise a K-contiguous B.
 static int gemm_tiled_mode(const float* A, const float* B, int M, int N, int K, const GemmStrides& a, const GemmStrides& b) {
@@ -272,6 +275,22 @@ static int launch_gemm(alsep_ctx* ctx, const float* A, const float* B, float* C,
     const int mode = gemm_tiled_mode(A, B, M, N, K, a, b);
     ProfScope prof(ctx, ALSEP_PROF_NN_GEMM);
     prof.work(2.0 * nb * (double)M * N * K, 4.0 * nb * ((double)M * K + (double)N * K + (double)M * N));
+    if (mode && ctx->nn_split && ctx->nn_range) {             // the same product as three f16 MFMAs per (hi, lo) pair (nn_f32s.h)
+        const dim3 grid((unsigned)ceil_div64(N, GemmSCfg::BR), (unsigned)ceil_div64(M, GemmSCfg::BC), (unsigned)nb);
+        const bool ct = gemm_ct_ok(C, N, c);
+#define ALSEP_GEMM_GO(CT_, BNN_)                                                                                                     \
+    do {                                                                                                                             \
+        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)nn_gemm_split_kernel<CT_, BNN_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           (int)GemmSCfg::lds_bytes));                                                               \
+        hipLaunchKernelGGL((nn_gemm_split_kernel<CT_, BNN_>), grid, dim3(kNsThreads), GemmSCfg::lds_bytes, ctx->stream, A, B, C, nb2, M, N, \
+                           K, a, b, c, alpha, bias, act, ctx->nn_range);                                                             \
+    } while (0)
+        if (mode == 1) { if (ct) ALSEP_GEMM_GO(true, false); else ALSEP_GEMM_GO(false, false); }
+        else { if (ct) ALSEP_GEMM_GO(true, true); else ALSEP_GEMM_GO(false, true); }
+#undef ALSEP_GEMM_GO
+        ALSEP_LAUNCH_CHECK(ctx, "nn_gemm_split_kernel");
+        return ALSEP_OK;
+    }
     if (mode) {
         const dim3 grid((unsigned)ceil_div64(N, kGemmBN), (unsigned)ceil_div64(M, kGemmBM), (unsigned)nb);
         const size_t lds = 2 * (size_t)(kGemmBM + kGemmBN) * kGemmLD * sizeof(float);       // (the [16][132] B image is smaller)
@@ -963,6 +982,34 @@ unsigned ew_grid(int64_t n) {
 
 #define NN_ARG(cond, what) \
     if (!(cond)) return alsep_fail(ctx, ALSEP_ERR_ARG, what ": bad argument")
+
+// 1: the generic float32 GEMM / convolution entry points of this context run their contractions as split-half products on the f16 matrix
+// pipe (float32 in and out, 2^-22 per product; operands limited to the half range); 0: exact f32 MFMA (the default).  Not inside a capture.
+extern "C" int alsep_nn_set_contraction(alsep_ctx* ctx, int split) {
+    ALSEP_ENTER(ctx);
+    if (!ctx || (split != 0 && split != 1)) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_set_contraction: bad argument");
+    if (split && !ctx->nn_range) {
+        ALSEP_HIP(ctx, hipMalloc((void**)&ctx->nn_range, 16));
+        ALSEP_HIP(ctx, hipMemset(ctx->nn_range, 0, 16));
+    }
+    ctx->nn_split = split;
+    return ALSEP_OK;
+}
+
+// *out = 1 when a split-contraction launch of this context met an operand beyond the half range (|x| > 65504, or not a number) since the
+// last call: results computed since then are invalid.  Reads and clears the word; synchronises the context's stream.
+extern "C" int alsep_nn_range_flag(alsep_ctx* ctx, int32_t* out) {
+    ALSEP_ENTER(ctx);
+    if (!ctx || !out) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_range_flag: null argument");
+    *out = 0;
+    if (!ctx->nn_range) return ALSEP_OK;
+    unsigned v = 0;
+    ALSEP_HIP(ctx, hipMemcpyAsync(&v, ctx->nn_range, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    ALSEP_HIP(ctx, hipMemsetAsync(ctx->nn_range, 0, sizeof(v), ctx->stream));
+    ALSEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = v != 0;
+    return ALSEP_OK;
+}
 
 extern "C" int alsep_nn_bgemm(alsep_ctx* ctx, const float* A, const float* B, float* C, int nb1, int nb2, int M, int N, int K,
                               const int64_t* sa, const int64_t* sb, const int64_t* sc, float alpha) {

@@ -212,6 +212,9 @@ nn_conv2d_tiled_kernel(const float* __restrict__ x, const float* __restrict__ w,
     }
 }
 
+#define ALSEP_NN_F32S_CONV
+#include "nn_f32s.h"
+
 // the tiled kernel applies when a K-slice stays inside one tap and the rows are 16-byte aligned
 static bool conv_tiled_ok(const float* x, const float* w, int Cin, int Cout, int64_t npix) {
     static const int on = [] { const char* e = getenv("ALSEP_NN_CONV_TILED"); return e ? atoi(e) : 1; }();
@@ -221,6 +224,14 @@ static void launch_conv_tiled(alsep_ctx* ctx, const float* x, const float* w, co
                               int H, int W, int Cin, int Cout, int Ho, int Wo, int KH, int KW, int stride_h, int stride_w, int pad_h,
                               int pad_w, int dil_h, int dil_w, int act, int y_ct, int y_c0) {
     const int vec = (y_ct % 4 == 0 && y_c0 % 4 == 0 && ((uintptr_t)y & 15) == 0) ? 1 : 0;
+    if (ctx->nn_split && ctx->nn_range) {                    // split-half contraction (nn_f32s.h): 128 pixels x 64 channels per workgroup
+        (void)hipFuncSetAttribute((const void*)nn_conv2d_split_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmSCfg::lds_bytes);
+        hipLaunchKernelGGL(nn_conv2d_split_kernel<0>, dim3((unsigned)((Cout + 63) / 64), (unsigned)ceil_div64(npix, 128)), dim3(kNsThreads),
+                           GemmSCfg::lds_bytes, ctx->stream, x, w, scale, shift, y, npix, H, W, Cin, Cout, Ho, Wo, KH, KW, stride_h, stride_w, pad_h,
+                           pad_w, dil_h, dil_w, act, y_ct, y_c0, vec, ctx->nn_range);
+        note_launch(ctx, "nn_conv2d_split_kernel");
+        return;
+    }
     const int64_t big = ((Cout + 127) / 128) * ceil_div64(npix, 128);
     if (big >= 192) {                                        // enough 128 x 128 tiles for the chip
         const size_t lds = (2 * (size_t)128 * kCvLDA + 2 * (size_t)kCvBK * (128 + 4)) * sizeof(float);

@@ -341,7 +341,8 @@ class Separator:
                              f"package, or {pt}); random-init weights are only used with Separator(allow_synthetic=True)")
         net = HTDemucs(cfg, sd, ctx=self.ctx)
         inst = _ModelInstance(model_filename, net, None, cfg.sources[0].capitalize(), None)
-        inst.demucs = DemucsRunner(net, shifts=int(opts.get("shifts", 2)), overlap=float(opts.get("overlap", 0.25)), sharded=self.sharded)
+        inst.demucs = DemucsRunner(net, shifts=int(opts.get("shifts", 2)), overlap=float(opts.get("overlap", 0.25)), sharded=self.sharded,
+                                   contraction=self.f32_contraction)
         inst.output_dir = self.output_dir
         inst.weights = weights
         self._cache[model_filename] = inst
@@ -400,7 +401,7 @@ class Separator:
         net = Roformer(cfg, sd, ctx=self.ctx, precision="f16" if half_ok else "f32")
         labels = tuple(opts.get("labels", ("Vocals",)))[: cfg.num_stems]
         inst = _ModelInstance(model_filename, net, None, labels[0], opts.get("secondary") if cfg.num_stems == 1 else None)
-        inst.roformer = RoformerRunner(net, labels, sharded=self.sharded)
+        inst.roformer = RoformerRunner(net, labels, sharded=self.sharded, contraction=self.f32_contraction)
         inst.output_dir = self.output_dir
         inst.weights = weights
         self._cache[model_filename] = inst
@@ -446,7 +447,7 @@ class Separator:
                            cfg.num_channels, cfg.growth)
         net = MDX23C(cfg, sd, ctx=self.ctx, precision="f16" if half_ok else "f32")
         inst = _ModelInstance(model_filename, net, None, labels[0], None)
-        inst.roformer = RoformerRunner(net, labels, sharded=self.sharded)   # the same chunked runner (training project's demix_track)
+        inst.roformer = RoformerRunner(net, labels, sharded=self.sharded, contraction=self.f32_contraction)   # the same chunked runner (demix_track)
         inst.output_dir = self.output_dir
         inst.weights = weights
         self._cache[model_filename] = inst

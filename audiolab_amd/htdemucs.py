@@ -527,11 +527,17 @@ class DemucsRunner:
     (audio_separator defaults: shifts 2, overlap 0.25, segments of the model's training length), on the device."""
 
     def __init__(self, net: HTDemucs, shifts: int = 2, overlap: float = 0.25, seed: int = 0, sharded: bool = False, group=None,
-                 lanes: Optional[int] = None, graphs: Optional[bool] = None):
+                 lanes: Optional[int] = None, graphs: Optional[bool] = None, contraction: str = "exact"):
         """``lanes``: (shift, segment) units in flight at once, each on a HIP stream of its own (default: 4 on a GPU, 1 elsewhere).  One
         segment of htdemucs_6s is ~450 launches of mostly small kernels (grids of 42-170 workgroups on 256 CUs): units are independent,
         so running a few side by side fills the chip; the weighted sums are kept per lane and added at the end."""
         self.net, self.ctx = net, net.ctx
+        # ``contraction="split"``: the network's float32 convolutions / GEMMs run as split-half products on the f16 matrix pipe (csrc/
+        # nn_f32s.h: float32 in and out, 2^-22 per product) for the duration of a track; a track during which an operand left the half
+        # range is run again on the exact f32 MFMA kernels
+        if contraction not in ("split", "exact"):
+            raise AlsepError("contraction must be 'split' or 'exact'")
+        self.contraction = contraction
         self.shifts, self.overlap, self.seed = shifts, overlap, seed
         self.sharded, self.group = sharded, group
         if lanes is None:
@@ -590,6 +596,26 @@ class DemucsRunner:
 
     def separate(self, mix: torch.Tensor) -> Dict[str, torch.Tensor]:
         """mix [2, L] on the device -> {source name: [2, L]} (sources in the model's order)"""
+        if self.contraction != "split":
+            return self._separate(mix)
+        ctxs = [self.ctx] + [ln.ctx for ln, _ in self._lanes() if ln.ctx is not self.ctx]
+        try:
+            for c in ctxs:
+                c.set_nn_contraction(True)
+            out = self._separate(mix)
+            exceeded = [c.nn_range_exceeded() for c in ctxs]
+        finally:
+            for c in ctxs:
+                c.set_nn_contraction(False)
+        if any(exceeded):
+            import logging
+            logging.getLogger(__name__).warning("DemucsRunner: an operand left the half range (|x| > 65504) during this track -- running it "
+                                                "again on the exact float32 kernels")
+            self._graphs.clear()                               # captured with the split kernels
+            out = self._separate(mix)
+        return out
+
+    def _separate(self, mix: torch.Tensor) -> Dict[str, torch.Tensor]:
         ctx, net = self.ctx, self.net
         cfg = net.cfg
         lib, h = ctx.lib, ctx.handle

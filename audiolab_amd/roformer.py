@@ -525,7 +525,7 @@ class RoformerRunner:
     """chunked inference (``demix_track`` of the training project the checkpoints come from): mix [2, L] -> {label: [2, L]}"""
 
     def __init__(self, net, labels: Tuple[str, ...], lanes: Optional[int] = None, graphs: Optional[bool] = None, sharded: bool = False,
-                 group=None):
+                 group=None, contraction: str = "exact"):
         """``sharded=True``: the chunks of a track are split into contiguous ranges over the ranks of ``group`` (torch.distributed; one
         process per GPU); see ``demix``.  ``net``: a Roformer, or any network of the same training project with ``cfg.chunk_size / num_overlap / num_stems`` and
         ``forward([2, chunk]) -> [num_stems, 2, chunk]`` (MDX23C).  ``lanes``: chunks in flight at once, each on a HIP stream of its
@@ -535,6 +535,11 @@ class RoformerRunner:
         to the lane's stream, which is the capturing stream) and replays it per chunk: static input / output buffers, one graph launch."""
         self.net, self.ctx, self.labels = net, net.ctx, labels
         self.sharded, self.group = bool(sharded), group
+        # ``contraction="split"`` (float32 networks): their convolutions / GEMMs as split-half products on the f16 matrix pipe for the
+        # duration of a track (csrc/nn_f32s.h); a track during which an operand left the half range is run again on the exact kernels
+        if contraction not in ("split", "exact"):
+            raise AlsepError("contraction must be 'split' or 'exact'")
+        self.contraction = contraction
         if len(labels) != net.cfg.num_stems:
             raise AlsepError("one label per stem")
         import os
@@ -593,6 +598,27 @@ class RoformerRunner:
         return static_out
 
     def demix(self, mix: torch.Tensor) -> torch.Tensor:
+        half = getattr(self.net, "precision", "f32") == "f16" or bool(getattr(self.net, "half", False))
+        if self.contraction != "split" or half:                  # (the f16 networks keep their few float32 contractions exact)
+            return self._demix(mix)
+        ctxs = [self.ctx] + [ln.ctx for ln, _ in self._lanes() if ln.ctx is not self.ctx]
+        try:
+            for c in ctxs:
+                c.set_nn_contraction(True)
+            out = self._demix(mix)
+            exceeded = [c.nn_range_exceeded() for c in ctxs]
+        finally:
+            for c in ctxs:
+                c.set_nn_contraction(False)
+        if any(exceeded):
+            import logging
+            logging.getLogger(__name__).warning("RoformerRunner: an operand left the half range (|x| > 65504) during this track -- running it "
+                                                "again on the exact float32 kernels")
+            self._graphs.clear()                               # captured with the split kernels
+            out = self._demix(mix)
+        return out
+
+    def _demix(self, mix: torch.Tensor) -> torch.Tensor:
         """Sharded: rank r runs a contiguous range of the chunks and owns the output samples from its first chunk's start to
         the next rank's.  Its chunks reach up to ``chunk - step`` samples beyond that span: those seam sums of all ranks travel in one
         small all-gather and every rank adds the pieces that fall into its span; it then divides its span by the summed window weights,

@@ -203,6 +203,14 @@ int alsep_net_forward_pcm(alsep_ctx* ctx, const alsep_net* net, const alsep_plan
                           int64_t chunk_stride, void* spec_out, int64_t B, void* workspace, int64_t workspace_bytes, float in_scale,
                           float out_alpha, float out_beta, int zero_low_bins);
 
+/* The generic float32 GEMM / convolution entry points (alsep_nn_bgemm*, alsep_nn_conv2d, alsep_vr_conv2d on their tiled paths) of THIS
+ * context: split = 1 runs their contractions as split-half products on the f16 matrix pipe (float32 in and out, 2^-22 per product,
+ * operands limited to the half range), split = 0 (default) on exact f32 MFMA.  Call outside a stream capture. */
+int alsep_nn_set_contraction(alsep_ctx* ctx, int split);
+/* *out = 1 when a split-contraction launch of this context met an operand beyond the half range since the last call (results since then
+ * are invalid: run them again with split = 0).  Reads and clears the word; synchronises ctx's stream. */
+int alsep_nn_range_flag(alsep_ctx* ctx, int32_t* out);
+
 /* ALSEP_NET_SPLIT_F16 networks: *out = 1 when any forward since the last call met an operand beyond the half range (|x| > 65504, or not
  * a number) -- the results of those forwards are invalid (rebuild the network without the flag for such input).  Reads and clears the
  * network's range word; synchronises ctx's stream.  *out = 0 for every other network. */

@@ -108,11 +108,15 @@ def test_runner_vs_oracle(dev, shifts, n):
     net, sd = build(dev, ocfg, seed=7)
     mix = torch.randn(2, n, generator=torch.Generator().manual_seed(11)) * 0.2 + 0.01
     want = ho.separate(ocfg, sd, mix, shifts=shifts, overlap=0.25, seed=0).numpy()
-    out = DemucsRunner(net, shifts=shifts, overlap=0.25, seed=0).separate(on(dev, mix))
-    assert list(out) == list(ocfg.sources)
-    got = np.stack([host(out[k]) for k in ocfg.sources])
-    assert got.shape == want.shape == (3, 2, n)
-    assert float(np.max(np.abs(got - want))) < 1e-4
+    for contraction in ("exact", "split"):                      # f32 MFMA, then split-half products on the f16 pipe (csrc/nn_f32s.h)
+        dev.launch_counts_reset()
+        out = DemucsRunner(net, shifts=shifts, overlap=0.25, seed=0, contraction=contraction).separate(on(dev, mix))
+        assert list(out) == list(ocfg.sources)
+        got = np.stack([host(out[k]) for k in ocfg.sources])
+        assert got.shape == want.shape == (3, 2, n)
+        assert float(np.max(np.abs(got - want))) < 1e-4, contraction
+        split_launches = dev.launch_count("nn_conv2d_split_kernel") + dev.launch_count("nn_gemm_split_kernel")
+        assert (split_launches > 0) == (contraction == "split") and not dev.nn_split     # the switch is back to exact after the track
 
 
 def test_engine_multistem_stage_runs_htdemucs(dev):

@@ -58,13 +58,24 @@ def test_bgemm_layouts_vs_torch(dev, case):
     sa = _arr(nb2 * M * lda, M * lda, lda, 1)
     sb = _arr(nb2 * N * K, N * K, K, 1) if case["b"] == "nk" else _arr(nb2 * N * K, N * K, 1, N)
     bd = on(dev, bias) if bias is not None else None
-    dev.check(dev.lib.alsep_nn_bgemm_bias(dev.handle, _lib.ptr(Ad), _lib.ptr(Bd), _lib.ptr(Cd), nb1, nb2, M, N, K, sa, sb, sc, 0.7,
-                                          _lib.ptr(bd) if bd is not None else None, case["act"]), "alsep_nn_bgemm_bias")
-    got = torch.from_numpy(host(Cd)).double()
-    if not case["ct"]:
-        got = got.transpose(-1, -2)
-    scale = float(want.abs().max())
-    assert float((got - want).abs().max()) < 2e-5 * max(1.0, scale)
+    # both contractions of the float32 entry points: exact f32 MFMA, and split-half products on the f16 pipe (nn_f32s.h)
+    try:
+        for split in (False, True):
+            dev.set_nn_contraction(split)
+            dev.launch_counts_reset()
+            Cd.zero_()
+            dev.check(dev.lib.alsep_nn_bgemm_bias(dev.handle, _lib.ptr(Ad), _lib.ptr(Bd), _lib.ptr(Cd), nb1, nb2, M, N, K, sa, sb, sc, 0.7,
+                                                  _lib.ptr(bd) if bd is not None else None, case["act"]), "alsep_nn_bgemm_bias")
+            got = torch.from_numpy(host(Cd)).double()
+            if not case["ct"]:
+                got = got.transpose(-1, -2)
+            scale = float(want.abs().max())
+            assert float((got - want).abs().max()) < 2e-5 * max(1.0, scale), f"split={split}"
+            tiled = dev.launch_count("nn_gemm_tn_kernel") + dev.launch_count("nn_gemm_split_kernel") > 0
+            assert (dev.launch_count("nn_gemm_split_kernel") > 0) == (split and tiled)      # the split kernel takes every tiled case
+            assert not dev.nn_range_exceeded()
+    finally:
+        dev.set_nn_contraction(False)
 
 
 @pytest.mark.parametrize("case", [
@@ -98,12 +109,43 @@ def test_conv2d_shapes_vs_torch(dev, case):
     out = dev.zeros((B, Ho, Wo, ct))
     xd, wd = on(dev, x), on(dev, w.permute(2, 3, 1, 0).contiguous())       # [KH][KW][Cin][Cout]
     sd, hd = on(dev, scale), on(dev, shift)
-    dev.check(dev.lib.alsep_nn_conv2d(dev.handle, _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(sd), _lib.ptr(hd), _lib.ptr(out), B, H, W, cin, cout,
-                                      kh, kw, sh, sw, ph, pw, dh, dw, act, ct, c0), "alsep_nn_conv2d")
-    got = torch.from_numpy(host(out)).double()
-    assert float((got[..., c0:c0 + cout] - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
-    if ct != cout:                                              # nothing written outside the slice
-        assert float(got[..., :c0].abs().max()) == 0.0 and float(got[..., c0 + cout:].abs().max()) == 0.0
+    try:
+        for split in (False, True):                            # exact f32 MFMA, then the split-half contraction (nn_f32s.h)
+            dev.set_nn_contraction(split)
+            dev.launch_counts_reset()
+            out.zero_()
+            dev.check(dev.lib.alsep_nn_conv2d(dev.handle, _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(sd), _lib.ptr(hd), _lib.ptr(out), B, H, W, cin, cout,
+                                              kh, kw, sh, sw, ph, pw, dh, dw, act, ct, c0), "alsep_nn_conv2d")
+            got = torch.from_numpy(host(out)).double()
+            assert float((got[..., c0:c0 + cout] - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max())), f"split={split}"
+            if ct != cout:                                      # nothing written outside the slice
+                assert float(got[..., :c0].abs().max()) == 0.0 and float(got[..., c0 + cout:].abs().max()) == 0.0
+            tiled = dev.launch_count("nn_conv2d_tiled_kernel") > 0             # (the tiled path's launch site counts under this name in both modes)
+            assert (dev.launch_count("nn_conv2d_split_kernel") > 0) == (split and tiled)
+            assert not dev.nn_range_exceeded()
+    finally:
+        dev.set_nn_contraction(False)
+
+
+def test_split_contraction_raises_the_range_word(dev):
+    """an operand beyond the half range (|x| > 65504) raises the context's range word in the split kernels, and only there"""
+    g = torch.Generator().manual_seed(3)
+    A, Bm = torch.randn(1, 1, 128, 64, generator=g), torch.randn(1, 1, 64, 64, generator=g)
+    A[0, 0, 5, 7] = 1.0e5
+    Ad, Bd, Cd = on(dev, A), on(dev, Bm), dev.empty((1, 1, 128, 64))
+    args = (_lib.ptr(Ad), _lib.ptr(Bd), _lib.ptr(Cd), 1, 1, 128, 64, 64, _arr(128 * 64, 128 * 64, 64, 1), _arr(64 * 64, 64 * 64, 64, 1),
+            _arr(128 * 64, 128 * 64, 64, 1), 1.0, None, 0)
+    try:
+        dev.set_nn_contraction(True)
+        dev.check(dev.lib.alsep_nn_bgemm_bias(dev.handle, *args), "alsep_nn_bgemm_bias")
+        assert dev.nn_range_exceeded() and not dev.nn_range_exceeded()          # read clears it
+        dev.set_nn_contraction(False)
+        dev.check(dev.lib.alsep_nn_bgemm_bias(dev.handle, *args), "alsep_nn_bgemm_bias")
+        assert not dev.nn_range_exceeded()
+        want = A[0, 0].double() @ Bm[0, 0].double().t()
+        assert float((torch.from_numpy(host(Cd))[0, 0].double() - want).abs().max()) < 1e-1 * 2e-5 * float(want.abs().max()) + 2e-2
+    finally:
+        dev.set_nn_contraction(False)
 
 
 def test_softmax_rows_with_leading_dimension(dev):

@@ -60,10 +60,13 @@ def test_runner_vs_oracle(dev, kind, n):
     mix = torch.randn(2, n, generator=torch.Generator().manual_seed(9)) * 0.25
     want = ro.demix_track(ocfg, sd, mix).numpy()
     labels = ("vocals", "other")[: ocfg.num_stems]
-    out = RoformerRunner(net, labels).separate(on(dev, mix))
-    got = np.stack([host(out[k]) for k in labels])
-    assert got.shape == want.shape
-    assert float(np.max(np.abs(got - want))) < 1e-4
+    for contraction in ("exact", "split"):                      # f32 MFMA, then split-half products on the f16 pipe (csrc/nn_f32s.h)
+        dev.launch_counts_reset()
+        out = RoformerRunner(net, labels, contraction=contraction).separate(on(dev, mix))
+        got = np.stack([host(out[k]) for k in labels])
+        assert got.shape == want.shape
+        assert float(np.max(np.abs(got - want))) < 1e-4, contraction
+        assert (dev.launch_count("nn_gemm_split_kernel") > 0) == (contraction == "split") and not dev.nn_split
 
 
 @pytest.mark.gpu
