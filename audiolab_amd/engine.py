@@ -174,7 +174,7 @@ class Separator:
                  dtype: Optional[torch.dtype] = None, sample_rate: int = 44100, chunks: int = 0, margin: int = 44100,
                  denoise: bool = False, max_batch: int = 32, sharded: bool = False, roster: Optional[Dict[str, tuple]] = None,
                  chunker: str = "margin", overlap: float = 0.25, compensate: Optional[float] = None,
-                 allow_synthetic: bool = False, normalization_threshold: float = 0.9, f32_contraction: str = "split", **_ignored):
+                 allow_synthetic: bool = False, normalization_threshold: float = 0.9, f32_contraction: str = "split", nn_contraction: str = "exact", **_ignored):
         """``allow_synthetic=True`` (bench, tests): a roster name without a weight file gets seeded random-init weights.
         The default refuses to: a missing model file is an error, never plausible-looking noise."""
         self.log_level = log_level
@@ -204,6 +204,11 @@ class Separator:
         if f32_contraction not in ("split", "exact"):
             raise AlsepError("f32_contraction must be 'split' or 'exact'")
         self.f32_contraction = f32_contraction
+        # the float32 modes of the OTHER families (HTDemucs, Roformer, MDX23C): "exact" (default: f32 MFMA, four runner lanes) or "split" (the
+        # generic kernels of csrc/nn_f32s.h on ONE lane: faster per kernel, but 16-bit MFMA kernels cannot share the GPU with other lanes' FFTs)
+        if nn_contraction not in ("split", "exact"):
+            raise AlsepError("nn_contraction must be 'split' or 'exact'")
+        self.nn_contraction = nn_contraction
         self.model_instance: Optional[_ModelInstance] = None
         self._cache: Dict[str, _ModelInstance] = {}
 
@@ -342,7 +347,7 @@ class Separator:
         net = HTDemucs(cfg, sd, ctx=self.ctx)
         inst = _ModelInstance(model_filename, net, None, cfg.sources[0].capitalize(), None)
         inst.demucs = DemucsRunner(net, shifts=int(opts.get("shifts", 2)), overlap=float(opts.get("overlap", 0.25)), sharded=self.sharded,
-                                   contraction=self.f32_contraction)
+                                   contraction=self.nn_contraction)
         inst.output_dir = self.output_dir
         inst.weights = weights
         self._cache[model_filename] = inst
@@ -401,7 +406,7 @@ class Separator:
         net = Roformer(cfg, sd, ctx=self.ctx, precision="f16" if half_ok else "f32")
         labels = tuple(opts.get("labels", ("Vocals",)))[: cfg.num_stems]
         inst = _ModelInstance(model_filename, net, None, labels[0], opts.get("secondary") if cfg.num_stems == 1 else None)
-        inst.roformer = RoformerRunner(net, labels, sharded=self.sharded, contraction=self.f32_contraction)
+        inst.roformer = RoformerRunner(net, labels, sharded=self.sharded, contraction=self.nn_contraction)
         inst.output_dir = self.output_dir
         inst.weights = weights
         self._cache[model_filename] = inst
@@ -447,7 +452,7 @@ class Separator:
                            cfg.num_channels, cfg.growth)
         net = MDX23C(cfg, sd, ctx=self.ctx, precision="f16" if half_ok else "f32")
         inst = _ModelInstance(model_filename, net, None, labels[0], None)
-        inst.roformer = RoformerRunner(net, labels, sharded=self.sharded, contraction=self.f32_contraction)   # the same chunked runner (demix_track)
+        inst.roformer = RoformerRunner(net, labels, sharded=self.sharded, contraction=self.nn_contraction)   # the same chunked runner (demix_track)
         inst.output_dir = self.output_dir
         inst.weights = weights
         self._cache[model_filename] = inst

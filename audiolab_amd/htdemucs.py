@@ -532,12 +532,16 @@ class DemucsRunner:
         segment of htdemucs_6s is ~450 launches of mostly small kernels (grids of 42-170 workgroups on 256 CUs): units are independent,
         so running a few side by side fills the chip; the weighted sums are kept per lane and added at the end."""
         self.net, self.ctx = net, net.ctx
-        # ``contraction="split"``: the network's float32 convolutions / GEMMs run as split-half products on the f16 matrix pipe (csrc/
-        # nn_f32s.h: float32 in and out, 2^-22 per product) for the duration of a track; a track during which an operand left the half
-        # range is run again on the exact f32 MFMA kernels
+        # ``contraction="split"`` (opt-in): the network's float32 convolutions / GEMMs run as split-half products on the f16 matrix pipe
+        # (csrc/nn_f32s.h: float32 in and out, 2^-22 per product) for the duration of a track, on ONE lane; a track during which an operand
+        # left the half range is run again on the exact f32 MFMA kernels.  Measured (10 min, one GPU): exact with four lanes 1.66 s; split
+        # with four lanes 1.38 s but WRONG (the FFT launches of the other lanes are corrupted beside the f16 MFMA waves, 3e-4 at peak
+        # 0.014 and not reproducible); hence one lane, and the default stays exact.
         if contraction not in ("split", "exact"):
             raise AlsepError("contraction must be 'split' or 'exact'")
         self.contraction = contraction
+        if contraction == "split":
+            lanes = 1          # the split kernels issue f16 MFMA: FFT launches must not share the GPU with them (roformer.RoformerRunner, DESIGN section 6)
         self.shifts, self.overlap, self.seed = shifts, overlap, seed
         self.sharded, self.group = sharded, group
         if lanes is None:

@@ -535,11 +535,15 @@ class RoformerRunner:
         to the lane's stream, which is the capturing stream) and replays it per chunk: static input / output buffers, one graph launch."""
         self.net, self.ctx, self.labels = net, net.ctx, labels
         self.sharded, self.group = bool(sharded), group
-        # ``contraction="split"`` (float32 networks): their convolutions / GEMMs as split-half products on the f16 matrix pipe for the
-        # duration of a track (csrc/nn_f32s.h); a track during which an operand left the half range is run again on the exact kernels
+        # ``contraction="split"`` (float32 networks, opt-in): their convolutions / GEMMs as split-half products on the f16 matrix pipe for
+        # the duration of a track (csrc/nn_f32s.h), on ONE lane; a track during which an operand left the half range is run again on the
+        # exact kernels.  With four lanes the split kernels (f16 MFMA) corrupt the other lanes' FFT launches: Mel-Band float32 120 s
+        # 2.72 -> 2.33 s but 7.6e-3 off at peak 0.10 and not reproducible (profiles/r04_contraction_ab.txt)
         if contraction not in ("split", "exact"):
             raise AlsepError("contraction must be 'split' or 'exact'")
         self.contraction = contraction
+        if contraction == "split":
+            lanes = 1          # f16 MFMA kernels on every lane's stream: the one-lane rule of the half-precision networks applies (below)
         if len(labels) != net.cfg.num_stems:
             raise AlsepError("one label per stem")
         import os

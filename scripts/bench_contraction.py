@@ -1,4 +1,5 @@
-"""float32 model families with their contractions as exact f32 MFMA vs split-half products on the f16 pipe (csrc/nn_f32s.h), one GPU:
+"""float32 model families with their contractions as exact f32 MFMA (four runner lanes) vs split-half products on the f16 pipe (csrc/nn_f32s.h;
+one lane: 16-bit MFMA kernels must not share the GPU with other lanes' FFT launches), one GPU:
 htdemucs_6s (10 min), Mel-Band Roformer, BS Roformer and MDX23C in their float32 modes (120 s); seconds per track, same stems check."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -12,7 +13,7 @@ for name, secs in cases:
     mix = torch.from_numpy(synth_mix(secs * 44100)).cuda()
     outs = {}
     for mode in ("exact", "split"):
-        eng = Separator(ctx=ctx, use_autocast=False, allow_synthetic=True, f32_contraction=mode)
+        eng = Separator(ctx=ctx, use_autocast=False, allow_synthetic=True, nn_contraction=mode)
         eng.load_model(name)
         eng.separate_array(mix[:, : 30 * 44100])
         torch.cuda.synchronize()

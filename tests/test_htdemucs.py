@@ -116,7 +116,7 @@ def test_runner_vs_oracle(dev, shifts, n):
         assert got.shape == want.shape == (3, 2, n)
         assert float(np.max(np.abs(got - want))) < 1e-4, contraction
         split_launches = dev.launch_count("nn_conv2d_split_kernel") + dev.launch_count("nn_gemm_split_kernel")
-        assert (split_launches > 0) == (contraction == "split") and not dev.nn_split     # the switch is back to exact after the track
+        assert (split_launches > 0) == (contraction == "split") and not dev.nn_split     # one lane on dev's stream; the switch is back to exact after the track
 
 
 def test_engine_multistem_stage_runs_htdemucs(dev):
