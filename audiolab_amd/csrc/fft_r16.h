@@ -217,11 +217,11 @@ template <> __device__ __forceinline__ void store_bin<bf16_t>(bf16_t* spec, int6
 // Bit-identical to stft + first_conv: the bin values are rounded to the storage type exactly where the spectrogram store rounded them,
 // each output is the same chain w.x x0, fma(w.y, x1), fma(w.z, x2), fma(w.w, x3), fma(., scale in_scale, shift), and the ReLU is taken on
 // the rounded value's 16-bit pattern (signed max with 0: rounding keeps the sign, and -0 becomes +0 as fmaxf(-0, 0) does).
-// Work split of the epilogue = first_conv_kernel's: once every thread holds its pass-C inputs the frame buffer is dead and receives the
-// frame's rounded bins ([dim_f] x 8 bytes); then thread tid < 126 owns ONE group of 8 output channels (tid % 6: its 32 weights, 8 scales
-// and 8 shifts stay in registers) and walks the bins 21 at a time (tid / 6 + 21 i), so that the workgroup's stores of one round are 126
-// consecutive 16-byte pieces of act.  (Two earlier forms -- every thread computing all 48 channels of its own bins, weights re-read per
-// bin pair from LDS or through scalar loads -- were bound by exactly those re-reads: 1.0-1.3 ms per launch of 52 chunks.)
+// Work split of the epilogue: once every thread holds its pass-C inputs the frame buffer is dead and receives the frame's rounded bins
+// ([dim_f] x 8 bytes); the store phase then writes the frame's activation row in whole 128-byte lines, 2048 bytes per round (see (2) in
+// the kernel).  (Earlier forms -- every thread computing all 48 channels of its own bins, weights re-read per bin pair from LDS or
+// through scalar loads -- were bound by exactly those re-reads: 1.0-1.3 ms per launch of 52 chunks; one fixed channel group per thread
+// with 126 active lanes wrote rounds of 2016 bytes that split lines between store instructions: 0.90 ms.)
 struct FirstConvArgs {
     const float* w;        // [48][4]
     const float* scale;    // [48]
@@ -231,7 +231,6 @@ struct FirstConvArgs {
 };
 constexpr int kFirstConvG = 48;
 constexpr int kFirstConvGroups = kFirstConvG / 8;            // 16-byte pieces per bin
-constexpr int kFirstConvBinsPerRound = kThreads / kFirstConvGroups;   // 21 (threads 126, 127 idle in the epilogue)
 
 // grid (T, n_chunks), 128 threads.
 template <int R2, typename OutT, int LAYOUT, bool FUSE = false>
@@ -421,34 +420,43 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
                 if (k1 < dim_f) xs[k1] = v1;
                 if (k2 < dim_f) xs[k2] = v2;
             }
-            // (2) this thread's channel group
-            const int cg = tid % kFirstConvGroups, bl = tid / kFirstConvGroups;
-            const bool active = bl < kFirstConvBinsPerRound;
-            v2f wx[4], wy[4], wz[4], ww[4], sc[4], sh[4];
+            // (2) the store phase walks the frame's activation row (dim_f x 96 bytes) LINEARLY, 128 pieces of 16 bytes = 2048 bytes = 16 whole
+            // 128-byte lines per round: piece 128 r + tid = (bin, channel group) = (piece / 6, piece % 6).  128 = 2 mod 6, so a thread's
+            // channel group cycles with period 3 in r: it keeps the weights of its three groups (tid % 6 + 2 s) % 6 in registers (144
+            // values -- the FFT's registers are dead by now) and a super-round of three rounds covers 64 bins.  (The earlier form gave a
+            // thread ONE group and 126 active lanes, i.e. rounds of 2016 bytes whose ends split a line between two store instructions:
+            // a bare fill in that shape runs at 4.15 TB/s on this box against 5.55 TB/s for whole lines, profiles/r04_fill_bench.txt.)
+            v2f wx[3][4], wy[3][4], wz[3][4], ww[3][4], sc[3][4], sh[3][4];
+            int bl[3];
 #pragma unroll
-            for (int pr = 0; pr < 4; ++pr) {
-                const int c = 8 * cg + 2 * pr;
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(fc.w + 4 * c), w1 = *reinterpret_cast<const f32x4*>(fc.w + 4 * c + 4);
-                wx[pr] = mk(w0[0], w1[0]); wy[pr] = mk(w0[1], w1[1]); wz[pr] = mk(w0[2], w1[2]); ww[pr] = mk(w0[3], w1[3]);
-                sc[pr] = mk(fc.scale[c] * fc.in_scale, fc.scale[c + 1] * fc.in_scale);
-                sh[pr] = mk(fc.shift[c], fc.shift[c + 1]);
+            for (int sr = 0; sr < 3; ++sr) {
+                const int j = kThreads * sr + tid;
+                const int cg = j % kFirstConvGroups;
+                bl[sr] = j / kFirstConvGroups;
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const int c = 8 * cg + 2 * pr;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(fc.w + 4 * c), w1 = *reinterpret_cast<const f32x4*>(fc.w + 4 * c + 4);
+                    wx[sr][pr] = mk(w0[0], w1[0]); wy[sr][pr] = mk(w0[1], w1[1]); wz[sr][pr] = mk(w0[2], w1[2]); ww[sr][pr] = mk(w0[3], w1[3]);
+                    sc[sr][pr] = mk(fc.scale[c] * fc.in_scale, fc.scale[c + 1] * fc.in_scale);
+                    sh[sr][pr] = mk(fc.shift[c], fc.shift[c + 1]);
+                }
             }
             __syncthreads();
-            // (3) rounds of 21 bins: piece index 126 i + tid of the frame's activation row, i.e. linear 16-byte stores
             char* dst = reinterpret_cast<char*>(spec + frame_off * kFirstConvG) + 16 * tid;
-            const int rounds = (dim_f + kFirstConvBinsPerRound - 1) / kFirstConvBinsPerRound;
             typedef OutT o2_t __attribute__((ext_vector_type(2)));
             typedef short s16x2 __attribute__((ext_vector_type(2)));
-            auto one = [&](x4_t x) {
+            auto one = [&](x4_t x, auto srt) {
+                constexpr int sr = decltype(srt)::value;
                 const float x0 = (float)x[0], x1 = (float)x[1], x2 = (float)x[2], x3 = (float)x[3];
                 s16x8 o;
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr) {
-                    v2f a = wx[pr] * x0;
-                    a = __builtin_elementwise_fma(wy[pr], mk(x1, x1), a);
-                    a = __builtin_elementwise_fma(wz[pr], mk(x2, x2), a);
-                    a = __builtin_elementwise_fma(ww[pr], mk(x3, x3), a);
-                    a = __builtin_elementwise_fma(a, sc[pr], sh[pr]);
+                    v2f a = wx[sr][pr] * x0;
+                    a = __builtin_elementwise_fma(wy[sr][pr], mk(x1, x1), a);
+                    a = __builtin_elementwise_fma(wz[sr][pr], mk(x2, x2), a);
+                    a = __builtin_elementwise_fma(ww[sr][pr], mk(x3, x3), a);
+                    a = __builtin_elementwise_fma(a, sc[sr][pr], sh[sr][pr]);
                     const s16x2 h = __builtin_bit_cast(s16x2, __builtin_convertvector(a, o2_t));    // one packed convert per pair
                     o[2 * pr] = h[0];
                     o[2 * pr + 1] = h[1];
@@ -456,21 +464,28 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
                 const s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
                 return __builtin_elementwise_max(o, zero);
             };
-            constexpr int U = 4;                                                     // rounds in flight
-            constexpr int kRoundBytes = kFirstConvBinsPerRound * kFirstConvG * (int)sizeof(OutT);
-            int i = 0;
-            if (active) {
-                for (; i + U <= rounds - 1; i += U) {                                // every bin of these rounds is below dim_f
-                    x4_t x[U];
+            constexpr int kRoundBytes = kThreads * 16;                                // 2048
+            constexpr int kSuperBins = 3 * kThreads / kFirstConvGroups;               // 64 bins per super-round
+            const int supers = dim_f / kSuperBins;                                    // whole super-rounds: every bin below dim_f
+            int I = 0;
+            for (; I + 2 <= supers; I += 2) {                                         // six rounds in flight
+                x4_t x[6];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) x[u] = xs[bl + kFirstConvBinsPerRound * (i + u)];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) stream_store(reinterpret_cast<s16x8*>(dst + (int64_t)kRoundBytes * (i + u)), one(x[u]));
-                }
-                for (; i < rounds; ++i) {
-                    const int bin = bl + kFirstConvBinsPerRound * i;
-                    if (bin < dim_f) stream_store(reinterpret_cast<s16x8*>(dst + (int64_t)kRoundBytes * i), one(xs[bin]));
-                }
+                for (int u = 0; u < 6; ++u) x[u] = xs[kSuperBins * (I + u / 3) + bl[u % 3]];
+                char* d = dst + (int64_t)(3 * kRoundBytes) * I;
+                stream_store(reinterpret_cast<s16x8*>(d), one(x[0], std::integral_constant<int, 0>()));
+                stream_store(reinterpret_cast<s16x8*>(d + kRoundBytes), one(x[1], std::integral_constant<int, 1>()));
+                stream_store(reinterpret_cast<s16x8*>(d + 2 * kRoundBytes), one(x[2], std::integral_constant<int, 2>()));
+                stream_store(reinterpret_cast<s16x8*>(d + 3 * kRoundBytes), one(x[3], std::integral_constant<int, 0>()));
+                stream_store(reinterpret_cast<s16x8*>(d + 4 * kRoundBytes), one(x[4], std::integral_constant<int, 1>()));
+                stream_store(reinterpret_cast<s16x8*>(d + 5 * kRoundBytes), one(x[5], std::integral_constant<int, 2>()));
+            }
+            for (; kSuperBins * I < dim_f; ++I) {                                     // the odd super-round and a ragged end (dim_f % 64)
+                char* d = dst + (int64_t)(3 * kRoundBytes) * I;
+                const int b0 = kSuperBins * I + bl[0], b1 = kSuperBins * I + bl[1], b2 = kSuperBins * I + bl[2];
+                if (b0 < dim_f) stream_store(reinterpret_cast<s16x8*>(d), one(xs[b0], std::integral_constant<int, 0>()));
+                if (b1 < dim_f) stream_store(reinterpret_cast<s16x8*>(d + kRoundBytes), one(xs[b1], std::integral_constant<int, 1>()));
+                if (b2 < dim_f) stream_store(reinterpret_cast<s16x8*>(d + 2 * kRoundBytes), one(xs[b2], std::integral_constant<int, 2>()));
             }
         } else {
             if (dim_f >= N / 2) emit(std::true_type());          // every bin below N/2 is kept: no per-bin predicate
