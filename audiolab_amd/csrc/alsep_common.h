@@ -51,7 +51,23 @@ struct alsep_ctx {
     // nn_range: one device word the split kernels raise when an operand leaves the half range (allocated with the first switch to 1)
     int nn_split = 0;
     unsigned* nn_range = nullptr;
+    void* zero_page = nullptr;               // 256 zero bytes, allocated by the first kernel that pads a ragged K from it (nn_gemm_h2.h)
 };
+
+// multiprocessors of the context's device (256 on MI355X), read once
+static inline int device_cu_count(alsep_ctx* ctx) {
+#ifdef ALSEP_CPU_EMUL
+    (void)ctx;
+    return 256;
+#else
+    if (ctx->cu_count <= 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || v <= 0) v = 256;
+        ctx->cu_count = v;
+    }
+    return ctx->cu_count;
+#endif
+}
 
 static inline void note_launch(alsep_ctx* ctx, const char* kernel) {
     if (ctx) ++ctx->launches[kernel];

@@ -78,6 +78,11 @@ __device__ __forceinline__ void global_load_async_bf16x8(bf16x8& dst, const void
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
 
+// The same for a float32 quad and a byte offset without immediate (epilogue operands of nn_gemm_h2.h)
+__device__ __forceinline__ void global_load_async_f32x4(f32x4& dst, const void* sbase, unsigned voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+
 // Asynchronous 16-byte LDS read into a register fragment, invisible to hipcc's waitcnt bookkeeping (as the global form above):
 //   dst <- *(lds_ptr + OFF bytes), OFF in the instruction's 16-bit immediate.
 // Why: in a software-pipelined k-loop (fragments of step s+1 requested before the MFMAs of step s) ROCm 7.2 waits

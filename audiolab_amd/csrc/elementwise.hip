@@ -274,6 +274,7 @@ extern "C" int alsep_destroy(alsep_ctx* ctx) {
     if (ctx)
         for (hipEvent_t ev : ctx->prof_events) (void)hipEventDestroy(ev);
     if (ctx && ctx->nn_range) (void)hipFree(ctx->nn_range);
+    if (ctx && ctx->zero_page) (void)hipFree(ctx->zero_page);
     delete ctx;
     return ALSEP_OK;
 }

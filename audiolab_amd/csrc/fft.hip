@@ -589,20 +589,6 @@ static int istft_pick_run(int n_blocks, int Q, int64_t n_chunks, int slots) {
     return best;
 }
 
-static int device_cu_count(alsep_ctx* ctx) {
-#ifdef ALSEP_CPU_EMUL
-    (void)ctx;
-    return 256;
-#else
-    if (ctx->cu_count <= 0) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || v <= 0) v = 256;
-        ctx->cu_count = v;
-    }
-    return ctx->cu_count;
-#endif
-}
-
 // ALSEP_STFT_R16=0 falls back to the generic multi-pass kernel for 4096 / 6144 (A/B timing, cross-check)
 static int stft_r16_enabled() {
     static const int v = [] { const char* e = getenv("ALSEP_STFT_R16"); return e ? atoi(e) : 1; }();

@@ -17,6 +17,7 @@
 //   roformer_bandsplit_in_kernel   gather + RMSNorm of every band of a frame -> zero-padded f16 rows of one batched Linear
 #include "alsep_common.h"
 #include <alsep_gfx950_asm.h>
+#include "nn_gemm_h2.h"
 
 namespace {
 
@@ -29,7 +30,8 @@ constexpr int kHThreads = 256;
 // exponential and a degree-5 polynomial instead of erff's branchy 40-instruction expansion (40 of the 162 us of the 48 060 x 1536 Linear)
 __device__ __forceinline__ float gelu_erf_h(float v) {
     const float x = fabsf(v) * 0.70710678118654752440f;
-    const float t = 1.f / fmaf(0.3275911f, x, 1.f);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));   // v_rcp_f32 (1 ulp): the IEEE division is ten instructions, and this epilogue
+                                                                      // is a third of the 48 060 x 1536 Linear's time
     const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
     const float erf_abs = 1.f - poly * __expf(-x * x);
     return 0.5f * v * (1.f + copysignf(erf_abs, v));
@@ -222,6 +224,13 @@ nn_gemm_hh_kernel(GemmHArgs p) {
             }
         }
     }
+}
+
+// the large-M form (nn_gemm_h2.h): persistent, 256 x 128 tiles, LDS-DMA ring across tile ends
+template <int ACT, bool CF16, bool RES, bool RAGK>
+__global__ void __launch_bounds__(h2::kThreads, 2)
+nn_gemm_h2_kernel(h2::Args p) {
+    h2::gemm_body<ACT, CF16, RES, RAGK>(p, [](float t) { return hg_act<ACT>(t); });
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -440,16 +449,17 @@ to_f16_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int64_t n) 
 // scaled by sigmoid(gates[row][head]) and stored as IEEE half (the A operand of the output projection) through (o_seq_stride,
 // o_row_stride).  head dimension 64.
 //
-// One workgroup = 64 queries of one (sequence, head), four waves of 16 queries; keys / values in chunks of 32 staged through LDS for
-// all four waves (K rows of 64 halves, 16-byte groups XOR-swizzled by row & 7: conflict-free ds_read_b128; V TRANSPOSED, rows of 32
-// keys padded to 36 halves: conflict-free ds_read_b64).  Per chunk and wave:
-//     S^T[key][query] = K Q^T            2 key blocks x 2 MFMA steps (d = 64); Q fragments live in registers (scaled by d^-1/2)
-//     online softmax per query           a query's 32 scores sit in the 4 lanes {l15, l15 + 16, + 32, + 48}: two shuffles for the max
-//     O^T[d][query] += V^T P^T           4 d blocks x 1 MFMA step; P^T is the B operand AS THE LANE HOLDS IT (contraction index e of lane
-//                                        quarter lq = key 16 (e / 4) + 4 lq + e % 4, V^T read in the same order), O rescaled per lane
+// One workgroup = 64 QB queries of one (sequence, head), four waves of QB blocks of 16 queries; keys / values in chunks of 64 staged
+// through LDS for all four waves (K rows of 64 halves, 16-byte groups XOR-swizzled by row & 7: conflict-free ds_read_b128; V TRANSPOSED,
+// rows of 64 keys padded to 72 halves: conflict-free ds_read_b64).  Per chunk and wave:
+//     S^T[key][query] = K Q^T            4 key blocks x 2 MFMA steps (d = 64) per query block; Q fragments live in registers (scaled by
+//                                        d^-1/2 log2 e: the scores are base-2 exponents)
+//     online softmax per query           a query's 64 scores sit in the 4 lanes {l15, l15 + 16, + 32, + 48}: two shuffles for the max
+//     O^T[d][query] += V^T P^T           4 d blocks x 2 MFMA steps; P^T is the B operand AS THE LANE HOLDS IT (contraction index e of lane
+//                                        quarter lq = key 32 ks + 16 (e / 4) + 4 lq + e % 4, V^T read in the same order), O rescaled per lane
 // The row sums are carried per lane and reduced once at the end.  float32 everywhere outside the two MFMA operands.
 // ------------------------------------------------------------------------------------------------------------------------------------
-constexpr int kAtD = 64, kAtKc = 32, kAtVld = 36;
+constexpr int kAtD = 64, kAtKc = 64, kAtVld = 72;
 
 // rotary embedding of 8 consecutive head-dimension values (4 interleaved pairs) by the table entries (cos, sin) of their position:
 // (a, b) -> (a cos - b sin, b cos + a sin), the arithmetic of nn_rotary_kernel
@@ -477,7 +487,7 @@ rotary_table_kernel(float* __restrict__ table, int L, int d) {
         table[2 * i + 1] = sinf(ang);
     }
 }
-constexpr size_t kAtLds = (size_t)kAtKc * kAtD * sizeof(_Float16) + (size_t)kAtD * kAtVld * sizeof(_Float16);     // 4096 + 4608
+constexpr size_t kAtLds = (size_t)kAtKc * kAtD * sizeof(_Float16) + (size_t)kAtD * kAtVld * sizeof(_Float16);     // 8192 + 9216
 
 // 8 halves -> two float4
 __device__ __forceinline__ void h8_to_f(const h16x8& v, f32x4& a, f32x4& b) {
@@ -485,120 +495,172 @@ __device__ __forceinline__ void h8_to_f(const h16x8& v, f32x4& a, f32x4& b) {
     b[0] = (float)v[4]; b[1] = (float)v[5]; b[2] = (float)v[6]; b[3] = (float)v[7];
 }
 
+// One pass over the keys in chunks of 64, online softmax, no score matrix in HBM.  A workgroup = 4 waves x QB blocks of 16 queries
+// (QB = 2: 128 queries for the long sequences; QB = 1 for sequences of <= 64).  The kernel is bound by vector-instruction issue, not by
+// the MFMAs (the 32-key, 64-query form ran ~0.39 vector instructions per (query, key) pair: 304 us for 60 x 8 sequences of 801), so the
+// structure minimises those: the K / V staging and K's rotation are shared by twice the queries, a chunk is 64 keys (half the barriers
+// and accumulator rescales per key), the scores are kept in the log2 domain (scale log2(e) folded into Q: one v_exp_f32 per score,
+// no multiply), keys beyond the sequence are masked only in the one chunk that has them, and V^T is scattered into LDS as 4-byte
+// pairs of keys.
+template <int QB>
 __global__ void __launch_bounds__(kHThreads)
 nn_attn_h_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out, int L, int heads, int64_t seq_stride, int64_t row_stride,
                  int64_t o_seq_stride, int64_t o_row_stride, float scale, const float* __restrict__ rot, const float* __restrict__ gates,
                  int64_t g_seq_stride, int64_t g_row_stride) {
-    _Float16* Ks = reinterpret_cast<_Float16*>(alsep_smem);                  // [32 keys][64 d], swizzled groups
-    _Float16* Vt = Ks + kAtKc * kAtD;                                         // [64 d][36]
+    _Float16* Ks = reinterpret_cast<_Float16*>(alsep_smem);                  // [64 keys][64 d], swizzled 16-byte groups
+    _Float16* Vt = Ks + kAtKc * kAtD;                                         // [64 d][72]: V transposed, rows padded by 8
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     // 1-D grid over (sequence, head, query block), query block fastest, dealt to the XCDs in contiguous runs: the workgroups that read the
     // same keys / values share one L2
-    const int qblocks = (L + 63) / 64;
+    constexpr int QW = 64 * QB;                                               // queries per workgroup
+    const int qblocks = (L + QW - 1) / QW;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int qb = wg % qblocks, head = (wg / qblocks) % heads, seq = wg / (qblocks * heads);
     const int inner = heads * kAtD;
     const _Float16* base = qkv + seq * seq_stride + head * kAtD;
     const _Float16* kbase = base + inner;
     const _Float16* vbase = base + 2 * inner;
-    const int q = qb * 64 + wave * 16 + l15;                                  // this lane's query (the MFMA column)
-    const bool qok = q < L;
-    // Q fragments: B operand of S^T = K Q^T: lane (col = query l15, quarter lq) holds Q[q][32 s + 8 lq .. + 7], rotated and scaled
-    h16x8 qf[2];
+    // Q fragments: B operand of S^T = K Q^T: lane (col = query l15, quarter lq) holds Q[q][32 s + 8 lq .. + 7], rotated, times
+    // scale log2(e)
+    const float qs = scale * 1.44269504088896340736f;
+    h16x8 qf[QB][2];
+    int qrow[QB];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
-        if (qok) {
-            h8_to_f(*reinterpret_cast<const h16x8*>(base + (int64_t)q * row_stride + 32 * s + 8 * lq), a, b);
-            if (rot) rotate8(a, b, rot + ((int64_t)q * (kAtD / 2) + 16 * s + 4 * lq) * 2);
+    for (int b = 0; b < QB; ++b) {
+        qrow[b] = qb * QW + (wave * QB + b) * 16 + l15;                       // this lane's query of block b (the MFMA column)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, c = a;
+            if (qrow[b] < L) {
+                h8_to_f(*reinterpret_cast<const h16x8*>(base + (int64_t)qrow[b] * row_stride + 32 * s2 + 8 * lq), a, c);
+                if (rot) rotate8(a, c, rot + ((int64_t)qrow[b] * (kAtD / 2) + 16 * s2 + 4 * lq) * 2);
+            }
+            qf[b][s2] = to_h8(a * qs, c * qs);
         }
-        qf[s] = to_h8(a * scale, b * scale);
     }
-    f32x4 o[4];
+    f32x4 o[QB][4];
+    float mrun[QB], lsum[QB];                                                 // running max (shared by a query's 4 lanes), this lane's partial sum
 #pragma unroll
-    for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float mrun = -3.0e38f, lsum = 0.f;                                        // running max (shared by the query's 4 lanes), this lane's partial sum
-    const int skey = tid >> 3, sgrp = tid & 7;                                // staging duty: key skey, 8 d values from 8 sgrp
-    h16x8 zh;
+    for (int b = 0; b < QB; ++b) {
+        mrun[b] = -3.0e38f;
+        lsum[b] = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) zh[e] = (_Float16)0.f;
+        for (int d = 0; d < 4; ++d) o[b][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // staging duty per chunk.  K: keys kkey and kkey + 32, 8 d values from 8 kgrp (8 lanes = one 128-byte row: coalesced).  V: the key
+    // PAIR (2 vpair, 2 vpair + 1), 8 d values from 8 vgrp, one 32-lane half per d group: its eight 4-byte stores (one per d, two keys
+    // each) then fall into 32 different banks
+    const int kkey = tid >> 3, kgrp = tid & 7;
+    const int vpair = tid & 31, vgrp = tid >> 5;
     for (int k0 = 0; k0 < L; k0 += kAtKc) {
-        const bool kin = k0 + skey < L;
-        const int64_t off = (int64_t)(kin ? k0 + skey : 0) * row_stride + 8 * sgrp;   // clamped: the loads are unconditional
-        h16x8 kv = *reinterpret_cast<const h16x8*>(kbase + off);
-        h16x8 vv = *reinterpret_cast<const h16x8*>(vbase + off);
-        if (rot) {
-            f32x4 ka, kb;
-            h8_to_f(kv, ka, kb);
-            rotate8(ka, kb, rot + ((int64_t)(kin ? k0 + skey : 0) * (kAtD / 2) + 4 * sgrp) * 2);
-            kv = to_h8(ka, kb);
+        h16x8 kv[2], vv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kr = k0 + kkey + 32 * h, krc = kr < L ? kr : L - 1;     // clamped: the loads are unconditional; masked below
+            kv[h] = *reinterpret_cast<const h16x8*>(kbase + (int64_t)krc * row_stride + 8 * kgrp);
+            const int vr = k0 + 2 * vpair + h, vrc = vr < L ? vr : L - 1;
+            vv[h] = *reinterpret_cast<const h16x8*>(vbase + (int64_t)vrc * row_stride + 8 * vgrp);
+            if (rot) {
+                f32x4 ka, kb;
+                h8_to_f(kv[h], ka, kb);
+                rotate8(ka, kb, rot + ((int64_t)krc * (kAtD / 2) + 4 * kgrp) * 2);
+                kv[h] = to_h8(ka, kb);
+            }
         }
-        if (!kin) { kv = zh; vv = zh; }
         __syncthreads();                                                      // every wave is done with the previous chunk
-        *reinterpret_cast<h16x8*>(Ks + skey * kAtD + 8 * (sgrp ^ (skey & 7))) = kv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) Vt[(8 * sgrp + e) * kAtVld + skey] = vv[e];
+        for (int h = 0; h < 2; ++h) {
+            const int row = kkey + 32 * h;
+            *reinterpret_cast<h16x8*>(Ks + row * kAtD + 8 * (kgrp ^ (row & 7))) = kv[h];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+            h16x2 pr;
+            pr[0] = vv[0][e];
+            pr[1] = vv[1][e];
+            *reinterpret_cast<h16x2*>(Vt + (8 * vgrp + e) * kAtVld + 2 * vpair) = pr;
+        }
         __syncthreads();
-        // S^T blocks: keys 16 kb + (4 lq + r), query l15
-        f32x4 s[2];
+        // S^T blocks (log2 domain): keys 16 kb + (4 lq + r), query l15 of block b; the K fragments serve both query blocks
+        f32x4 sc[QB][4];
 #pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2) {
-            s[kb2] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int krow = 16 * kb2 + l15;
+        for (int kb = 0; kb < 4; ++kb) {
+            const int krow = 16 * kb + l15;
+            h16x8 kf[2];
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const h16x8 kf = *reinterpret_cast<const h16x8*>(Ks + krow * kAtD + 8 * ((4 * st + lq) ^ (krow & 7)));
-                s[kb2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[st], s[kb2], 0, 0, 0);
+            for (int st = 0; st < 2; ++st) kf[st] = *reinterpret_cast<const h16x8*>(Ks + krow * kAtD + 8 * ((4 * st + lq) ^ (krow & 7)));
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+                sc[b][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[0], qf[b][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                sc[b][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[1], qf[b][1], sc[b][kb], 0, 0, 0);
             }
         }
-        float cmax = -3.0e38f;
+        if (k0 + kAtKc > L) {                                                 // the last chunk only: keys beyond the sequence
 #pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2)
+            for (int b = 0; b < QB; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (k0 + 16 * kb2 + 4 * lq + r >= L) s[kb2][r] = -3.0e38f;   // keys beyond the sequence
-                cmax = fmaxf(cmax, s[kb2][r]);
-            }
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-        const float mnew = fmaxf(mrun, cmax);
-        const float corr = __expf(mrun - mnew);
-        mrun = mnew;
-        h16x8 pf;
-        float psum = 0.f;
+                for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = s[kb2][r] > -1.0e38f ? __expf(s[kb2][r] - mnew) : 0.f;
-                psum += pv;
-                pf[4 * kb2 + r] = (_Float16)pv;
-            }
-        lsum = lsum * corr + psum;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            o[d] *= corr;
-            // A operand: V^T rows d = 16 d + l15, contraction index e of quarter lq = key 16 (e / 4) + 4 lq + e % 4
-            const _Float16* vr = Vt + (16 * d + l15) * kAtVld + 4 * lq;
-            const h16x4 v0 = *reinterpret_cast<const h16x4*>(vr), v1 = *reinterpret_cast<const h16x4*>(vr + 16);
-            h16x8 vf;
-            vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
-            vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
-            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[d], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + 16 * kb + 4 * lq + r >= L) sc[b][kb][r] = -3.0e38f;
         }
+        h16x8 pf[QB][2];
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            float cmax = fmaxf(fmaxf(sc[b][0][0], sc[b][0][1]), fmaxf(sc[b][0][2], sc[b][0][3]));
+#pragma unroll
+            for (int kb = 1; kb < 4; ++kb) cmax = fmaxf(cmax, fmaxf(fmaxf(sc[b][kb][0], sc[b][kb][1]), fmaxf(sc[b][kb][2], sc[b][kb][3])));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 16));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+            const float mnew = fmaxf(mrun[b], cmax);
+            const float corr = __builtin_amdgcn_exp2f(mrun[b] - mnew);
+            mrun[b] = mnew;
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(sc[b][kb][r] - mnew);   // a masked key: exp2(-3e38) = 0
+                    psum += pv;
+                    pf[b][kb >> 1][4 * (kb & 1) + r] = (_Float16)pv;
+                }
+            lsum[b] = lsum[b] * corr + psum;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o[b][d] *= corr;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                // A operand: V^T rows d = 16 d + l15, contraction index e of quarter lq = key 32 ks + 16 (e / 4) + 4 lq + e % 4
+                const _Float16* vr = Vt + (16 * d + l15) * kAtVld + 32 * ks + 4 * lq;
+                const h16x4 v0 = *reinterpret_cast<const h16x4*>(vr), v1 = *reinterpret_cast<const h16x4*>(vr + 16);
+                h16x8 vf;
+                vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+                vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+#pragma unroll
+                for (int b = 0; b < QB; ++b) o[b][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[b][ks], o[b][d], 0, 0, 0);
+            }
     }
-    lsum += __shfl_xor(lsum, 16);
-    lsum += __shfl_xor(lsum, 32);
-    if (qok) {
-        float inv = 1.f / lsum;
-        if (gates) inv *= 1.f / (1.f + expf(-gates[seq * g_seq_stride + (int64_t)q * g_row_stride + head]));    // out * sigmoid(gate[row][head])
-        _Float16* dst = out + seq * o_seq_stride + (int64_t)q * o_row_stride + head * kAtD;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {                                         // O^T rows d = 16 d + 4 lq + r
-            h16x4 hv;
-            hv[0] = (_Float16)(o[d][0] * inv); hv[1] = (_Float16)(o[d][1] * inv); hv[2] = (_Float16)(o[d][2] * inv); hv[3] = (_Float16)(o[d][3] * inv);
-            *reinterpret_cast<h16x4*>(dst + 16 * d + 4 * lq) = hv;
+    for (int b = 0; b < QB; ++b) {
+        float ls = lsum[b];
+        ls += __shfl_xor(ls, 16);
+        ls += __shfl_xor(ls, 32);
+        const int q = qrow[b];
+        if (q < L) {
+            float inv = 1.f / ls;
+            if (gates) inv *= 1.f / (1.f + expf(-gates[seq * g_seq_stride + (int64_t)q * g_row_stride + head]));    // out * sigmoid(gate[row][head])
+            _Float16* dst = out + seq * o_seq_stride + (int64_t)q * o_row_stride + head * kAtD;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {                                     // O^T rows d = 16 d + 4 lq + r
+                h16x4 hv;
+                hv[0] = (_Float16)(o[b][d][0] * inv); hv[1] = (_Float16)(o[b][d][1] * inv);
+                hv[2] = (_Float16)(o[b][d][2] * inv); hv[3] = (_Float16)(o[b][d][3] * inv);
+                *reinterpret_cast<h16x4*>(dst + 16 * d + 4 * lq) = hv;
+            }
         }
     }
 }
@@ -689,6 +751,44 @@ extern "C" int alsep_nn_gemm_f16(alsep_ctx* ctx, const void* A, int64_t lda, int
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_gemm_f16: operands do not meet the alignment this kernel needs");
     if ((int64_t)M * lda >= ((int64_t)1 << 31) || (int64_t)N * ldw >= ((int64_t)1 << 31))
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_gemm_f16: an operand of 2^31 or more elements per batch (32-bit row offsets)");
+    // Large M without per-batch ragged N: the persistent kernel (one workgroup per CU).  Its residual / bias requests carry 32-bit byte
+    // offsets; an activation together with a residual stays with the tile-per-workgroup kernel (no caller has one).
+    if (M >= 2048 && N >= 64 && !n_per_batch && !(R && act != 0) && (!R || (int64_t)M * ldr < ((int64_t)1 << 30)) ) {
+        if (K % h2::BK && !ctx->zero_page) {
+            ALSEP_HIP(ctx, hipMalloc(&ctx->zero_page, 256));
+            ALSEP_HIP(ctx, hipMemsetAsync(ctx->zero_page, 0, 256, ctx->stream));
+        }
+        h2::Args q{(const _Float16*)A, lda, sa_b, (const _Float16*)W, ldw, sw_b, C, ldc, sc_b, bias, bias_b, R, ldr, sr_b, M, N, K, alpha,
+                   (const _Float16*)ctx->zero_page, (int)ceil_div64(M, h2::BM), (int)ceil_div64(N, h2::BN), 0};
+        const int64_t nt = (int64_t)q.tiles_m * q.tiles_n * nb;
+        if (nt > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_gemm_f16: too many tiles");
+        q.ntiles = (int)nt;
+        int g = device_cu_count(ctx) / 8 * 8;
+        if (g < 8) g = 8;                               // a multiple of the 8 XCDs; fewer workgroups than tiles never idle a whole XCD
+        if (nt < g) g = (int)((nt + 7) / 8 * 8);
+        ProfScope prof(ctx, ALSEP_PROF_NN_GEMM_H);
+        prof.work(2.0 * nb * (double)M * N * K, (double)nb * (2.0 * M * K + 2.0 * N * K + ((c_f16 ? 2.0 : 4.0) + (R ? 4.0 : 0.0)) * M * N));
+#define ALSEP_H2_GO(ACT_, CF_, RES_)                                                                                                        \
+    do {                                                                                                                                    \
+        if (K % h2::BK) {                                                                                                                   \
+            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)nn_gemm_h2_kernel<ACT_, CF_, RES_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h2::kLds)); \
+            hipLaunchKernelGGL((nn_gemm_h2_kernel<ACT_, CF_, RES_, true>), dim3((unsigned)g), dim3(h2::kThreads), h2::kLds, ctx->stream, q);   \
+        } else {                                                                                                                            \
+            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)nn_gemm_h2_kernel<ACT_, CF_, RES_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h2::kLds)); \
+            hipLaunchKernelGGL((nn_gemm_h2_kernel<ACT_, CF_, RES_, false>), dim3((unsigned)g), dim3(h2::kThreads), h2::kLds, ctx->stream, q);  \
+        }                                                                                                                                   \
+    } while (0)
+        if (R) {
+            if (c_f16) ALSEP_H2_GO(0, true, true); else ALSEP_H2_GO(0, false, true);
+        } else if (c_f16) {
+            if (act == 3) ALSEP_H2_GO(3, true, false); else if (act == 5) ALSEP_H2_GO(5, true, false); else ALSEP_H2_GO(0, true, false);
+        } else {
+            if (act == 3) ALSEP_H2_GO(3, false, false); else if (act == 5) ALSEP_H2_GO(5, false, false); else ALSEP_H2_GO(0, false, false);
+        }
+#undef ALSEP_H2_GO
+        ALSEP_LAUNCH_CHECK(ctx, "nn_gemm_h2_kernel");
+        return ALSEP_OK;
+    }
     GemmHArgs p{(const _Float16*)A, lda, sa_b, (const _Float16*)W, ldw, sw_b, C, ldc, sc_b, bias, bias_b, R, ldr, sr_b, M, N, K, alpha, n_per_batch};
     const int64_t n_wg = ceil_div64(N, kHgBN) * ceil_div64(M, kHgBM) * nb;
     if (n_wg > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_gemm_f16: too many tiles");
@@ -810,14 +910,19 @@ extern "C" int alsep_nn_attention_f16(alsep_ctx* ctx, const void* qkv, void* out
     if (dim_head != kAtD) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_attention_f16: head dimension %d (64 is implemented)", dim_head);
     if (seq_stride % 8 || row_stride % 8 || o_seq_stride % 4 || o_row_stride % 4 || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7))
         return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_attention_f16: strides / bases must be multiples of 16 (qkv) / 8 (out) bytes");
-    const int64_t n_wg = ceil_div64(L, 64) * heads * n_seq;
+    const int QB = L > 64 ? 2 : 1;                               // query blocks of 16 per wave: 128 or 64 queries per workgroup
+    const int64_t n_wg = ceil_div64(L, 64 * QB) * heads * n_seq;
     if (n_wg > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_attention_f16: too many workgroups");
     const dim3 grid((unsigned)n_wg);
     ProfScope prof(ctx, ALSEP_PROF_NN_ATTN_H);
     prof.work(4.0 * n_seq * heads * (double)L * L * kAtD, 2.0 * n_seq * heads * (double)L * kAtD * 4.0);
     if (rot_table && ((uintptr_t)rot_table & 15)) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_attention_f16: rotary table must be 16-byte aligned");
-    hipLaunchKernelGGL(nn_attn_h_kernel, grid, dim3(kHThreads), kAtLds, ctx->stream, (const _Float16*)qkv, (_Float16*)out, L, heads, seq_stride,
-                       row_stride, o_seq_stride, o_row_stride, scale, rot_table, gates, g_seq_stride, g_row_stride);
+    if (QB == 2)
+        hipLaunchKernelGGL(nn_attn_h_kernel<2>, grid, dim3(kHThreads), kAtLds, ctx->stream, (const _Float16*)qkv, (_Float16*)out, L, heads, seq_stride,
+                           row_stride, o_seq_stride, o_row_stride, scale, rot_table, gates, g_seq_stride, g_row_stride);
+    else
+        hipLaunchKernelGGL(nn_attn_h_kernel<1>, grid, dim3(kHThreads), kAtLds, ctx->stream, (const _Float16*)qkv, (_Float16*)out, L, heads, seq_stride,
+                           row_stride, o_seq_stride, o_row_stride, scale, rot_table, gates, g_seq_stride, g_row_stride);
     ALSEP_LAUNCH_CHECK(ctx, "nn_attn_h_kernel");
     return ALSEP_OK;
 }

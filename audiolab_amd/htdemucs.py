@@ -554,7 +554,9 @@ class DemucsRunner:
             graphs = os.environ.get("ALSEP_DEMUCS_GRAPH", "0") != "0"
         self.graphs = bool(graphs) and self.ctx.device.type == "cuda"
         self._lane_nets: List[tuple] = []                      # [(HTDemucs view, torch stream)], built on first use
-        self._graphs: Dict[int, tuple] = {}                    # lane index -> (graph, static input, static output)
+        self._graphs: Dict[int, list] = {}                     # lane index -> [(graph, static input, static output)] x graphs_per_lane
+        self._graph_turn: Dict[int, int] = {}
+        self.graphs_per_lane = max(1, int(os.environ.get("ALSEP_RUNNER_GRAPHS_PER_LANE", "2")))
 
     def _lanes(self):
         if not self._lane_nets:
@@ -570,16 +572,19 @@ class DemucsRunner:
         """the network on one [2, seg] segment on lane k's stream: eagerly, or -- from the lane's second unit on -- as a graph replay"""
         if not self.graphs:
             return lane_net.forward(chunk)
-        if k not in self._graphs:
+        slots = self._graphs.setdefault(k, [])                  # two captures per lane, replayed in turn (roformer.RoformerRunner._forward_chunk)
+        if len(slots) < self.graphs_per_lane:
             y = lane_net.forward(chunk)                         # eager first: plans, tables, workspaces outside a capture
             st.synchronize()
             static_in = chunk.clone()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=st):
                 static_out = lane_net.forward(static_in)
-            self._graphs[k] = (g, static_in, static_out)
+            slots.append((g, static_in, static_out))
             return y
-        g, static_in, static_out = self._graphs[k]
+        turn = self._graph_turn.get(k, 0)
+        self._graph_turn[k] = (turn + 1) % len(slots)
+        g, static_in, static_out = slots[turn]
         static_in.copy_(chunk)
         g.replay()
         return static_out

@@ -567,7 +567,9 @@ class RoformerRunner:
             lanes = 1
         self.lanes = max(1, int(lanes)) if gpu else 1
         self._lane_nets: List[tuple] = []
-        self._graphs: Dict[int, tuple] = {}                    # lane index -> (graph, static input, static output)
+        self._graphs: Dict[int, list] = {}                     # lane index -> [(graph, static input, static output)] x graphs_per_lane
+        self._graph_turn: Dict[int, int] = {}
+        self.graphs_per_lane = max(1, int(os.environ.get("ALSEP_RUNNER_GRAPHS_PER_LANE", "2")))
 
     def _lanes(self):
         if not self._lane_nets:
@@ -587,16 +589,23 @@ class RoformerRunner:
         graph captured on that stream"""
         if not self.graphs:
             return lane_net.forward(chunk)
-        if k not in self._graphs:
+        # TWO captures per lane, replayed in turn: a graph launched again while its previous launch is still running makes the host wait
+        # for that launch first (ROCm 7.2), so with one capture the GPU idles for the host's per-chunk work (input copy, ~110 packets of
+        # the launch itself: 3.8 of 13.2 ms per Mel-Band chunk, profiles/r04_mel_half_trace_gaps.txt); with two, chunk n + 1 is queued
+        # while chunk n runs.  Same stream: the replays still execute one after the other.
+        slots = self._graphs.setdefault(k, [])
+        if len(slots) < self.graphs_per_lane:
             y = lane_net.forward(chunk)                         # eager first: builds plans, tables and kernel attributes outside a capture
             st.synchronize()
             static_in = chunk.clone()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=st):
                 static_out = lane_net.forward(static_in)
-            self._graphs[k] = (g, static_in, static_out)
+            slots.append((g, static_in, static_out))
             return y
-        g, static_in, static_out = self._graphs[k]
+        turn = self._graph_turn.get(k, 0)
+        self._graph_turn[k] = (turn + 1) % len(slots)
+        g, static_in, static_out = slots[turn]
         static_in.copy_(chunk)
         g.replay()
         return static_out

@@ -23,6 +23,9 @@ for g in (2048, 8192):
     run(4, g, "read, grid-stride 16 B/lane")
 for g in (2048, 8192):
     run(5, g, "copy, grid-stride 16 B/lane (read + write)")
+for g in (512, 2048, 106496):
+    run(6, g, "fill, m0 epilogue shape (64 B + 32 B per pixel)")
+    run(7, g, "fill, m0 tile rows as linear 16 B/lane stores")
 import time
 torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(10): a.zero_()

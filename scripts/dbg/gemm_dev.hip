@@ -1,0 +1,125 @@
+// Development harness of csrc/nn_gemm_h2.h: correctness against a one-thread-per-output reference and launch time, standalone.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I audiolab_amd/csrc scripts/dbg/gemm_dev.hip -o scripts/dbg/gemm_dev
+#include "nn_gemm_h2.h"
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+template <int ACT, bool CF16, bool RES, bool RAGK>
+__global__ void __launch_bounds__(h2::kThreads, 2) gemm_h2_kernel(h2::Args p) {
+    h2::gemm_body<ACT, CF16, RES, RAGK>(p, [](float t) { return t; });
+}
+template <bool CF16, bool RES>
+__global__ void __launch_bounds__(h2::kThreads, 2) gemm_h2_stamp_kernel(h2::Args p, unsigned long long* stamps) {
+    h2::gemm_body<0, CF16, RES, false, true>(p, [](float t) { return t; }, stamps);
+}
+__global__ void ref_kernel(const _Float16* A, const _Float16* W, float* C, const float* bias, const float* R, int M, int N, int K, int64_t sa, int64_t sw,
+                           int64_t sc) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int bz = blockIdx.y;
+    if (i >= (int64_t)M * N) return;
+    const int m = (int)(i / N), n = (int)(i % N);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += (float)A[bz * sa + (int64_t)m * K + k] * (float)W[bz * sw + (int64_t)n * K + k];
+    C[bz * sc + i] = s + (bias ? bias[bz * N + n] : 0.f) + (R ? R[bz * sc + i] : 0.f);
+}
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <bool CF16, bool RES, bool RAGK>
+static void launch(const h2::Args& a, int grid) {
+    auto k = gemm_h2_kernel<0, CF16, RES, RAGK>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h2::kLds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(h2::kThreads), h2::kLds, 0, a);
+}
+
+static void run(int M, int N, int K, int nb, bool c16, bool res, int cus) {
+    const size_t na = (size_t)nb * M * K, nw = (size_t)nb * N * K, nc = (size_t)nb * M * N;
+    std::vector<_Float16> ha(na), hw(nw);
+    std::vector<float> hb((size_t)nb * N), hr(res ? nc : 1);
+    unsigned st = 12345u + M + 7 * N + 13 * K;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.f - 1.f; };
+    for (auto& v : ha) v = (_Float16)rnd();
+    for (auto& v : hw) v = (_Float16)rnd();
+    for (auto& v : hb) v = rnd();
+    for (auto& v : hr) v = rnd();
+    _Float16 *dA, *dW, *dZ; void* dC; float *dB, *dR = nullptr, *dRef;
+    CK(hipMalloc(&dA, na * 2)); CK(hipMalloc(&dW, nw * 2)); CK(hipMalloc(&dC, nc * 4)); CK(hipMalloc(&dB, hb.size() * 4)); CK(hipMalloc(&dRef, nc * 4));
+    CK(hipMalloc(&dZ, 256)); CK(hipMemset(dZ, 0, 256));
+    if (res) { CK(hipMalloc(&dR, nc * 4)); CK(hipMemcpy(dR, hr.data(), nc * 4, hipMemcpyHostToDevice)); }
+    CK(hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hw.data(), nw * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dC, 0xff, nc * 4));
+    h2::Args a{};
+    a.A = dA; a.lda = K; a.sa_b = (int64_t)M * K; a.B = dW; a.ldb = K; a.sb_b = (int64_t)N * K; a.C = dC; a.ldc = N; a.sc_b = (int64_t)M * N;
+    a.bias = dB; a.bias_b = N; a.R = dR; a.ldr = N; a.sr_b = (int64_t)M * N; a.M = M; a.N = N; a.K = K; a.alpha = 1.f; a.zero_page = dZ;
+    a.tiles_m = (M + h2::BM - 1) / h2::BM; a.tiles_n = (N + h2::BN - 1) / h2::BN; a.ntiles = nb * a.tiles_m * a.tiles_n;
+    int grid = cus; while (grid > 8 && grid / 8 * 8 > a.ntiles) grid -= 8;
+    if (grid > a.ntiles) grid = (a.ntiles + 7) / 8 * 8;
+    const bool rag = K % h2::BK != 0;
+    auto go = [&]() {
+        if (c16 && res) { if (rag) launch<true, true, true>(a, grid); else launch<true, true, false>(a, grid); }
+        else if (c16) { if (rag) launch<true, false, true>(a, grid); else launch<true, false, false>(a, grid); }
+        else if (res) { if (rag) launch<false, true, true>(a, grid); else launch<false, true, false>(a, grid); }
+        else { if (rag) launch<false, false, true>(a, grid); else launch<false, false, false>(a, grid); }
+    };
+    go();
+    CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(ref_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256), nb), dim3(256), 0, 0, dA, dW, dRef, dB, dR, M, N, K, (int64_t)M * K, (int64_t)N * K,
+                       (int64_t)M * N);
+    CK(hipDeviceSynchronize());
+    std::vector<float> ref(nc);
+    CK(hipMemcpy(ref.data(), dRef, nc * 4, hipMemcpyDeviceToHost));
+    double worst = 0, peak = 0;
+    if (c16) {
+        std::vector<_Float16> got(nc);
+        CK(hipMemcpy(got.data(), dC, nc * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < nc; ++i) { worst = fmax(worst, fabs((double)got[i] - ref[i])); peak = fmax(peak, fabs(ref[i])); }
+    } else {
+        std::vector<float> got(nc);
+        CK(hipMemcpy(got.data(), dC, nc * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < nc; ++i) { worst = fmax(worst, fabs((double)got[i] - ref[i])); peak = fmax(peak, fabs(ref[i])); }
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) go();
+    CK(hipEventRecord(e0, 0));
+    const int iters = 20;
+    for (int i = 0; i < iters; ++i) go();
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1000.0 / iters, fl = 2.0 * nb * M * N * (double)K;
+    if (!rag) {                                       // phase stamps (s_memtime ticks at 100 MHz): mean over waves, in us
+        unsigned long long* dS; CK(hipMalloc(&dS, (size_t)grid * 64 * 8)); CK(hipMemset(dS, 0, (size_t)grid * 64 * 8));
+        auto launch_s = [&](auto kern) {
+            CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h2::kLds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(h2::kThreads), h2::kLds, 0, a, dS);
+        };
+        if (c16 && res) launch_s(gemm_h2_stamp_kernel<true, true>); else if (c16) launch_s(gemm_h2_stamp_kernel<true, false>);
+        else if (res) launch_s(gemm_h2_stamp_kernel<false, true>); else launch_s(gemm_h2_stamp_kernel<false, false>);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hs((size_t)grid * 64);
+        CK(hipMemcpy(hs.data(), dS, hs.size() * 8, hipMemcpyDeviceToHost));
+        double sum[8] = {0}; int nw = 0;
+        for (int w = 0; w < grid * 8; ++w) { if (hs[(size_t)w * 8 + 7] == 0) continue; ++nw; for (int k = 0; k < 8; ++k) sum[k] += (double)hs[(size_t)w * 8 + k]; }
+        printf("    stamps (us per wave, 100 MHz ticks): dma-wait %.1f  barrier %.1f  issue %.1f  mfma %.1f  epi-wait %.1f  epilogue %.1f  | total %.1f  slices %.0f\n",
+               sum[0] / nw / 100, sum[1] / nw / 100, sum[2] / nw / 100, sum[3] / nw / 100, sum[4] / nw / 100, sum[5] / nw / 100, sum[6] / nw / 100, sum[7] / nw);
+        hipFree(dS);
+    }
+    printf("M %6d N %5d K %5d nb %3d %s%s grid %4d: %8.1f us %7.1f TFLOP/s   max|err| %.3g (peak %.3g)%s\n", M, N, K, nb, c16 ? "f16" : "f32", res ? "+res" : "    ", grid,
+           us, fl / us / 1e6, worst, peak, worst > (c16 ? 2e-3 : 2e-5) * (peak + 1) ? "   <-- WRONG" : "");
+    fflush(stdout);
+    hipFree(dA); hipFree(dW); hipFree(dC); hipFree(dB); hipFree(dRef); hipFree(dZ); if (dR) hipFree(dR);
+}
+
+int main(int argc, char** argv) {
+    int cus = 256;
+    if (argc > 1) cus = atoi(argv[1]);
+    run(1000, 256, 128, 1, false, false, cus);       // small: ragged M
+    run(777, 136, 200, 2, true, true, cus);          // ragged everything, batched
+    run(48060, 1536, 384, 1, true, false, cus);
+    run(48060, 384, 1536, 1, false, true, cus);
+    run(48060, 384, 512, 1, false, true, cus);
+    run(801, 1536, 384, 60, true, false, cus);
+    run(801, 1040, 1536, 60, false, false, cus);
+    run(801, 384, 520, 60, false, false, cus);
+    return 0;
+}

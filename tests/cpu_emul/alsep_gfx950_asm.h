@@ -40,6 +40,10 @@ static inline void global_load_async_bf16x8(bf16x8& dst, const void* sbase, unsi
     dst = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(sbase) + voff + OFF);
 }
 
+static inline void global_load_async_f32x4(f32x4& dst, const void* sbase, unsigned voff) {
+    dst = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(sbase) + voff);
+}
+
 template <int OFF>
 static inline void lds_read_async_b128(bf16x8& dst, const bf16_t* lds_ptr) {
     std::memcpy(&dst, reinterpret_cast<const char*>(lds_ptr) + OFF, 16);

@@ -91,6 +91,8 @@ void wave_sync();
 static inline void __syncthreads() { emul::sync_block(); }
 // device math the host libm lacks
 #define __expf(x) std::exp((float)(x))   /* glibc declares, but does not export, a symbol of this name */
+static inline float __builtin_amdgcn_exp2f(float x) { return std::exp2(x); }   /* v_exp_f32 */
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.f / x; }   /* v_rcp_f32: 1 ulp on the device */
 static inline void sincospi(double x, double* s, double* c) { *s = std::sin(M_PI * x); *c = std::cos(M_PI * x); }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                       \

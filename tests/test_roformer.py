@@ -159,6 +159,44 @@ def _rel(a, b):
     return float(np.sqrt((d ** 2).sum() / max((np.asarray(b, dtype=np.float64) ** 2).sum(), 1e-300)))
 
 
+@pytest.mark.parametrize("M,N,K,nb,act,res,c16", [(2100, 136, 200, 1, 3, False, True), (2049, 384, 64, 1, 0, True, False), (2304, 72, 128, 2, 5, False, False),
+                                                  (2050, 200, 72, 3, 0, True, True)])
+def test_half_gemm_large_m_persistent_kernel(dev, M, N, K, nb, act, res, c16):
+    """the large-M form of alsep_nn_gemm_f16 (csrc/nn_gemm_h2.h: persistent 256 x 128 tiles, LDS-DMA ring across tile ends, epilogue operands
+    requested a slice early): same contract as the tile-per-workgroup kernel -- ragged M / N / K tails, batches, bias, activation, float32
+    residual, half or float32 output, padded rows -- against float64 on the same operands"""
+    from audiolab_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    lda, ldc = K + 8, N + 8
+    a = torch.randn(nb, M, lda, generator=g).half()
+    w = (torch.randn(nb, N, K, generator=g) / K ** 0.5).half()
+    bias = torch.randn(nb, N, generator=g)
+    r = torch.randn(nb, M, ldc, generator=g)
+    ad, wd, bd, rd = on(dev, a), on(dev, w), on(dev, bias), on(dev, r)
+    c = torch.zeros((nb, M, ldc), dtype=torch.float16 if c16 else torch.float32, device=dev.device)
+    dev.launch_counts_reset()
+    dev.check(dev.lib.alsep_nn_gemm_f16(dev.handle, _lib.ptr(ad), lda, M * lda, _lib.ptr(wd), K, N * K, _lib.ptr(c), 1 if c16 else 0, ldc, M * ldc,
+                                        _lib.ptr(bd), N, _lib.ptr(rd) if res else None, ldc, M * ldc, nb, M, N, K, 0.5, act, None), "alsep_nn_gemm_f16")
+    assert dev.launch_count("nn_gemm_h2_kernel") == 1 and dev.launch_count("nn_gemm_hh_kernel") == 0
+    want = 0.5 * torch.einsum("bmk,bnk->bmn", a[:, :, :K].double(), w.double()) + bias.double()[:, None, :]
+    if act == 3:
+        want = torch.nn.functional.gelu(want)
+    elif act == 5:
+        want = torch.tanh(want)
+    if res:
+        want = want + r[:, :, :N].double()
+    got = host(c).astype(np.float64)
+    tol = (1e-3 if c16 else 2e-5) * max(1.0, float(want.abs().max()))
+    assert np.max(np.abs(got[:, :, :N] - want.numpy())) < tol
+    assert np.all(got[:, :, N:] == 0)                          # nothing written beyond the N columns
+    # the same product without bias (the attention output projection has none)
+    c.zero_()
+    dev.check(dev.lib.alsep_nn_gemm_f16(dev.handle, _lib.ptr(ad), lda, M * lda, _lib.ptr(wd), K, N * K, _lib.ptr(c), 1 if c16 else 0, ldc, M * ldc,
+                                        None, 0, None, 0, 0, nb, M, N, K, 1.0, 0, None), "alsep_nn_gemm_f16")
+    want = torch.einsum("bmk,bnk->bmn", a[:, :, :K].double(), w.double())
+    assert np.max(np.abs(host(c).astype(np.float64)[:, :, :N] - want.numpy())) < (1e-3 if c16 else 2e-5) * max(1.0, float(want.abs().max()))
+
+
 @pytest.mark.parametrize("M,N,K,act,res,c16", [(200, 132, 40, 0, False, False), (130, 256, 64, 3, True, False), (64, 4, 8, 5, False, True),
                                                (257, 384, 1536, 0, True, False), (300, 136, 200, 3, False, True)])
 def test_half_gemm_vs_float64(dev, M, N, K, act, res, c16):
@@ -228,7 +266,7 @@ def test_rmsnorm_half_out(dev):
     assert float((y.cpu().double() - want).abs().max()) < 1.5e-3 * float(want.abs().max())
 
 
-@pytest.mark.parametrize("over_time,L,n_seq", [(True, 70, 3), (False, 33, 5), (True, 64, 1), (False, 1, 2)])
+@pytest.mark.parametrize("over_time,L,n_seq", [(True, 70, 3), (False, 33, 5), (True, 64, 1), (False, 1, 2), (True, 301, 2)])
 def test_half_attention_vs_float64(dev, over_time, L, n_seq):
     """alsep_nn_attention_f16 on a packed IEEE-half q | k | v block in both stride patterns of the Roformer (sequences along time / along
     bands), with and without the rotary embedding on load and the head gates, against the same arithmetic in float64: f16 q d^-1/2, k, v
