@@ -25,10 +25,18 @@ namespace h2 {
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kThreads = 512, BM = 256, BN = 128, BK = 64, STAGES = 3;
-constexpr int kStageHalves = (BM + BN) * BK;                         // 24 576 halves = 48 KB
-constexpr size_t kLds = (size_t)STAGES * kStageHalves * sizeof(_Float16);
-constexpr int kDmaPerWave = (BM + BN) * BK * 2 / 1024 / 8;           // 6 LDS-DMA instructions per wave and stage (4 of A, 2 of W)
+constexpr int BN = 128, BK = 64, STAGES = 3;
+// Tile height BM = 256 (8 waves as 4 x 2) or 192 (6 waves as 3 x 2): every wave owns 64 x 64 of the tile either way.  The launcher takes
+// the height whose tile count fills the 256 workgroups' rounds better: 48 060 rows x 384 columns are 564 tiles of 256 (2.2 per workgroup:
+// three rounds, the third a fifth full) but 753 tiles of 192 (2.94).
+template <int BM> struct Geo {
+    static constexpr int kWaves = BM / 32, kThreads = 64 * kWaves;
+    static constexpr int kStageHalves = (BM + BN) * BK;                      // 48 KB / 40 KB
+    static constexpr int kInstr = (BM + BN) / 8;                             // 1 KB LDS-DMA instructions per stage: 48 / 40
+    static constexpr int kDmaPerWave = (kInstr + kWaves - 1) / kWaves;       // 6 / 7 per wave (BM = 192: the two surplus ones land in a scratch KB)
+    static constexpr size_t kLds = (size_t)STAGES * kStageHalves * sizeof(_Float16) + 1024;
+    static_assert(BM / 8 == 4 * kWaves, "four A instructions per wave");
+};
 
 struct Args {
     const _Float16* A; int64_t lda, sa_b;
@@ -38,7 +46,7 @@ struct Args {
     const float* R; int64_t ldr, sr_b;
     int M, N, K;
     float alpha;
-    const _Float16* zero_page;                                       // >= 16 zero bytes (RAGK)
+    const _Float16* zero_page;                                       // >= 16 zero bytes: ragged K groups, and the bias of a product without one
     int tiles_m, tiles_n, ntiles;
 };
 
@@ -56,7 +64,7 @@ __device__ __forceinline__ int w_perm(int rho) {
     return (rho & ~31) + 8 * ((r32 >> 2) & 3) + 4 * (r32 >> 4) + (r32 & 3);
 }
 
-template <int ACT, bool CF16, bool RES, bool RAGK, bool STAMP = false, typename ActFn>
+template <int BM, int ACT, bool CF16, bool RES, bool RAGK, bool STAMP = false, typename ActFn>
 __device__ __forceinline__ void gemm_body(const Args& p, ActFn actf, unsigned long long* stamps = nullptr) {
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0, tk0 = 0;
     auto stamp = [&](int k) {
@@ -67,7 +75,10 @@ __device__ __forceinline__ void gemm_body(const Args& p, ActFn actf, unsigned lo
         }
     };
     if constexpr (STAMP) tk0 = tlast = clock_cycles();
+    typedef Geo<BM> G;
+    constexpr int kWaves = G::kWaves, kStageHalves = G::kStageHalves, kDmaPerWave = G::kDmaPerWave;
     _Float16* lds = reinterpret_cast<_Float16*>(alsep_smem);
+    _Float16* const scratch = lds + (size_t)STAGES * kStageHalves;          // 1 KB: where a surplus request lands
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
@@ -95,16 +106,17 @@ __device__ __forceinline__ void gemm_body(const Args& p, ActFn actf, unsigned lo
         iss_b = p.B + bz * p.sb_b;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int r = m0 + 8 * (wave + 8 * j) + lrow;
+            const int r = m0 + 8 * (wave + kWaves * j) + lrow;
             off[j] = (unsigned)((r < p.M ? r : p.M - 1) * (int)p.lda) + 8u * lg;
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = n0 + w_perm(8 * (wave + 8 * j) + lrow);
-            off[4 + j] = (unsigned)((c < Nb ? c : (Nb > 0 ? Nb - 1 : 0)) * (int)p.ldb) + 8u * lg;
+        for (int j = 4; j < kDmaPerWave; ++j) {
+            const int wi = wave + kWaves * (j - 4);                        // W instruction: LDS rows 8 wi .. 8 wi + 7 (BM = 192: wi >= 16 is surplus)
+            const int c = n0 + w_perm(8 * (wi < 16 ? wi : 0) + lrow);
+            off[j] = (unsigned)((c < Nb ? c : (Nb > 0 ? Nb - 1 : 0)) * (int)p.ldb) + 8u * lg;
         }
     };
-    // one slice's six requests are issued as six single instructions BETWEEN the MFMAs of the slice being multiplied (issue_one(j) from
+    // one slice's six (BM = 192: seven) requests are issued as single instructions BETWEEN the MFMAs of the slice being multiplied (issue_one(j) from
     // compute()): all eight waves issuing their six right behind the barrier kept the CU's one address path busy for ~800 cycles with the
     // matrix pipes idle, and then the matrix pipes for ~850 with the address path idle (phase stamps, scripts/dbg/gemm_dev.hip)
     _Float16* iss_dst = lds;
@@ -115,7 +127,9 @@ __device__ __forceinline__ void gemm_body(const Args& p, ActFn actf, unsigned lo
     };
     auto issue_one = [&](int j) {
         const _Float16* src = (j < 4 ? iss_a : iss_b) + (off[j] + (unsigned)iss_k);
-        glds16(iss_zero ? p.zero_page : src, iss_dst + (size_t)j * 8 * 512);
+        _Float16* dst = iss_dst + (size_t)j * kWaves * 512;                 // instruction wave + kWaves j of the stage (A first, then W)
+        if (kWaves * kDmaPerWave > G::kInstr && j == kDmaPerWave - 1 && wave + kWaves * j >= G::kInstr) dst = scratch;
+        glds16(iss_zero ? p.zero_page : src, dst);
     };
     auto issue_done = [&]() {
         iss_stage = iss_stage == STAGES - 1 ? 0 : iss_stage + 1;
@@ -158,9 +172,10 @@ __device__ __forceinline__ void gemm_body(const Args& p, ActFn actf, unsigned lo
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-                if (i < 3) {                                         // three requests per k-step, each behind four MFMAs
+                const int slot_ = i < 3 ? 3 * st + i : (st == 1 ? 6 : -1);   // three requests per k-step, each behind four MFMAs; a seventh last
+                if (slot_ >= 0 && slot_ < kDmaPerWave) {
                     __builtin_amdgcn_sched_barrier(0);
-                    issue_one(3 * st + i);
+                    issue_one(slot_);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -183,16 +198,16 @@ __device__ __forceinline__ void gemm_body(const Args& p, ActFn actf, unsigned lo
         int bz, m0, n0;
         tile_origin(k, bz, m0, n0);
         const int cmax = p.N >= 4 ? p.N - 4 : 0;
-        if (p.bias) {
-            const float* bias = p.bias + bz * p.bias_b;
+        // no bias: the same four loads from the zero page (a conditional around the asm would make bv a merged value the compiler copies
+        // before the data is in)
+        const float* bias = p.bias ? p.bias + bz * p.bias_b : reinterpret_cast<const float*>(p.zero_page);
 #pragma unroll
-            for (int jp = 0; jp < 2; ++jp)
+        for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int col = n0 + wn * 64 + 32 * jp + 8 * lq + 4 * h;
-                    global_load_async_f32x4(bv[jp][h], bias, 4u * (unsigned)(col < cmax ? col : cmax));
-                }
-        }
+            for (int h = 0; h < 2; ++h) {
+                const int col = n0 + wn * 64 + 32 * jp + 8 * lq + 4 * h;
+                global_load_async_f32x4(bv[jp][h], bias, p.bias ? 4u * (unsigned)(col < cmax ? col : cmax) : 0u);
+            }
         if constexpr (RES) {
             const float* res = p.R + bz * p.sr_b;
 #pragma unroll
@@ -213,7 +228,6 @@ __device__ __forceinline__ void gemm_body(const Args& p, ActFn actf, unsigned lo
         int bz, m0, n0;
         tile_origin(k, bz, m0, n0);
         const int Nb = p.N;
-        const bool has_bias = p.bias != nullptr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = m0 + wm * 64 + i * 16 + l15;
@@ -227,9 +241,7 @@ __device__ __forceinline__ void gemm_body(const Args& p, ActFn actf, unsigned lo
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float t = p.alpha * acc[i][2 * jp + h][r];
-                        if (has_bias) t += bv[jp][h][r];
-                        t = actf(t);
+                        float t = actf(p.alpha * acc[i][2 * jp + h][r] + bv[jp][h][r]);
                         if constexpr (RES) t += rv[i][jp][h][r];
                         v[h][r] = t;
                     }
@@ -253,37 +265,43 @@ __device__ __forceinline__ void gemm_body(const Args& p, ActFn actf, unsigned lo
     issue();
     issue();
     zero_acc();
-    int stage = 0, ks = 0, tile_k = 0;
-    bool after_end = false;
-    for (int s = 0; s < total; ++s) {
-        // requests in flight, oldest first: slice s, slice s + 1 (6 each): "at most 6 outstanding" = slice s is in (loads complete in
-        // order).  Straight after a tile end the epilogue's wait has already covered slice s (see below) and nothing is waited for.
-        if (!after_end) wait_vmcnt<kDmaPerWave>();
+    int stage = 0;
+    // Requests in flight at the top of a slice, oldest first: slice s, slice s + 1 (kDmaPerWave each): "at most kDmaPerWave outstanding" =
+    // slice s is in (loads complete in order).  The first slice after a tile end needs no wait: the epilogue's wait has covered it.
+    // A tile's LAST slice is written out on its own: the epilogue operands are requested, multiplied past and consumed in one region of
+    // straight-line code.  (Requested in one conditional of a flat slice loop and consumed in another they were loop-carried values to
+    // hipcc, which copied the freshly "defined" registers elsewhere right behind the asm -- before the data had landed -- and reused
+    // the originals: wrong residuals, then wild addresses, on one launch in six.  scripts/check_async_regs.py, tests/test_codegen.py.)
+    for (int tile_k = 0; tile_k < my_tiles; ++tile_k) {
+        for (int ks = 0; ks < nk - 1; ++ks) {
+            if (ks > 0 || tile_k == 0) wait_vmcnt<kDmaPerWave>();
+            stamp(0);
+            barrier_nodrain();                                  // slice s is in LDS for every wave; stage (s + 2) % 3 was read by s - 1: free
+            stamp(1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(stage);
+            stamp(3);
+            stage = stage == STAGES - 1 ? 0 : stage + 1;
+        }
+        if (nk > 1 || tile_k == 0) wait_vmcnt<kDmaPerWave>();
         stamp(0);
         barrier_nodrain();
-        stamp(1);                                           // slice s is in LDS for every wave; stage (s + 2) % 3 was read by s - 1: free
+        stamp(1);
         __builtin_amdgcn_sched_barrier(0);
-        const bool last = ks == nk - 1;
-        if (last) epilogue_request(tile_k);
+        epilogue_request(tile_k);
         __builtin_amdgcn_sched_barrier(0);
         stamp(2);
         compute(stage);
         stamp(3);
         stage = stage == STAGES - 1 ? 0 : stage + 1;
-        if (last) {
-            // oldest first: slice s + 1, the epilogue operands, slice s + 2: everything but the newest 6 is in
-            __builtin_amdgcn_sched_barrier(0);
-            wait_vmcnt<kDmaPerWave>();
-            __builtin_amdgcn_sched_barrier(0);
-            stamp(4);
-            epilogue(tile_k++);
-            zero_acc();
-            stamp(5);
-            ks = 0;
-        } else {
-            ++ks;
-        }
-        after_end = last;
+        // oldest first: slice s + 1, the epilogue operands, slice s + 2: everything but the newest requests (slice s + 2) is in
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vmcnt<kDmaPerWave>();
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(4);
+        epilogue(tile_k);
+        zero_acc();
+        stamp(5);
     }
     wait_vmcnt<0>();                                                 // the surplus requests land before the wave ends
     if constexpr (STAMP) {

@@ -227,10 +227,10 @@ nn_gemm_hh_kernel(GemmHArgs p) {
 }
 
 // the large-M form (nn_gemm_h2.h): persistent, 256 x 128 tiles, LDS-DMA ring across tile ends
-template <int ACT, bool CF16, bool RES, bool RAGK>
-__global__ void __launch_bounds__(h2::kThreads, 2)
+template <int BM, int ACT, bool CF16, bool RES, bool RAGK>
+__global__ void __launch_bounds__(h2::Geo<BM>::kThreads, 2)
 nn_gemm_h2_kernel(h2::Args p) {
-    h2::gemm_body<ACT, CF16, RES, RAGK>(p, [](float t) { return hg_act<ACT>(t); });
+    h2::gemm_body<BM, ACT, CF16, RES, RAGK>(p, [](float t) { return hg_act<ACT>(t); });
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -553,15 +553,24 @@ nn_attn_h_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out, i
     // each) then fall into 32 different banks
     const int kkey = tid >> 3, kgrp = tid & 7;
     const int vpair = tid & 31, vgrp = tid >> 5;
-    for (int k0 = 0; k0 < L; k0 += kAtKc) {
-        h16x8 kv[2], vv[2];
+    // the next chunk's K / V rows are requested while this chunk is multiplied (one register set ahead: a chunk's loads used to be waited
+    // for right where they were issued, every iteration, with only the other resident workgroups to cover the latency)
+    h16x8 kv[2], vv[2];
+    auto request = [&](int k0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int kr = k0 + kkey + 32 * h, krc = kr < L ? kr : L - 1;     // clamped: the loads are unconditional; masked below
             kv[h] = *reinterpret_cast<const h16x8*>(kbase + (int64_t)krc * row_stride + 8 * kgrp);
             const int vr = k0 + 2 * vpair + h, vrc = vr < L ? vr : L - 1;
             vv[h] = *reinterpret_cast<const h16x8*>(vbase + (int64_t)vrc * row_stride + 8 * vgrp);
-            if (rot) {
+        }
+    };
+    request(0);
+    for (int k0 = 0; k0 < L; k0 += kAtKc) {
+        if (rot) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kr = k0 + kkey + 32 * h, krc = kr < L ? kr : L - 1;
                 f32x4 ka, kb;
                 h8_to_f(kv[h], ka, kb);
                 rotate8(ka, kb, rot + ((int64_t)krc * (kAtD / 2) + 4 * kgrp) * 2);
@@ -583,6 +592,7 @@ nn_attn_h_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out, i
             *reinterpret_cast<h16x2*>(Vt + (8 * vgrp + e) * kAtVld + 2 * vpair) = pr;
         }
         __syncthreads();
+        request(k0 + kAtKc < L ? k0 + kAtKc : k0);                           // past the end: this chunk again (unconditional loads)
         // S^T blocks (log2 domain): keys 16 kb + (4 lq + r), query l15 of block b; the K fragments serve both query blocks
         f32x4 sc[QB][4];
 #pragma unroll
@@ -754,28 +764,36 @@ extern "C" int alsep_nn_gemm_f16(alsep_ctx* ctx, const void* A, int64_t lda, int
     // Large M without per-batch ragged N: the persistent kernel (one workgroup per CU).  Its residual / bias requests carry 32-bit byte
     // offsets; an activation together with a residual stays with the tile-per-workgroup kernel (no caller has one).
     if (M >= 2048 && N >= 64 && !n_per_batch && !(R && act != 0) && (!R || (int64_t)M * ldr < ((int64_t)1 << 30)) ) {
-        if (K % h2::BK && !ctx->zero_page) {
+        if (!ctx->zero_page) {
             ALSEP_HIP(ctx, hipMalloc(&ctx->zero_page, 256));
             ALSEP_HIP(ctx, hipMemsetAsync(ctx->zero_page, 0, 256, ctx->stream));
         }
-        h2::Args q{(const _Float16*)A, lda, sa_b, (const _Float16*)W, ldw, sw_b, C, ldc, sc_b, bias, bias_b, R, ldr, sr_b, M, N, K, alpha,
-                   (const _Float16*)ctx->zero_page, (int)ceil_div64(M, h2::BM), (int)ceil_div64(N, h2::BN), 0};
-        const int64_t nt = (int64_t)q.tiles_m * q.tiles_n * nb;
+        int g = device_cu_count(ctx) / 8 * 8;                        // a multiple of the 8 XCDs
+        if (g < 8) g = 8;
+        // tile height: the one whose tiles fill the workgroups' rounds better (rounds x height = rows a workgroup walks); a tie goes to 256
+        const int64_t tn = ceil_div64(N, h2::BN);
+        const int64_t t256 = ceil_div64(M, 256) * tn * nb, t192 = ceil_div64(M, 192) * tn * nb;
+        const int bm = ceil_div64(t192, g) * 192 < ceil_div64(t256, g) * 256 ? 192 : 256;
+        const int64_t nt = bm == 192 ? t192 : t256;
         if (nt > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_gemm_f16: too many tiles");
-        q.ntiles = (int)nt;
-        int g = device_cu_count(ctx) / 8 * 8;
-        if (g < 8) g = 8;                               // a multiple of the 8 XCDs; fewer workgroups than tiles never idle a whole XCD
-        if (nt < g) g = (int)((nt + 7) / 8 * 8);
+        h2::Args q{(const _Float16*)A, lda, sa_b, (const _Float16*)W, ldw, sw_b, C, ldc, sc_b, bias, bias_b, R, ldr, sr_b, M, N, K, alpha,
+                   (const _Float16*)ctx->zero_page, (int)ceil_div64(M, bm), (int)tn, (int)nt};
+        if (nt < g) g = (int)((nt + 7) / 8 * 8);                     // fewer workgroups than tiles never idle a whole XCD
         ProfScope prof(ctx, ALSEP_PROF_NN_GEMM_H);
         prof.work(2.0 * nb * (double)M * N * K, (double)nb * (2.0 * M * K + 2.0 * N * K + ((c_f16 ? 2.0 : 4.0) + (R ? 4.0 : 0.0)) * M * N));
+#define ALSEP_H2_LAUNCH(BM_, ACT_, CF_, RES_, RAG_)                                                                                        \
+    do {                                                                                                                                    \
+        typedef h2::Geo<BM_> Geo_;                                                                                                          \
+        ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)nn_gemm_h2_kernel<BM_, ACT_, CF_, RES_, RAG_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           (int)Geo_::kLds));                                                                              \
+        hipLaunchKernelGGL((nn_gemm_h2_kernel<BM_, ACT_, CF_, RES_, RAG_>), dim3((unsigned)g), dim3(Geo_::kThreads), Geo_::kLds, ctx->stream, q); \
+    } while (0)
 #define ALSEP_H2_GO(ACT_, CF_, RES_)                                                                                                        \
     do {                                                                                                                                    \
-        if (K % h2::BK) {                                                                                                                   \
-            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)nn_gemm_h2_kernel<ACT_, CF_, RES_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h2::kLds)); \
-            hipLaunchKernelGGL((nn_gemm_h2_kernel<ACT_, CF_, RES_, true>), dim3((unsigned)g), dim3(h2::kThreads), h2::kLds, ctx->stream, q);   \
+        if (bm == 192) {                                                                                                                    \
+            if (K % h2::BK) ALSEP_H2_LAUNCH(192, ACT_, CF_, RES_, true); else ALSEP_H2_LAUNCH(192, ACT_, CF_, RES_, false);                \
         } else {                                                                                                                            \
-            ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)nn_gemm_h2_kernel<ACT_, CF_, RES_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h2::kLds)); \
-            hipLaunchKernelGGL((nn_gemm_h2_kernel<ACT_, CF_, RES_, false>), dim3((unsigned)g), dim3(h2::kThreads), h2::kLds, ctx->stream, q);  \
+            if (K % h2::BK) ALSEP_H2_LAUNCH(256, ACT_, CF_, RES_, true); else ALSEP_H2_LAUNCH(256, ACT_, CF_, RES_, false);                \
         }                                                                                                                                   \
     } while (0)
         if (R) {
@@ -786,6 +804,7 @@ extern "C" int alsep_nn_gemm_f16(alsep_ctx* ctx, const void* A, int64_t lda, int
             if (act == 3) ALSEP_H2_GO(3, false, false); else if (act == 5) ALSEP_H2_GO(5, false, false); else ALSEP_H2_GO(0, false, false);
         }
 #undef ALSEP_H2_GO
+#undef ALSEP_H2_LAUNCH
         ALSEP_LAUNCH_CHECK(ctx, "nn_gemm_h2_kernel");
         return ALSEP_OK;
     }

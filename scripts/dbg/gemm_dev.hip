@@ -5,13 +5,17 @@
 #include <cstdlib>
 #include <vector>
 
+#ifndef DEV_BM
+#define DEV_BM 256
+#endif
+typedef h2::Geo<DEV_BM> G;
 template <int ACT, bool CF16, bool RES, bool RAGK>
-__global__ void __launch_bounds__(h2::kThreads, 2) gemm_h2_kernel(h2::Args p) {
-    h2::gemm_body<ACT, CF16, RES, RAGK>(p, [](float t) { return t; });
+__global__ void __launch_bounds__(G::kThreads, 2) gemm_h2_kernel(h2::Args p) {
+    h2::gemm_body<DEV_BM, ACT, CF16, RES, RAGK>(p, [](float t) { return t; });
 }
 template <bool CF16, bool RES>
-__global__ void __launch_bounds__(h2::kThreads, 2) gemm_h2_stamp_kernel(h2::Args p, unsigned long long* stamps) {
-    h2::gemm_body<0, CF16, RES, false, true>(p, [](float t) { return t; }, stamps);
+__global__ void __launch_bounds__(G::kThreads, 2) gemm_h2_stamp_kernel(h2::Args p, unsigned long long* stamps) {
+    h2::gemm_body<DEV_BM, 0, CF16, RES, false, true>(p, [](float t) { return t; }, stamps);
 }
 __global__ void ref_kernel(const _Float16* A, const _Float16* W, float* C, const float* bias, const float* R, int M, int N, int K, int64_t sa, int64_t sw,
                            int64_t sc) {
@@ -28,8 +32,8 @@ __global__ void ref_kernel(const _Float16* A, const _Float16* W, float* C, const
 template <bool CF16, bool RES, bool RAGK>
 static void launch(const h2::Args& a, int grid) {
     auto k = gemm_h2_kernel<0, CF16, RES, RAGK>;
-    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h2::kLds));
-    hipLaunchKernelGGL(k, dim3(grid), dim3(h2::kThreads), h2::kLds, 0, a);
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(G::kThreads), G::kLds, 0, a);
 }
 
 static void run(int M, int N, int K, int nb, bool c16, bool res, int cus) {
@@ -52,7 +56,7 @@ static void run(int M, int N, int K, int nb, bool c16, bool res, int cus) {
     h2::Args a{};
     a.A = dA; a.lda = K; a.sa_b = (int64_t)M * K; a.B = dW; a.ldb = K; a.sb_b = (int64_t)N * K; a.C = dC; a.ldc = N; a.sc_b = (int64_t)M * N;
     a.bias = dB; a.bias_b = N; a.R = dR; a.ldr = N; a.sr_b = (int64_t)M * N; a.M = M; a.N = N; a.K = K; a.alpha = 1.f; a.zero_page = dZ;
-    a.tiles_m = (M + h2::BM - 1) / h2::BM; a.tiles_n = (N + h2::BN - 1) / h2::BN; a.ntiles = nb * a.tiles_m * a.tiles_n;
+    a.tiles_m = (M + DEV_BM - 1) / DEV_BM; a.tiles_n = (N + h2::BN - 1) / h2::BN; a.ntiles = nb * a.tiles_m * a.tiles_n;
     int grid = cus; while (grid > 8 && grid / 8 * 8 > a.ntiles) grid -= 8;
     if (grid > a.ntiles) grid = (a.ntiles + 7) / 8 * 8;
     const bool rag = K % h2::BK != 0;
@@ -90,8 +94,8 @@ static void run(int M, int N, int K, int nb, bool c16, bool res, int cus) {
     if (!rag) {                                       // phase stamps (s_memtime ticks at 100 MHz): mean over waves, in us
         unsigned long long* dS; CK(hipMalloc(&dS, (size_t)grid * 64 * 8)); CK(hipMemset(dS, 0, (size_t)grid * 64 * 8));
         auto launch_s = [&](auto kern) {
-            CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h2::kLds));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(h2::kThreads), h2::kLds, 0, a, dS);
+            CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::kLds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(G::kThreads), G::kLds, 0, a, dS);
         };
         if (c16 && res) launch_s(gemm_h2_stamp_kernel<true, true>); else if (c16) launch_s(gemm_h2_stamp_kernel<true, false>);
         else if (res) launch_s(gemm_h2_stamp_kernel<false, true>); else launch_s(gemm_h2_stamp_kernel<false, false>);
@@ -104,7 +108,7 @@ static void run(int M, int N, int K, int nb, bool c16, bool res, int cus) {
                sum[0] / nw / 100, sum[1] / nw / 100, sum[2] / nw / 100, sum[3] / nw / 100, sum[4] / nw / 100, sum[5] / nw / 100, sum[6] / nw / 100, sum[7] / nw);
         hipFree(dS);
     }
-    printf("M %6d N %5d K %5d nb %3d %s%s grid %4d: %8.1f us %7.1f TFLOP/s   max|err| %.3g (peak %.3g)%s\n", M, N, K, nb, c16 ? "f16" : "f32", res ? "+res" : "    ", grid,
+    printf("BM %d M %6d N %5d K %5d nb %3d %s%s grid %4d: %8.1f us %7.1f TFLOP/s   max|err| %.3g (peak %.3g)%s\n", DEV_BM, M, N, K, nb, c16 ? "f16" : "f32", res ? "+res" : "    ", grid,
            us, fl / us / 1e6, worst, peak, worst > (c16 ? 2e-3 : 2e-5) * (peak + 1) ? "   <-- WRONG" : "");
     fflush(stdout);
     hipFree(dA); hipFree(dW); hipFree(dC); hipFree(dB); hipFree(dRef); hipFree(dZ); if (dR) hipFree(dR);
@@ -112,6 +116,14 @@ static void run(int M, int N, int K, int nb, bool c16, bool res, int cus) {
 
 int main(int argc, char** argv) {
     int cus = 256;
+    if (argc > 1 && atoi(argv[1]) < 0) {              // soak: the residual shapes again and again (a rare wrong element shows as WRONG)
+        for (int i = 0; i < -atoi(argv[1]); ++i) {
+            run(48060, 384, 512, 1, false, true, cus);
+            run(48060, 384, 1536, 1, false, true, cus);
+            run(48060, 1536, 384, 1, true, false, cus);
+        }
+        return 0;
+    }
     if (argc > 1) cus = atoi(argv[1]);
     run(1000, 256, 128, 1, false, false, cus);       // small: ragged M
     run(777, 136, 200, 2, true, true, cus);          // ragged everything, batched
