@@ -87,6 +87,7 @@ __device__ __forceinline__ float hg_act(float t) {
     return t;
 }
 
+#ifndef ALSEP_NN_HALF_CONV_TU
 template <int ACT, bool CF16>
 __global__ void __launch_bounds__(kHThreads, 2)
 nn_gemm_hh_kernel(GemmHArgs p) {
@@ -233,6 +234,7 @@ nn_gemm_h2_kernel(h2::Args p) {
     h2::gemm_body<BM, ACT, CF16, RES, RAGK>(p, [](float t) { return hg_act<ACT>(t); });
 }
 
+#else   // ALSEP_NN_HALF_CONV_TU: the convolution kernel and its entry points, compiled as nn_conv_half.hip (which says why)
 // ------------------------------------------------------------------------------------------------------------------------------------
 // Convolution as the same GEMM (MDX23C's TFC convolutions in half-precision mode): M = output pixels, N = output channels,
 // K = (tap, ci) with Cin % 64 == 0, so a 64-wide K slice is 64 consecutive input channels of ONE tap -- one 128-byte line of the pixel the
@@ -420,6 +422,8 @@ conv_splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t np
     }
 }
 
+#endif  // ALSEP_NN_HALF_CONV_TU (kernels)
+#ifndef ALSEP_NN_HALF_CONV_TU
 // lucidrains RMSNorm (y = x / max(||x||_2, 1e-12) sqrt(C) gamma, sum of squares in double as nn_rmsnorm_kernel) with the result stored
 // as IEEE half: the A operand of the Linear that follows.  One wave per row.
 __global__ void __launch_bounds__(kHThreads)
@@ -720,9 +724,11 @@ roformer_bandsplit_in_kernel(const float* __restrict__ spec, const int* __restri
     }
 }
 
+#endif  // !ALSEP_NN_HALF_CONV_TU
 }  // namespace
 
 // feat[band][t][kmax] = RMSNorm_band(gathered bins of frame t), zero-padded (see roformer_bandsplit_in_kernel); kmax <= 640, even
+#ifndef ALSEP_NN_HALF_CONV_TU
 extern "C" int alsep_roformer_bandsplit_in(alsep_ctx* ctx, const float* spec, const int* pidx, const float* gamma, const int* width, void* feat,
                                            int nb, int F, int T, int kmax) {
     ALSEP_ENTER(ctx);
@@ -829,6 +835,7 @@ extern "C" int alsep_nn_gemm_f16(alsep_ctx* ctx, const void* A, int64_t lda, int
     return ALSEP_OK;
 }
 
+#else   // ALSEP_NN_HALF_CONV_TU
 // Split K: a layer whose 128 x 128 tiles do not fill the chip (the deep levels of the U-Net: 8 x 32 pixels x 768 channels are 12 tiles
 // with 108 K slices each -- 225 us at 12 TFLOP/s) is cut along K into `splits` ranges of >= 8 slices, each workgroup writes its partial
 // tile, conv_splitk_reduce_kernel adds them in a fixed order (deterministic, unlike atomics).
@@ -901,6 +908,8 @@ extern "C" int alsep_nn_conv2d_f16(alsep_ctx* ctx, const void* x, const void* w,
     return ALSEP_OK;
 }
 
+#endif  // ALSEP_NN_HALF_CONV_TU (entry points)
+#ifndef ALSEP_NN_HALF_CONV_TU
 // y[r][C] (IEEE half) = RMSNorm(x[r][C]) gamma (see nn_rmsnorm_h_kernel); strides in elements
 extern "C" int alsep_nn_rmsnorm_f16(alsep_ctx* ctx, const float* x, void* y, const float* gamma, int64_t rows, int C, int64_t x_stride,
                                     int64_t y_stride) {
@@ -945,3 +954,4 @@ extern "C" int alsep_nn_attention_f16(alsep_ctx* ctx, const void* qkv, void* out
     ALSEP_LAUNCH_CHECK(ctx, "nn_attn_h_kernel");
     return ALSEP_OK;
 }
+#endif  // !ALSEP_NN_HALF_CONV_TU

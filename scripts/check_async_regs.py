@@ -30,7 +30,7 @@ def vregs(text):
 
 def compile_asm(src):
     out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-I", os.path.join(ROOT, "audiolab_amd", "csrc"),
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-I", os.path.join(ROOT, "audiolab_amd", "csrc"),
            "-I", os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out, src]
     subprocess.run(cmd, check=True, cwd=tempfile.gettempdir())
     text = open(out).read()

@@ -6,7 +6,7 @@ set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 CXX="${ALSEP_HOST_CXX:-/opt/rocm/lib/llvm/bin/clang++}"
-SRC="$ROOT/audiolab_amd/csrc/fft.hip $ROOT/audiolab_amd/csrc/tdfnet.hip $ROOT/audiolab_amd/csrc/elementwise.hip $ROOT/audiolab_amd/csrc/vrnet.hip $ROOT/audiolab_amd/csrc/nn.hip $ROOT/audiolab_amd/csrc/nn_half.hip $ROOT/audiolab_amd/csrc/reverb.hip $ROOT/audiolab_amd/csrc/tdfnet_f16.hip $ROOT/audiolab_amd/csrc/fft_f16.hip"
+SRC="$ROOT/audiolab_amd/csrc/fft.hip $ROOT/audiolab_amd/csrc/tdfnet.hip $ROOT/audiolab_amd/csrc/elementwise.hip $ROOT/audiolab_amd/csrc/vrnet.hip $ROOT/audiolab_amd/csrc/nn.hip $ROOT/audiolab_amd/csrc/nn_half.hip $ROOT/audiolab_amd/csrc/nn_conv_half.hip $ROOT/audiolab_amd/csrc/reverb.hip $ROOT/audiolab_amd/csrc/tdfnet_f16.hip $ROOT/audiolab_amd/csrc/fft_f16.hip"
 # -DALSEP_EXPERIMENTS: the emulated library keeps the superseded / timing-experiment kernel variants, which the tests use as
 # bit-identity cross-checks of the production kernels (the product libalsep.so is built without it)
 COMMON="-DALSEP_EXPERIMENTS -std=c++17 -fPIC -shared -pthread -I$HERE -I$ROOT/audiolab_amd/csrc -Wno-unused-value -Wno-pass-failed -Wno-unknown-pragmas"
