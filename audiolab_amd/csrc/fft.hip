@@ -647,9 +647,21 @@ static int launch_stft_first_conv(alsep_ctx* ctx, const alsep_plan* p, const flo
     for (int64_t b0 = 0; b0 < n_chunks; b0 += 32768) {
         const int64_t nb = std::min<int64_t>(32768, n_chunks - b0);
         const int64_t off = b0 * (int64_t)r16::kFirstConvG * p->dim_f * p->dim_t;
-        hipLaunchKernelGGL((r16::stft_r16_kernel<N / 256, OutT, ALSEP_LAYOUT_NHWC, true>), dim3(p->dim_t, (unsigned)nb), dim3(r16::kThreads), lds,
-                           ctx->stream, pcm + b0 * chunk_stride, ch_stride, chunk_stride, p->chunk, p->hop, p->dim_f, p->dim_t,
-                           (const float2*)p->tw, act + off, fc);
+        const int64_t frames = nb * p->dim_t;
+        if (N / 256 > 24) {
+            // persistent (fft_r16.h, PERSIST): as many workgroups as are resident at once (LDS: two per CU at 7680 points), a multiple of 8
+            int64_t g = (int64_t)device_cu_count(ctx) * (int64_t)((160 * 1024) / lds);
+            g = g / 8 * 8;
+            if (g > frames) g = (frames + 7) / 8 * 8;
+            if (g < 8) g = 8;
+            hipLaunchKernelGGL((r16::stft_r16_kernel<N / 256, OutT, ALSEP_LAYOUT_NHWC, true>), dim3((unsigned)g), dim3(r16::kThreads), lds,
+                               ctx->stream, pcm + b0 * chunk_stride, ch_stride, chunk_stride, p->chunk, p->hop, p->dim_f, p->dim_t,
+                               (const float2*)p->tw, act + off, fc, (int)frames);
+        } else {
+            hipLaunchKernelGGL((r16::stft_r16_kernel<N / 256, OutT, ALSEP_LAYOUT_NHWC, true>), dim3(p->dim_t, (unsigned)nb), dim3(r16::kThreads), lds,
+                               ctx->stream, pcm + b0 * chunk_stride, ch_stride, chunk_stride, p->chunk, p->hop, p->dim_f, p->dim_t,
+                               (const float2*)p->tw, act + off, fc, 0);
+        }
     }
     ALSEP_LAUNCH_CHECK(ctx, "stft_first_conv_kernel");
     return ALSEP_OK;

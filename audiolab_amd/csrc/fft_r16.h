@@ -234,9 +234,9 @@ constexpr int kFirstConvGroups = kFirstConvG / 8;            // 16-byte pieces p
 
 // grid (T, n_chunks), 128 threads.
 template <int R2, typename OutT, int LAYOUT, bool FUSE = false>
-__global__ void __launch_bounds__(kThreads) ALSEP_WAVES_PER_EU(2)
+__global__ void __launch_bounds__(kThreads) ALSEP_WAVES_PER_EU(R2 > 24 ? 1 : 2)      // 7680: LDS allows two workgroups (one wave per SIMD) anyway
 stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_stride, int chunk, int hop, int dim_f,
-                int T, const float2* __restrict__ tw_, OutT* __restrict__ spec, FirstConvArgs fc) {
+                int T, const float2* __restrict__ tw_, OutT* __restrict__ spec, FirstConvArgs fc, int n_frames = 0) {
     constexpr int N = 256 * R2, NT = kThreads;
     constexpr int M = N / 16;                 // butterflies of passes A and B
     constexpr int NB = (M + NT - 1) / NT;     // per thread (2, 3; 4 for R2 = 30, where the last threads own fewer)
@@ -248,10 +248,21 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
     static_assert(NB <= 4, "geometry");
     const v2f* __restrict__ tw = reinterpret_cast<const v2f*>(tw_);
     v2f* buf = reinterpret_cast<v2f*>(alsep_smem);
-    const int tid = threadIdx.x;
     // consecutive workgroup ids are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of frames so
-    // that the 6-fold re-read of every PCM sample (hop = n_fft / 6) is served by ONE L2 instead of all eight
-    const int wg = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    // that the 6-fold re-read of every PCM sample (hop = n_fft / 6) is served by ONE L2 instead of all eight.
+    // PERSIST (the fused front end at 7680 points; n_frames = its frame count): a 1-D grid of as many workgroups as fit the chip at once (a multiple of 8), each walking
+    // frames id, id + grid, ... of the same XCD's run -- a workgroup's 64-deep queue of epilogue stores then drains under its NEXT
+    // frame's loads and passes instead of holding its LDS until the last store has left (7680: the frame buffer allows two workgroups
+    // per CU, and a quarter of the launch was that wait).
+    // Only where it pays (PERSIST): at 6144 points three workgroups per CU already hide a frame's FFT under the others' stores, and the
+    // frame loop costs the kernel 12 % (740 -> 830 us); at 7680 (two per CU) it takes 1000 -> 844 us.
+    constexpr bool PERSIST = FUSE && R2 > 24;
+    const int n_wg = gridDim.x * gridDim.y, total = PERSIST ? n_frames : n_wg;
+    for (int id = blockIdx.x + gridDim.x * blockIdx.y, it = 0; PERSIST ? id < total : it < 1; id += n_wg, ++it) {
+    // everything derived from the thread index is computed afresh per frame (an opaque copy): hoisted out of the frame loop these values
+    // stay live across it, and the kernel has no register to spare (it spilled 130-320 dwords with them hoisted)
+    const int tid = PERSIST ? opaque_vgpr((int)threadIdx.x) : (int)threadIdx.x;
+    const int wg = xcd_remap(id, total);
     const int t = wg % T;
     const int64_t b = wg / T;
     const int p0 = t * hop - N / 2;
@@ -495,6 +506,8 @@ stft_r16_kernel(const float* __restrict__ pcm, int64_t ch_stride, int64_t chunk_
                 store_bin<OutT>(spec, frame_off, b, N / 2, T, t, dim_f, LAYOUT, cx_add_conj(z, z), cx_sub_conj_divi(z, z));
             }
         }
+    }
+    if (PERSIST && id + n_wg < total) __syncthreads();       // the frame buffer (the epilogue's rounded bins) is free for the next frame's pass A
     }
 }
 

@@ -703,7 +703,31 @@ def main() -> None:
         del buf
     if cfg.n_fft != 7680:                                    # the geometry of the reference's own vocal models (Voc_FT, Kim_Vocal_*: n_fft 7680, dim_f 3072)
         from audiolab_amd.mdx import StftPlan
-        fft_stage_lines(StftPlan(ctx, 7680, 1024, 3072, 256), "_7680")
+        plan7 = StftPlan(ctx, 7680, 1024, 3072, 256)
+        fft_stage_lines(plan7, "_7680")
+        if half and cfg.dim_f == plan7.dim_f and cfg.dim_t == plan7.dim_t:   # the fused front end at that geometry (same first layer)
+            p_gen = plan7.chunk_size - 2 * plan7.trim
+            nb = min(n_samples // p_gen + 1, args.batch)
+            pad_len = plan7.trim * 2 + nb * p_gen + plan7.chunk_size
+            buf = torch.zeros((2, pad_len), device=device)
+            buf[:, plan7.trim:plan7.trim + min(n_samples, pad_len - 2 * plan7.trim)] = mix[:, :min(n_samples, pad_len - 2 * plan7.trim)]
+            import dataclasses as _dc
+            net7 = TDFNet(_dc.replace(cfg, n_fft=7680), sds[0], ctx=ctx, dtype=dtype, max_batch=args.batch)   # same weights: only the front end differs
+            if net7.forward_pcm(plan7, buf, pad_len, p_gen, nb) is not None:
+                torch.cuda.synchronize()
+                reps = 5
+                ctx.profile_begin(_lib.PROF_STFT)
+                for _ in range(reps):
+                    net7.forward_pcm(plan7, buf, pad_len, p_gen, nb)
+                ms, launches = ctx.profile_end()
+                alg = 2 * plan7.chunk_size * 4 + plan7.dim_f * plan7.dim_t * cfg.g * es
+                gbs = alg * nb * reps / (ms * 1e-3) / 1e9
+                stages["stft_first_conv_7680"] = {"kernel": "stft_r16_kernel<30, FUSE>", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                                                  "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "n_fft": 7680, "bytes_per_chunk": alg,
+                                                  "chunks_per_launch": nb, "us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
+                                                  "us_per_chunk": round(ms * 1e3 / max(launches, 1) / nb, 3), "traffic": None,
+                                                  "algorithmic_bytes_per_launch": alg * nb}
+            del buf, net7
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
