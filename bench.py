@@ -725,7 +725,8 @@ def main() -> None:
                 stages["stft_first_conv_7680"] = {"kernel": "stft_r16_kernel<30, FUSE>", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
                                                   "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "n_fft": 7680, "bytes_per_chunk": alg,
                                                   "chunks_per_launch": nb, "us_per_launch": round(ms * 1e3 / max(launches, 1), 2),
-                                                  "us_per_chunk": round(ms * 1e3 / max(launches, 1) / nb, 3), "traffic": None,
+                                                  "us_per_chunk": round(ms * 1e3 / max(launches, 1) / nb, 3),
+                                                  "traffic": pmc_traffic("stft_r16_kernel<30><fused>", nb),
                                                   "algorithmic_bytes_per_launch": alg * nb}
             del buf, net7
 
