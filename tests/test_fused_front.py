@@ -73,3 +73,32 @@ def test_bench_geometry_runner_uses_the_fused_kernel(gpu_ctx):
     plain = pred.demix(mix)
     assert gpu_ctx.launch_count("stft_r16_kernel") == 1 and gpu_ctx.launch_count("first_conv_kernel") == 1
     assert torch.equal(fused, plain)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_front_end_7680_persistent_workgroups_bit_identical(gpu_ctx, dtype):
+    """n_fft 7680 runs the fused front end with PERSISTENT workgroups (fft_r16.h PERSIST: two per CU, each walking several frames with the
+    frame buffer reused behind a barrier): 1 664 frames over 512 workgroups = 3-4 frames each, ragged dim_f, reflect-padded edges and
+    zeroed low bins -- bit for bit the two-step path"""
+    from audiolab_amd import _lib
+    from audiolab_amd.mdx import StftPlan
+    from audiolab_amd.synth import synthetic_state_dict
+    from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
+    from oracle.toy import synth_mix
+    cfg = TDFNetConfig(dim_f=200, dim_t=64, n_fft=7680, hop=1024, num_blocks=1, g=48, bn=8)
+    sd = synthetic_state_dict(cfg, seed=3, calib="noise")
+    net = TDFNet(cfg, sd, ctx=gpu_ctx, dtype=dtype, max_batch=26)
+    plan = StftPlan(gpu_ctx, cfg.n_fft, cfg.hop, cfg.dim_f, cfg.dim_t)
+    chunk, step, nb = plan.chunk_size, 20000, 26
+    total = (nb - 1) * step + chunk + 9
+    pcm = torch.from_numpy(synth_mix(total, seed=5) * 2.0).cuda()
+    gpu_ctx.launch_counts_reset()
+    got = net.forward_pcm(plan, pcm, total, step, nb, pcm_offset=3, zero_low_bins=2)
+    assert got is not None and gpu_ctx.launch_count("stft_first_conv_kernel") == 1
+    spek = plan.stft_strided(pcm, total, step, nb, dtype, _lib.LAYOUT_NHWC, pcm_offset=3)
+    gpu_ctx.check(gpu_ctx.lib.alsep_zero_low_bins(gpu_ctx.handle, _lib.ptr(spek), _lib.dtype_code(dtype), _lib.LAYOUT_NHWC, nb, plan.dim_f, plan.dim_t, 2),
+                  "alsep_zero_low_bins")
+    want = net.forward_nhwc(spek)
+    assert float(want.float().abs().max()) > 1e-3
+    assert torch.equal(got.cpu(), want.cpu())
