@@ -13,3 +13,5 @@ for m in mq mny big; do
 done
 # the fp32 model families' kernels (tiled GEMM / conv, InstanceNorm statistics, softmax with a leading dimension; about 2 minutes)
 ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 LD_PRELOAD="$RT" python "$HERE/asan_cases_nn.py"
+# the round-4 kernels: persistent f16 GEMM, 64-key attention, split-half contractions (about 2 minutes)
+ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 LD_PRELOAD="$RT" python "$HERE/asan_cases_half.py"
