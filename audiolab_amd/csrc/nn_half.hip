@@ -776,10 +776,12 @@ extern "C" int alsep_nn_gemm_f16(alsep_ctx* ctx, const void* A, int64_t lda, int
         }
         int g = device_cu_count(ctx) / 8 * 8;                        // a multiple of the 8 XCDs
         if (g < 8) g = 8;
-        // tile height: the one whose tiles fill the workgroups' rounds better (rounds x height = rows a workgroup walks); a tie goes to 256
+        // tile height: 192 where its tiles fill the workgroups' rounds (rounds x height = rows a workgroup walks) at least 15 % better -- the
+        // six-wave kernel is that much slower per flop (48 060 x 1536 x 384: 88-91 us against 73-75), so a 2 % better fill (BS Roformer's
+        // 49 662 x 1536) must not select it; the 384-column Linears of Mel-Band (576 against 768) do
         const int64_t tn = ceil_div64(N, h2::BN);
         const int64_t t256 = ceil_div64(M, 256) * tn * nb, t192 = ceil_div64(M, 192) * tn * nb;
-        const int bm = ceil_div64(t192, g) * 192 < ceil_div64(t256, g) * 256 ? 192 : 256;
+        const int bm = ceil_div64(t192, g) * 192 * 115 < ceil_div64(t256, g) * 256 * 100 ? 192 : 256;
         const int64_t nt = bm == 192 ? t192 : t256;
         if (nt > 0x7fffffff) return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_nn_gemm_f16: too many tiles");
         h2::Args q{(const _Float16*)A, lda, sa_b, (const _Float16*)W, ldw, sw_b, C, ldc, sc_b, bias, bias_b, R, ldr, sr_b, M, N, K, alpha,
