@@ -254,16 +254,23 @@ def test_half_gemm_vs_float64(dev, M, N, K, act, res, c16):
             assert np.all(got3[b][:, nv:] == 7.0)
 
 
-def test_rmsnorm_half_out(dev):
+@pytest.mark.parametrize("rows,C,pad", [(37, 96, 0), (1001, 384, 8), (130, 512, 0), (3, 384, 0)])
+def test_rmsnorm_half_out(dev, rows, C, pad):
+    """generic widths (one wave per row) and the Roformers' 384 / 512 (four rows per wave, vector loads; rows % 16 != 0, padded rows)"""
     from audiolab_amd import _lib
-    g = torch.Generator().manual_seed(3)
-    x = torch.randn(37, 96, generator=g) * 3
-    gamma = 1.0 + 0.1 * torch.randn(96, generator=g)
+    g = torch.Generator().manual_seed(3 + rows)
+    ld = C + pad
+    x = torch.randn(rows, ld, generator=g) * 3
+    gamma = 1.0 + 0.1 * torch.randn(C, generator=g)
     xd, gd = on(dev, x), on(dev, gamma)
-    y = torch.zeros((37, 96), dtype=torch.float16, device=dev.device)
-    dev.check(dev.lib.alsep_nn_rmsnorm_f16(dev.handle, _lib.ptr(xd), _lib.ptr(y), _lib.ptr(gd), 37, 96, 96, 96), "alsep_nn_rmsnorm_f16")
-    want = torch.nn.functional.normalize(x.double(), dim=-1) * 96 ** 0.5 * gamma.double()
-    assert float((y.cpu().double() - want).abs().max()) < 1.5e-3 * float(want.abs().max())
+    y = torch.zeros((rows, ld), dtype=torch.float16, device=dev.device)
+    dev.launch_counts_reset()
+    dev.check(dev.lib.alsep_nn_rmsnorm_f16(dev.handle, _lib.ptr(xd), _lib.ptr(y), _lib.ptr(gd), rows, C, ld, ld), "alsep_nn_rmsnorm_f16")
+    assert dev.launch_count("nn_rmsnorm_h4_kernel" if C in (384, 512) else "nn_rmsnorm_h_kernel") == 1
+    want = torch.nn.functional.normalize(x[:, :C].double(), dim=-1) * C ** 0.5 * gamma.double()
+    got = y.cpu().double()
+    assert float((got[:, :C] - want).abs().max()) < 1.5e-3 * float(want.abs().max())
+    assert float(got[:, C:].abs().max()) == 0 if pad else True          # nothing written beyond the C columns
 
 
 @pytest.mark.parametrize("over_time,L,n_seq", [(True, 70, 3), (False, 33, 5), (True, 64, 1), (False, 1, 2), (True, 301, 2)])
