@@ -102,3 +102,29 @@ def test_fused_front_end_7680_persistent_workgroups_bit_identical(gpu_ctx, dtype
     want = net.forward_nhwc(spek)
     assert float(want.float().abs().max()) > 1e-3
     assert torch.equal(got.cpu(), want.cpu())
+
+
+def test_fused_front_end_7680_persistent_loop_on_the_emulation(dev):
+    """the frame loop of the persistent 7680 kernel on the emulated kernels: 560 frames over the 512 workgroups a 256-CU device takes, so 48
+    workgroups walk two frames (frame buffer reused behind the barrier) -- bit for bit the two-step path"""
+    from audiolab_amd import _lib
+    from audiolab_amd.mdx import StftPlan
+    from audiolab_amd.synth import synthetic_state_dict
+    from audiolab_amd.tdfnet import TDFNet, TDFNetConfig
+    from oracle.toy import synth_mix
+    if dev.device.type != "cpu":
+        pytest.skip("the GPU runs test_fused_front_end_7680_persistent_workgroups_bit_identical")
+    cfg = TDFNetConfig(dim_f=80, dim_t=8, n_fft=7680, hop=1024, num_blocks=1, g=48, bn=8)
+    net = TDFNet(cfg, synthetic_state_dict(cfg, seed=2, calib="noise"), ctx=dev, dtype=torch.float16, max_batch=70)
+    plan = StftPlan(dev, cfg.n_fft, cfg.hop, cfg.dim_f, cfg.dim_t)
+    chunk, step, nb = plan.chunk_size, 1500, 70
+    total = (nb - 1) * step + chunk + 17
+    pcm = on(dev, synth_mix(total, seed=4) * 3.0)
+    got = net.forward_pcm(plan, pcm, total, step, nb, pcm_offset=5, zero_low_bins=1)
+    assert got is not None
+    spek = plan.stft_strided(pcm, total, step, nb, torch.float16, _lib.LAYOUT_NHWC, pcm_offset=5)
+    dev.check(dev.lib.alsep_zero_low_bins(dev.handle, _lib.ptr(spek), _lib.dtype_code(torch.float16), _lib.LAYOUT_NHWC, nb, plan.dim_f, plan.dim_t, 1),
+              "alsep_zero_low_bins")
+    want = net.forward_nhwc(spek)
+    assert float(want.float().abs().max()) > 1e-3
+    assert torch.equal(got.cpu(), want.cpu())
