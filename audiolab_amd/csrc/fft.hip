@@ -580,7 +580,7 @@ extern "C" int alsep_plan_destroy(alsep_plan* plan) {
 static int istft_pick_run(int n_blocks, int Q, int64_t n_chunks, int slots) {
     int best = 16;
     double best_cost = 1e30;
-    for (int run = 4; run <= 64; ++run) {
+    for (int run = 1; run <= 64; ++run) {                    // (from 1: a single chunk of 801 frames -- the Roformers -- is one round of 801 short workgroups)
         const int64_t wgs = n_chunks * ((n_blocks + run - 1) / run);
         const int64_t rounds = (wgs + slots - 1) / slots;
         const double cost = (double)rounds * (run + Q - 1);
@@ -707,7 +707,6 @@ extern "C" int ALSEP_TU_NAME(alsep_stft)(alsep_ctx* ctx, const alsep_plan* plan,
     return alsep_fail(ctx, ALSEP_ERR_ARG, "alsep_stft: unsupported n_fft %d", plan->n_fft);
 }
 
-constexpr int kIstftRun = 32;   // hop-blocks finished per workgroup (warm-up = ceil(N/hop)-1 frames)
 
 template <int N, typename InT, int LAYOUT>
 static int launch_istft(alsep_ctx* ctx, const alsep_plan* p, const void* spec, int64_t n_chunks, float* out,
@@ -785,13 +784,17 @@ static int launch_istft(alsep_ctx* ctx, const alsep_plan* p, const void* spec, i
     const size_t lds = sizeof(float2) * (size_t)(N + Q * p->hop);
     ALSEP_HIP(ctx, hipFuncSetAttribute((const void*)istft_kernel<N, InT, LAYOUT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int groups = (j_hi - j_lo + kIstftRun - 1) / kIstftRun;
+    // hop-blocks per workgroup: chosen like the three-pass kernels' (a single chunk of 801 frames -- a Roformer's -- as 801 short workgroups
+    // instead of 51 long ones on 256 CUs: the Q - 1 warm-up frames cost less than the idle CUs)
+    const int slots_g = device_cu_count(ctx) * (int)std::max<size_t>(1, (160 * 1024) / lds);
+    const int run_g = istft_pick_run(j_hi - j_lo, Q, n_chunks, slots_g);
+    const int groups = (j_hi - j_lo + run_g - 1) / run_g;
     for (int64_t b0 = 0; b0 < n_chunks; b0 += 32768) {
         const int64_t nb = std::min<int64_t>(32768, n_chunks - b0);
         const int64_t spec_off = b0 * 4 * (int64_t)p->dim_f * p->dim_t;
         hipLaunchKernelGGL((istft_kernel<N, InT, LAYOUT>), dim3(groups, (unsigned)nb), dim3(kFftThreads), lds,
                            ctx->stream, (const InT*)spec + spec_off, p->hop, p->dim_f, p->dim_t,
-                           (const float2*)p->tw, (const float*)p->win, (const float*)p->env, j_lo, j_hi, kIstftRun,
+                           (const float2*)p->tw, (const float*)p->win, (const float*)p->env, j_lo, j_hi, run_g,
                            out + b0 * out_chunk_stride, out_ch_stride, out_chunk_stride, keep_lo, keep_hi,
                            out_limit - b0 * out_chunk_stride);
     }

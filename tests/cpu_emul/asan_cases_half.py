@@ -42,6 +42,23 @@ for over_time, L, n_seq in ((True, 301, 2), (True, 70, 3), (False, 33, 5), (Fals
                                          heads if over_time else L * heads, n_seq * heads if over_time else heads), "attention")
     assert torch.isfinite(out.float()).all()
     print("attention", over_time, L, n_seq, "ok", flush=True)
+# RMSNorm: the four-rows-per-wave kernel (rows % 16 != 0: the last wave's rows beyond the end read the last row) and the generic one
+for rows, C in ((1001, 384), (130, 512), (3, 384), (37, 96)):
+    x = torch.randn(rows, C, generator=g); gm = torch.ones(C); y = torch.zeros(rows, C, dtype=torch.float16)
+    ctx.check(lib.alsep_nn_rmsnorm_f16(h, _lib.ptr(x), _lib.ptr(y), _lib.ptr(gm), rows, C, C, C), "rmsnorm")
+    assert torch.isfinite(y.float()).all()
+    print("rmsnorm", rows, C, "ok", flush=True)
+# the persistent 7680 fused front end: 528 frames over 512 workgroups (16 of them walk two frames)
+from audiolab_amd.mdx import StftPlan  # noqa: E402
+from audiolab_amd.synth import synthetic_state_dict as _ssd  # noqa: E402
+from audiolab_amd.tdfnet import TDFNet as _TDFNet, TDFNetConfig as _Cfg  # noqa: E402
+c7 = _Cfg(dim_f=80, dim_t=8, n_fft=7680, hop=1024, num_blocks=1, g=48, bn=8)
+n7 = _TDFNet(c7, _ssd(c7, seed=2, calib="noise"), ctx=ctx, dtype=torch.float16, max_batch=66)
+p7 = StftPlan(ctx, c7.n_fft, c7.hop, c7.dim_f, c7.dim_t)
+tot7 = 65 * 1500 + p7.chunk_size + 17
+out7 = n7.forward_pcm(p7, torch.randn(2 * tot7, generator=g), tot7, 1500, 66)          # flat buffer: channel stride tot7, chunk stride 1500
+assert out7 is not None and torch.isfinite(out7.float()).all()
+print("fused 7680 persistent ok", flush=True)
 # split-half generic GEMM / convolution: a small HTDemucs forward with the contraction on
 from audiolab_amd.htdemucs import HTDemucs, HTDemucsConfig  # noqa: E402
 from oracle import htdemucs_oracle as ho  # noqa: E402
